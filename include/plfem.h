@@ -1,0 +1,168 @@
+/* plfem.h — C-ABI of libplfem_hip.so: the MI355X (gfx950) implementation of the vectorial H-field
+ * P2 FEM eigenmode path of KhaoulaAguech/pl-fem-vectoriel.
+ *
+ * The reference has no native boundary: the whole path is Python calling scikit-fem and SciPy
+ * (reference solver_fem.py:113-239).  Each entry point below names the reference statement(s) it
+ * replaces; the Python host (pl_fem_vectoriel_amd/solver_fem.py) binds them with ctypes and keeps
+ * the reference's class / method surface.  INTEGRATION.md shows the binding a maintainer of the
+ * reference would add.
+ *
+ * Conventions
+ *  - every function returns 0 on success and a negative PLFEM_E* code on failure; the message is
+ *    available from plfem_last_error(ctx) (or the err buffer for the context-free symbolic calls);
+ *    nothing throws across the boundary;
+ *  - all array arguments are caller-owned; "host" / "dev" in a parameter name says where the
+ *    pointer must live.  The library never frees caller memory;
+ *  - DOF order of all full-length vectors is the reference's block order (solver_fem.py:166):
+ *    x[0:N] = Hx DOFs, x[N:2N] = Hy DOFs, N = number of P2 DOFs including boundary DOFs, whose
+ *    entries are kept at zero (Dirichlet H = 0, solver_fem.py:179-182);
+ *  - all floating point data is IEEE double; indices are int32 (nnz < 2^31), offsets int64;
+ *  - a plfem_ctx owns one HIP stream's worth of state; contexts are independent (no globals),
+ *    one context must not be used from two threads at once.
+ */
+#ifndef PLFEM_H
+#define PLFEM_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PLFEM_OK 0
+#define PLFEM_EINVAL (-1)   /* bad argument / inconsistent sizes            -> ValueError   */
+#define PLFEM_EMESH (-2)    /* malformed mesh                               -> ValueError   */
+#define PLFEM_EHIP (-3)     /* HIP runtime error (message has the call)     -> RuntimeError */
+#define PLFEM_ENOCONV (-4)  /* Lanczos did not converge within maxiter      -> ArpackNoConvergence-like */
+#define PLFEM_ESTATE (-5)   /* call order violated (e.g. solve before factor) -> RuntimeError */
+#define PLFEM_ESINGULAR (-6)/* factorisation broke down (sigma is an eigenvalue) -> RuntimeError */
+
+typedef struct plfem_symbolic plfem_symbolic; /* host-only, mesh-only analysis               */
+typedef struct plfem_ctx plfem_ctx;           /* device + stream + workspaces for one symbolic */
+
+/* ---------------------------------------------------------------------------------------------
+ * Symbolic phase (host, no GPU needed).
+ * Replaces: Basis(mesh, ElementTriP2())            reference solver_fem.py:126
+ *           basis.get_dofs().all() / setdiff1d     reference solver_fem.py:179-180
+ *           sparsity work inside asm()/tocsr()     reference solver_fem.py:153-156
+ *           splu ordering + symbolic factorisation scipy arpack.py:915 via solver_fem.py:197
+ * p_host: [2][nv] doubles (x row, y row) = mesh.p; t_host: [3][ne] int32 = mesh.t.
+ * leaf_elems: target triangles per leaf front of the nested-dissection tree (<=0: default).
+ * ------------------------------------------------------------------------------------------- */
+int plfem_symbolic_create(int32_t nv, int32_t ne, const double* p_host, const int32_t* t_host,
+                          int32_t leaf_elems, int32_t nthreads, plfem_symbolic** out,
+                          char* err, int32_t errlen);
+void plfem_symbolic_destroy(plfem_symbolic* sym);
+
+/* info[] indices */
+enum {
+  PLFEM_INFO_NV = 0, PLFEM_INFO_NE, PLFEM_INFO_NEDGES, PLFEM_INFO_N, PLFEM_INFO_NSOLVE,
+  PLFEM_INFO_NNZ, PLFEM_INFO_LEVELS, PLFEM_INFO_NFRONTS, PLFEM_INFO_FRONT_DOUBLES,
+  PLFEM_INFO_MAX_FRONT, PLFEM_INFO_SOLVE_ENTRIES, PLFEM_INFO_FACTOR_FLOPS,
+  PLFEM_INFO_T_NUMBERING_US, PLFEM_INFO_T_PATTERN_US, PLFEM_INFO_T_TREE_US, PLFEM_INFO_T_FRONTS_US,
+  PLFEM_INFO_COUNT
+};
+int plfem_symbolic_info(const plfem_symbolic* sym, int64_t* info /* [PLFEM_INFO_COUNT] */);
+
+/* Copy a named host array out of the analysis (for the Python compatibility surface and tests).
+ * names: "edof"[6][ne] i32, "doflocs"[2][N] f64, "bmask"[N] u8, "interior"[nsolve] i32,
+ * "rowptr"[N+1] i32, "colind"[nnz] i32, "srcptr"[nnz+1] i32, "src"[36 ne] i32, "edges"[2][nedges] i32,
+ * "leaf_of_elem"[ne] i32, "owner"[N] i32, "fs","fb"[nfronts] i32, "fnode_ptr","foff"[nfronts+1] i64,
+ * "fnodes","cinv0","cinv1"[fnode_ptr[nfronts]] i32, "epos"[6][ne] i32.
+ * plfem_symbolic_array_bytes returns the size in bytes or a negative error. */
+int64_t plfem_symbolic_array_bytes(const plfem_symbolic* sym, const char* name);
+int plfem_symbolic_get(const plfem_symbolic* sym, const char* name, void* out_host, int64_t nbytes);
+
+/* ---------------------------------------------------------------------------------------------
+ * Context: binds a symbolic analysis to a device and stream, uploads the index structures and
+ * allocates every workspace (nothing is allocated later, so calls are graph-capturable).
+ * hip_stream: a hipStream_t (e.g. torch.cuda.current_stream().cuda_stream) or NULL for a private one.
+ * max_ncv: largest Lanczos basis the context must hold.
+ * ------------------------------------------------------------------------------------------- */
+int plfem_create(const plfem_symbolic* sym, int32_t device, void* hip_stream, int32_t max_ncv,
+                 plfem_ctx** out, char* err, int32_t errlen);
+void plfem_destroy(plfem_ctx* ctx);
+const char* plfem_last_error(const plfem_ctx* ctx);
+int plfem_synchronize(plfem_ctx* ctx);
+
+/* ---------------------------------------------------------------------------------------------
+ * Numeric assembly.
+ * Replaces: the nine @BilinearForm closures + 9 x asm()   reference solver_fem.py:131-156
+ *           geometry.epsilon at quadrature points          reference geometry_unified.py:325-336
+ *           block build A_xx..A_yy, B                      reference solver_fem.py:158-167
+ * cores_host: [ncore][3] = cx, cy, r (closed discs, later cores overwrite earlier ones — with two
+ * permittivities that is a union).  eps_core / eps_clad are n_core^2, n_clad^2 (the PML factor has
+ * no real part contribution: solver_fem.py:132 takes np.real).  alpha_p is the divergence penalty
+ * (solver_fem.py:158).  Fills the device CSR value arrays of the blocks
+ * Axx, Axy, Ayx, Ayy, Minv (= B_xx = B_yy), Dxx, Dxy, Dyy on the shared scalar pattern.
+ * ------------------------------------------------------------------------------------------- */
+int plfem_assemble_hfield(plfem_ctx* ctx, const double* cores_host, int32_t ncore, double eps_core,
+                          double eps_clad, double k0, double alpha_p);
+
+enum { PLFEM_BLK_AXX = 0, PLFEM_BLK_AXY, PLFEM_BLK_AYX, PLFEM_BLK_AYY, PLFEM_BLK_MINV,
+       PLFEM_BLK_DXX, PLFEM_BLK_DXY, PLFEM_BLK_DYY, PLFEM_BLK_COUNT };
+/* device pointer of a block's CSR values (length nnz), valid until plfem_destroy */
+int plfem_block_values_dev(plfem_ctx* ctx, int32_t block, const double** values_dev);
+/* copy a block's CSR values to the host (synchronises the stream) */
+int plfem_block_values_host(plfem_ctx* ctx, int32_t block, double* values_host);
+
+/* ---------------------------------------------------------------------------------------------
+ * CSR SpMV on the interior-restricted pencil, y = A_int x or y = B_int x embedded in 2N-vectors.
+ * Replaces: B @ x inside ARPACK's reverse communication (scipy arpack.py:568-569) and the
+ *           restriction A[idx,:][:,idx] (reference solver_fem.py:181-182) — boundary rows/cols masked.
+ * which: 0 = A, 1 = B.
+ * ------------------------------------------------------------------------------------------- */
+int plfem_spmv(plfem_ctx* ctx, int32_t which, const double* x_dev, double* y_dev);
+
+/* ---------------------------------------------------------------------------------------------
+ * Shift-invert operator.
+ * Replaces: splu((A - sigma B).tocsc())   scipy arpack.py:915 (via reference solver_fem.py:197)
+ *           lu.solve(rhs)                 scipy arpack.py:920-928
+ * Multifrontal block Gauss-Jordan factorisation of the symmetric indefinite K = A_int - sigma B_int
+ * on the nested-dissection front tree, all fronts dense in HBM; solve = two sweeps of batched
+ * dense panel products over the tree levels.  refine_steps extra iterative-refinement passes.
+ * ------------------------------------------------------------------------------------------- */
+int plfem_factor(plfem_ctx* ctx, double sigma);
+int plfem_solve(plfem_ctx* ctx, const double* rhs_dev, double* x_dev, int32_t refine_steps);
+
+/* ---------------------------------------------------------------------------------------------
+ * Eigen-solve.
+ * Replaces: eigsh(A_int, k, M=B_int, sigma=sigma, which='LM', tol, maxiter)
+ *           reference solver_fem.py:196-197 -> scipy arpack.py:1359-1700 (mode 3, bmat='G').
+ * Thick-restart Lanczos in the B inner product on OP = (A - sigma B)^-1 B with full (CGS2)
+ * re-orthogonalisation; returns the k eigenvalues nearest sigma (largest |1/(lambda - sigma)|),
+ * ascending, and B-orthonormal eigenvectors as 2N-vectors on the device.
+ * Requires plfem_assemble_hfield + plfem_factor(sigma) before the call.
+ * evals_host[k]; evecs_dev[k][2N] (row c = vector c); stats_host[8] (may be NULL):
+ *   [0] converged pairs, [1] OP applications, [2] restarts, [3] max relative Ritz residual.
+ * Returns PLFEM_ENOCONV if fewer than k pairs converged after maxiter OP applications (outputs
+ * still hold the current Ritz pairs, like ArpackNoConvergence.eigenvalues).
+ * ------------------------------------------------------------------------------------------- */
+int plfem_lanczos_shift_invert(plfem_ctx* ctx, int32_t k, int32_t ncv, double tol, int32_t maxiter,
+                               double sigma, double* evals_host, double* evecs_dev, double* stats_host);
+
+/* ---------------------------------------------------------------------------------------------
+ * Per-mode post-processing.
+ * Replaces: the per-mode loop of reference solver_fem.py:200-225 and _polarization_from_interp
+ *           (solver_fem.py:68-107): Euclidean normalisation, divergence energy with the interior
+ *           Dxx/Dxy/Dyy, core-mask sums.
+ * evecs_dev[k][2N] as returned by plfem_lanczos_shift_invert (normalised IN PLACE to
+ * sum(vx^2)+sum(vy^2) = 1 as solver_fem.py:213).  cores_host as in plfem_assemble_hfield.
+ * out_host[k][PLFEM_POST_COUNT]; frac_core_host = (#interior DOF nodes inside a core)/N_solve.
+ * modes_int_dev (may be NULL): [k][2*nsolve] interior-only copies (vx then vy) in the reference's
+ * 'Ex_dofs'/'Ey_dofs' layout.
+ * ------------------------------------------------------------------------------------------- */
+enum { PLFEM_POST_NORM = 0, PLFEM_POST_DIV_ENERGY, PLFEM_POST_CORE_X, PLFEM_POST_CORE_Y,
+       PLFEM_POST_ALL_X, PLFEM_POST_ALL_Y, PLFEM_POST_COUNT };
+int plfem_postprocess(plfem_ctx* ctx, int32_t k, double* evecs_dev, const double* cores_host,
+                      int32_t ncore, double* out_host, double* frac_core_host, double* modes_int_dev);
+
+/* timings of the last calls in microseconds (HIP events on the context's stream):
+ * [0] assemble, [1] factor, [2] lanczos, [3] postprocess, [4] upload; plus counters
+ * [5] pivot perturbations in the last factorisation. */
+int plfem_timings(plfem_ctx* ctx, double* out_host /* [8] */);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PLFEM_H */

@@ -1,0 +1,261 @@
+"""ctypes binding of ``libplfem_hip.so`` (C-ABI declared in ``include/plfem.h``).
+
+There is no CPU fallback: if the shared library is missing, or no HIP device is visible when a
+device context is requested, a ``RuntimeError`` is raised (the reference raises
+``RuntimeError("scikit-fem requis")`` when its backend is missing, ``solver_fem.py:115-116``).
+PyTorch is used only as the provider of device buffers and of the HIP stream.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import Optional
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libplfem_hip.so")
+
+PLFEM_OK = 0
+PLFEM_EINVAL, PLFEM_EMESH, PLFEM_EHIP, PLFEM_ENOCONV, PLFEM_ESTATE, PLFEM_ESINGULAR = -1, -2, -3, -4, -5, -6
+BLOCKS = ("Axx", "Axy", "Ayx", "Ayy", "Minv", "Dxx", "Dxy", "Dyy")
+INFO_NAMES = ("nv", "ne", "nedges", "N", "nsolve", "nnz", "levels", "nfronts", "front_doubles", "max_front",
+              "solve_entries", "factor_flops", "t_numbering_us", "t_pattern_us", "t_tree_us", "t_fronts_us")
+POST_NAMES = ("norm", "div_energy", "core_x", "core_y", "all_x", "all_y")
+
+# every symbol include/plfem.h declares (tests check the library exports all of them)
+EXPORTS = (
+    "plfem_symbolic_create", "plfem_symbolic_destroy", "plfem_symbolic_info", "plfem_symbolic_array_bytes",
+    "plfem_symbolic_get", "plfem_create", "plfem_destroy", "plfem_last_error", "plfem_synchronize",
+    "plfem_assemble_hfield", "plfem_block_values_dev", "plfem_block_values_host", "plfem_spmv", "plfem_factor",
+    "plfem_solve", "plfem_lanczos_shift_invert", "plfem_postprocess", "plfem_timings",
+)
+
+_ARRAY_DTYPES = {
+    "edof": np.int32, "tsorted": np.int32, "edges": np.int32, "doflocs": np.float64, "bmask": np.uint8,
+    "interior": np.int32, "int_index": np.int32, "rowptr": np.int32, "colind": np.int32, "srcptr": np.int32,
+    "src": np.int32, "leaf_of_elem": np.int32, "leaf_elem_ptr": np.int32, "leaf_elems": np.int32, "epos": np.int32,
+    "owner": np.int32, "fs": np.int32, "fb": np.int32, "fs_true": np.int32, "fb_true": np.int32,
+    "fnode_ptr": np.int64, "fnodes": np.int32, "cinv0": np.int32, "cinv1": np.int32, "foff": np.int64,
+}
+
+
+class ArpackLikeNoConvergence(RuntimeError):
+    """Raised when the Lanczos iteration does not converge (mirrors ``ArpackNoConvergence``)."""
+
+    def __init__(self, msg, eigenvalues=None, eigenvectors=None):
+        super().__init__(msg)
+        self.eigenvalues = eigenvalues
+        self.eigenvectors = eigenvectors
+
+
+_lib = None
+
+
+def load_library() -> ctypes.CDLL:
+    """Load ``libplfem_hip.so``; raise loudly if it has not been built (``__graft_entry__.build()``)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"libplfem_hip.so requis: {LIB_PATH} not found — build it with "
+            "`python -c 'import __graft_entry__ as g; g.build()'` (hipcc --offload-arch=gfx950). "
+            "There is no CPU fallback for the eigenmode path.")
+    lib = ctypes.CDLL(LIB_PATH)
+    c_void_pp = ctypes.POINTER(ctypes.c_void_p)
+    lib.plfem_symbolic_create.argtypes = [ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p,
+                                          ctypes.c_int32, ctypes.c_int32, c_void_pp, ctypes.c_char_p, ctypes.c_int32]
+    lib.plfem_symbolic_destroy.argtypes = [ctypes.c_void_p]
+    lib.plfem_symbolic_destroy.restype = None
+    lib.plfem_symbolic_info.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    lib.plfem_symbolic_array_bytes.argtypes = [ctypes.c_void_p, ctypes.c_char_p]
+    lib.plfem_symbolic_array_bytes.restype = ctypes.c_int64
+    lib.plfem_symbolic_get.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_void_p, ctypes.c_int64]
+    lib.plfem_create.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32, c_void_pp,
+                                 ctypes.c_char_p, ctypes.c_int32]
+    lib.plfem_destroy.argtypes = [ctypes.c_void_p]
+    lib.plfem_destroy.restype = None
+    lib.plfem_last_error.argtypes = [ctypes.c_void_p]
+    lib.plfem_last_error.restype = ctypes.c_char_p
+    lib.plfem_synchronize.argtypes = [ctypes.c_void_p]
+    lib.plfem_assemble_hfield.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_double,
+                                          ctypes.c_double, ctypes.c_double, ctypes.c_double]
+    lib.plfem_block_values_dev.argtypes = [ctypes.c_void_p, ctypes.c_int32, c_void_pp]
+    lib.plfem_block_values_host.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p]
+    lib.plfem_spmv.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]
+    lib.plfem_factor.argtypes = [ctypes.c_void_p, ctypes.c_double]
+    lib.plfem_solve.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32]
+    lib.plfem_lanczos_shift_invert.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_double,
+                                               ctypes.c_int32, ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p,
+                                               ctypes.c_void_p]
+    lib.plfem_postprocess.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p,
+                                      ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    lib.plfem_timings.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    _lib = lib
+    return lib
+
+
+def _ptr(a: np.ndarray):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+class Symbolic:
+    """Mesh-only analysis (P2 numbering, CSR pattern, front tree).  Host only — needs no GPU."""
+
+    def __init__(self, p, t, leaf_elems: int = 0, nthreads: int = 0):
+        lib = load_library()
+        p = np.ascontiguousarray(np.asarray(p, dtype=np.float64))
+        t = np.ascontiguousarray(np.asarray(t, dtype=np.int32))
+        if p.ndim != 2 or p.shape[0] != 2 or t.ndim != 2 or t.shape[0] != 3:
+            raise ValueError("mesh.p must be (2, nv) and mesh.t (3, ne)")
+        h = ctypes.c_void_p()
+        err = ctypes.create_string_buffer(512)
+        if nthreads <= 0:
+            nthreads = min(os.cpu_count() or 1, 8)
+        rc = lib.plfem_symbolic_create(p.shape[1], t.shape[1], _ptr(p), _ptr(t), int(leaf_elems), int(nthreads),
+                                       ctypes.byref(h), err, 512)
+        if rc != PLFEM_OK:
+            raise ValueError(f"plfem_symbolic_create failed ({rc}): {err.value.decode()}")
+        self._h = h
+        self._lib = lib
+        info = np.zeros(32, dtype=np.int64)
+        lib.plfem_symbolic_info(h, _ptr(info))
+        self.info = {k: int(info[i]) for i, k in enumerate(INFO_NAMES)}
+        for k in ("nv", "ne", "nedges", "N", "nsolve", "nnz"):
+            setattr(self, k, self.info[k])
+
+    def array(self, name: str) -> np.ndarray:
+        nb = self._lib.plfem_symbolic_array_bytes(self._h, name.encode())
+        if nb < 0:
+            raise KeyError(name)
+        out = np.empty(nb // np.dtype(_ARRAY_DTYPES[name]).itemsize, dtype=_ARRAY_DTYPES[name])
+        rc = self._lib.plfem_symbolic_get(self._h, name.encode(), _ptr(out), ctypes.c_int64(nb))
+        if rc != PLFEM_OK:
+            raise RuntimeError(f"plfem_symbolic_get({name}) failed: {rc}")
+        return out
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.plfem_symbolic_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Context:
+    """Device context bound to one :class:`Symbolic` (owns every device workspace)."""
+
+    def __init__(self, sym: Symbolic, device: Optional[int] = None, max_ncv: int = 65, use_torch_stream: bool = True):
+        import torch
+
+        lib = load_library()
+        if not torch.cuda.is_available():
+            raise RuntimeError("no HIP device visible: the eigenmode path has no CPU fallback")
+        if device is None:
+            device = torch.cuda.current_device()
+        self.torch = torch
+        self.device = int(device)
+        self.tdev = torch.device("cuda", self.device)
+        self.sym = sym          # keep the host analysis alive as long as the context
+        self._lib = lib
+        stream = torch.cuda.current_stream(self.tdev).cuda_stream if use_torch_stream else 0
+        h = ctypes.c_void_p()
+        err = ctypes.create_string_buffer(512)
+        rc = lib.plfem_create(sym._h, self.device, ctypes.c_void_p(stream), int(max_ncv), ctypes.byref(h), err, 512)
+        if rc != PLFEM_OK:
+            raise RuntimeError(f"plfem_create failed ({rc}): {err.value.decode()}")
+        self._h = h
+        self.max_ncv = int(max_ncv)
+        self.N = sym.N
+        self.n2 = 2 * sym.N
+
+    # -- helpers ----------------------------------------------------------------------------------
+    def _check(self, rc, what):
+        if rc == PLFEM_OK:
+            return
+        msg = self._lib.plfem_last_error(self._h).decode()
+        if rc in (PLFEM_EINVAL, PLFEM_EMESH):
+            raise ValueError(f"{what}: {msg}")
+        raise RuntimeError(f"{what} failed ({rc}): {msg}")
+
+    def _cores(self, cores):
+        c = np.ascontiguousarray(np.asarray(cores, dtype=np.float64).reshape(-1, 3))
+        return c, c.shape[0]
+
+    def empty(self, *shape):
+        return self.torch.empty(*shape, dtype=self.torch.float64, device=self.tdev)
+
+    # -- C-ABI calls ------------------------------------------------------------------------------
+    def assemble(self, cores, eps_core, eps_clad, k0, alpha_p=1.0):
+        c, n = self._cores(cores)
+        self._check(self._lib.plfem_assemble_hfield(self._h, _ptr(c), n, float(eps_core), float(eps_clad),
+                                                    float(k0), float(alpha_p)), "plfem_assemble_hfield")
+
+    def block_values(self, name: str) -> np.ndarray:
+        out = np.empty(self.sym.nnz, dtype=np.float64)
+        self._check(self._lib.plfem_block_values_host(self._h, BLOCKS.index(name), _ptr(out)), "plfem_block_values_host")
+        return out
+
+    def spmv(self, which: str, x):
+        y = self.empty(self.n2)
+        self._check(self._lib.plfem_spmv(self._h, 0 if which == "A" else 1, ctypes.c_void_p(x.data_ptr()),
+                                         ctypes.c_void_p(y.data_ptr())), "plfem_spmv")
+        return y
+
+    def factor(self, sigma: float):
+        self._check(self._lib.plfem_factor(self._h, float(sigma)), "plfem_factor")
+
+    def solve(self, rhs, refine_steps: int = 0):
+        x = self.empty(self.n2)
+        self._check(self._lib.plfem_solve(self._h, ctypes.c_void_p(rhs.data_ptr()), ctypes.c_void_p(x.data_ptr()),
+                                          int(refine_steps)), "plfem_solve")
+        return x
+
+    def lanczos(self, k, ncv, tol, maxiter, sigma):
+        evals = np.empty(k, dtype=np.float64)
+        evecs = self.empty(k, self.n2)
+        stats = np.zeros(8, dtype=np.float64)
+        rc = self._lib.plfem_lanczos_shift_invert(self._h, int(k), int(ncv), float(tol), int(maxiter), float(sigma),
+                                                  _ptr(evals), ctypes.c_void_p(evecs.data_ptr()), _ptr(stats))
+        st = {"nconv": int(stats[0]), "n_opinv": int(stats[1]), "restarts": int(stats[2]), "max_rel_res": float(stats[3])}
+        if rc == PLFEM_ENOCONV:
+            raise ArpackLikeNoConvergence(self._lib.plfem_last_error(self._h).decode(), evals, evecs)
+        self._check(rc, "plfem_lanczos_shift_invert")
+        return evals, evecs, st
+
+    def postprocess(self, evecs, cores, want_interior: bool = True):
+        k = evecs.shape[0]
+        c, n = self._cores(cores)
+        out = np.zeros((k, len(POST_NAMES)), dtype=np.float64)
+        frac = ctypes.c_double(0.0)
+        modes_int = self.empty(k, 2 * self.sym.nsolve) if want_interior else None
+        self._check(self._lib.plfem_postprocess(self._h, int(k), ctypes.c_void_p(evecs.data_ptr()), _ptr(c), n,
+                                                _ptr(out), ctypes.byref(frac),
+                                                ctypes.c_void_p(modes_int.data_ptr()) if want_interior else None),
+                    "plfem_postprocess")
+        return out, float(frac.value), modes_int
+
+    def timings(self):
+        t = np.zeros(8, dtype=np.float64)
+        self._check(self._lib.plfem_timings(self._h, _ptr(t)), "plfem_timings")
+        return {"assemble_us": t[0], "factor_us": t[1], "lanczos_us": t[2], "post_us": t[3], "upload_us": t[4],
+                "pivot_perturbations": int(t[5])}
+
+    def synchronize(self):
+        self._check(self._lib.plfem_synchronize(self._h), "plfem_synchronize")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.plfem_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

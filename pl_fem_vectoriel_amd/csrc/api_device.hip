@@ -1,0 +1,494 @@
+// C-ABI of the device half of libplfem_hip.so: context, assembly, SpMV, factor/solve, the
+// thick-restart Lanczos driver and post-processing (include/plfem.h).
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <numeric>
+
+#include "device.h"
+
+using plfem::LevelInfo;
+using plfem::Symbolic;
+
+#define HIP_TRY(ctx, call)                                                                   \
+  do {                                                                                       \
+    hipError_t e__ = (call);                                                                 \
+    if (e__ != hipSuccess) {                                                                 \
+      (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e__);                       \
+      return PLFEM_EHIP;                                                                     \
+    }                                                                                        \
+  } while (0)
+
+namespace {
+
+template <class T>
+int upload(plfem_ctx* c, T** dst, const std::vector<T>& src) {
+  size_t bytes = std::max<size_t>(src.size(), 1) * sizeof(T);
+  HIP_TRY(c, hipMalloc((void**)dst, bytes));
+  if (!src.empty()) HIP_TRY(c, hipMemcpyAsync(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice, c->stream));
+  return PLFEM_OK;
+}
+
+template <class T>
+int dalloc(plfem_ctx* c, T** dst, size_t count) {
+  HIP_TRY(c, hipMalloc((void**)dst, std::max<size_t>(count, 1) * sizeof(T)));
+  return PLFEM_OK;
+}
+
+#define TRY(x)                      \
+  do {                              \
+    int rc__ = (x);                 \
+    if (rc__ != PLFEM_OK) return rc__; \
+  } while (0)
+
+int check_launch(plfem_ctx* c, const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    c->err = std::string(what) + ": " + hipGetErrorString(e);
+    return PLFEM_EHIP;
+  }
+  return PLFEM_OK;
+}
+
+// cyclic Jacobi eigen-decomposition of a small dense symmetric matrix (n <= ~130).
+// A: n x n column major (destroyed), V: eigenvectors in columns, w: eigenvalues.
+void jacobi_eigh(int n, std::vector<double>& A, std::vector<double>& V, std::vector<double>& w) {
+  V.assign((size_t)n * n, 0.0);
+  for (int i = 0; i < n; ++i) V[(size_t)i * n + i] = 1.0;
+  auto a = [&](int i, int j) -> double& { return A[(size_t)j * n + i]; };
+  auto v = [&](int i, int j) -> double& { return V[(size_t)j * n + i]; };
+  for (int sweep = 0; sweep < 60; ++sweep) {
+    double off = 0.0, diag = 0.0;
+    for (int j = 0; j < n; ++j) {
+      diag += a(j, j) * a(j, j);
+      for (int i = 0; i < j; ++i) off += a(i, j) * a(i, j);
+    }
+    if (off <= 1e-34 * (diag + off) || off == 0.0) break;
+    for (int p = 0; p < n - 1; ++p)
+      for (int q = p + 1; q < n; ++q) {
+        double apq = a(p, q);
+        if (apq == 0.0) continue;
+        double app = a(p, p), aqq = a(q, q);
+        double tau = (aqq - app) / (2.0 * apq);
+        double t = (tau >= 0 ? 1.0 : -1.0) / (std::fabs(tau) + std::sqrt(1.0 + tau * tau));
+        double cs = 1.0 / std::sqrt(1.0 + t * t), sn = t * cs;
+        for (int k = 0; k < n; ++k) {
+          double akp = a(k, p), akq = a(k, q);
+          a(k, p) = cs * akp - sn * akq;
+          a(k, q) = sn * akp + cs * akq;
+        }
+        for (int k = 0; k < n; ++k) {
+          double apk = a(p, k), aqk = a(q, k);
+          a(p, k) = cs * apk - sn * aqk;
+          a(q, k) = sn * apk + cs * aqk;
+        }
+        for (int k = 0; k < n; ++k) {
+          double vkp = v(k, p), vkq = v(k, q);
+          v(k, p) = cs * vkp - sn * vkq;
+          v(k, q) = sn * vkp + cs * vkq;
+        }
+      }
+  }
+  w.resize(n);
+  for (int i = 0; i < n; ++i) w[i] = a(i, i);
+}
+
+void free_all(plfem_ctx* c) {
+  auto F = [](void* p) { if (p) (void)hipFree(p); };
+  F(c->d_tsorted); F(c->d_edof); F(c->d_rowptr); F(c->d_colind); F(c->d_srcptr); F(c->d_src); F(c->d_interior);
+  F(c->d_bmask); F(c->d_doflocs); F(c->d_fs2); F(c->d_fm); F(c->d_fnode_ptr); F(c->d_foff); F(c->d_fnodes);
+  F(c->d_cinv0); F(c->d_cinv1); F(c->d_epos); F(c->d_leaf_elem_ptr); F(c->d_leaf_elems); F(c->d_cores);
+  F(c->d_elem);
+  for (auto& p : c->d_vals) F(p);
+  F(c->d_front); F(c->d_fvec); F(c->d_wbuf); F(c->d_rbuf); F(c->d_dinv); F(c->d_counters);
+  F(c->d_V); F(c->d_BV); F(c->d_V2); F(c->d_BV2); F(c->d_w); F(c->d_bw); F(c->d_t1); F(c->d_t2);
+  F(c->d_h); F(c->d_hacc); F(c->d_partial); F(c->d_scal); F(c->d_S); F(c->d_Hcols); F(c->d_coremask); F(c->d_post);
+  if (c->h_pinned) (void)hipHostFree(c->h_pinned);
+  for (auto& pr : c->ev)
+    for (auto& e : pr)
+      if (e) (void)hipEventDestroy(e);
+  if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+}
+
+int create_impl(plfem_ctx* c, const plfem_symbolic* sym, int device, void* stream, int max_ncv) {
+  const Symbolic& S = sym->S;
+  c->S = &S;
+  c->device = device;
+  HIP_TRY(c, hipSetDevice(device));
+  if (stream) {
+    c->stream = (hipStream_t)stream;
+  } else {
+    HIP_TRY(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    c->own_stream = true;
+  }
+  for (int q = 0; q < 5; ++q)
+    for (int r = 0; r < 2; ++r) HIP_TRY(c, hipEventCreate(&c->ev[q][r]));
+  HIP_TRY(c, hipEventRecord(c->ev[4][0], c->stream));
+  c->nv = S.nv; c->ne = S.ne; c->N = S.N; c->nnz = (int)S.colind.size(); c->nsolve = S.nsolve;
+  c->L = S.L; c->nfronts = S.nfronts; c->n2 = 2 * (int64_t)S.N; c->max_ncv = max_ncv;
+  // per-front DOF counts + level table
+  std::vector<int32_t> fs2(S.nfronts), fm(S.nfronts);
+  for (int f = 0; f < S.nfronts; ++f) { fs2[f] = 2 * S.fs[f]; fm[f] = 2 * (S.fs[f] + S.fb[f]); }
+  c->levels.assign(S.L + 1, LevelInfo());
+  for (int lev = 0; lev <= S.L; ++lev) {
+    LevelInfo& li = c->levels[lev];
+    li.first = (1 << lev) - 1;
+    li.count = 1 << lev;
+    for (int f = li.first; f < li.first + li.count; ++f) {
+      li.max_m = std::max(li.max_m, fm[f]);
+      li.max_s2 = std::max(li.max_s2, fs2[f]);
+      li.max_b2 = std::max(li.max_b2, fm[f] - fs2[f]);
+    }
+    if (li.count > 65535) { c->err = "front tree level exceeds the launch grid limit"; return PLFEM_EINVAL; }
+  }
+  TRY(upload(c, &c->d_tsorted, S.tsorted));
+  TRY(upload(c, &c->d_edof, S.edof));
+  TRY(upload(c, &c->d_rowptr, S.rowptr));
+  TRY(upload(c, &c->d_colind, S.colind));
+  TRY(upload(c, &c->d_srcptr, S.srcptr));
+  TRY(upload(c, &c->d_src, S.src));
+  TRY(upload(c, &c->d_interior, S.interior));
+  TRY(upload(c, &c->d_bmask, S.bmask));
+  TRY(upload(c, &c->d_doflocs, S.doflocs));
+  TRY(upload(c, &c->d_fs2, fs2));
+  TRY(upload(c, &c->d_fm, fm));
+  TRY(upload(c, &c->d_fnode_ptr, S.fnode_ptr));
+  TRY(upload(c, &c->d_foff, S.foff));
+  TRY(upload(c, &c->d_fnodes, S.fnodes));
+  TRY(upload(c, &c->d_cinv0, S.cinv0));
+  TRY(upload(c, &c->d_cinv1, S.cinv1));
+  TRY(upload(c, &c->d_epos, S.epos));
+  TRY(upload(c, &c->d_leaf_elem_ptr, S.leaf_elem_ptr));
+  TRY(upload(c, &c->d_leaf_elems, S.leaf_elems));
+  TRY(dalloc(c, &c->d_cores, 64 * 3));
+  TRY(dalloc(c, &c->d_elem, (size_t)S.ne * plfem::ELEM_STRIDE));
+  for (auto& p : c->d_vals) TRY(dalloc(c, &p, (size_t)c->nnz));
+  const int64_t fnodes_total = S.fnode_ptr[S.nfronts];
+  TRY(dalloc(c, &c->d_front, (size_t)S.foff[S.nfronts]));
+  TRY(dalloc(c, &c->d_fvec, (size_t)2 * fnodes_total));
+  TRY(dalloc(c, &c->d_wbuf, (size_t)2 * fnodes_total * plfem::NB));
+  TRY(dalloc(c, &c->d_rbuf, (size_t)2 * fnodes_total * plfem::NB));
+  TRY(dalloc(c, &c->d_dinv, (size_t)S.nfronts * plfem::NB * plfem::NB));
+  TRY(dalloc(c, &c->d_counters, 4));
+  HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, 4 * sizeof(int32_t), c->stream));
+  const size_t n2 = (size_t)c->n2, nc1 = (size_t)max_ncv + 1;
+  TRY(dalloc(c, &c->d_V, n2 * nc1));
+  TRY(dalloc(c, &c->d_BV, n2 * nc1));
+  TRY(dalloc(c, &c->d_V2, n2 * nc1));
+  TRY(dalloc(c, &c->d_BV2, n2 * nc1));
+  TRY(dalloc(c, &c->d_w, n2));
+  TRY(dalloc(c, &c->d_bw, n2));
+  TRY(dalloc(c, &c->d_t1, n2));
+  TRY(dalloc(c, &c->d_t2, n2));
+  c->npartial = (int)((c->n2 + 2047) / 2048);
+  TRY(dalloc(c, &c->d_h, nc1 + 8));
+  TRY(dalloc(c, &c->d_hacc, nc1 + 8));
+  TRY(dalloc(c, &c->d_partial, (size_t)c->npartial * (nc1 + 8)));
+  TRY(dalloc(c, &c->d_scal, 16));
+  TRY(dalloc(c, &c->d_S, nc1 * nc1));
+  TRY(dalloc(c, &c->d_Hcols, (nc1 + 1) * (nc1 + 1)));
+  TRY(dalloc(c, &c->d_coremask, (size_t)S.N));
+  const size_t post_blocks = (size_t)(S.N + 255) / 256;
+  TRY(dalloc(c, &c->d_post, nc1 * post_blocks * 5 + nc1 * 5 + 16));
+  HIP_TRY(c, hipHostMalloc((void**)&c->h_pinned, sizeof(double) * (8192 + (nc1 + 1) * (nc1 + 1)), hipHostMallocDefault));
+  HIP_TRY(c, hipEventRecord(c->ev[4][1], c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  c->ev_used[4] = true;
+  return PLFEM_OK;
+}
+
+int upload_cores(plfem_ctx* c, const double* cores_host, int ncore) {
+  if (ncore < 0 || ncore > 64 || (ncore > 0 && !cores_host)) {
+    c->err = "ncore must be in [0, 64]";
+    return PLFEM_EINVAL;
+  }
+  if (ncore > 0) {
+    std::memcpy(c->h_pinned + 6144, cores_host, sizeof(double) * 3 * ncore);
+    HIP_TRY(c, hipMemcpyAsync(c->d_cores, c->h_pinned + 6144, sizeof(double) * 3 * ncore, hipMemcpyHostToDevice, c->stream));
+  }
+  return PLFEM_OK;
+}
+
+}  // namespace
+
+extern "C" int plfem_create(const plfem_symbolic* sym, int32_t device, void* hip_stream, int32_t max_ncv,
+                            plfem_ctx** out, char* err, int32_t errlen) {
+  if (!out) return PLFEM_EINVAL;
+  *out = nullptr;
+  auto fail = [&](const std::string& m, int code) {
+    if (err && errlen > 0) std::snprintf(err, (size_t)errlen, "%s", m.c_str());
+    return code;
+  };
+  if (!sym) return fail("plfem_create: null symbolic handle", PLFEM_EINVAL);
+  if (max_ncv < 3 || max_ncv > 160) return fail("plfem_create: max_ncv must be in [3, 160]", PLFEM_EINVAL);
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+    return fail("plfem_create: no HIP device available (this library has no CPU fallback)", PLFEM_EHIP);
+  if (device < 0 || device >= ndev) return fail("plfem_create: device index out of range", PLFEM_EINVAL);
+  plfem_ctx* c = new plfem_ctx();
+  int rc = create_impl(c, sym, device, hip_stream, max_ncv);
+  if (rc != PLFEM_OK) {
+    std::string m = c->err;
+    free_all(c);
+    delete c;
+    return fail(m, rc);
+  }
+  *out = c;
+  return PLFEM_OK;
+}
+
+extern "C" void plfem_destroy(plfem_ctx* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  free_all(ctx);
+  delete ctx;
+}
+
+extern "C" const char* plfem_last_error(const plfem_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+extern "C" int plfem_synchronize(plfem_ctx* ctx) {
+  if (!ctx) return PLFEM_EINVAL;
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return PLFEM_OK;
+}
+
+extern "C" int plfem_assemble_hfield(plfem_ctx* c, const double* cores_host, int32_t ncore, double eps_core,
+                                     double eps_clad, double k0, double alpha_p) {
+  if (!c) return PLFEM_EINVAL;
+  if (!(eps_core > 0) || !(eps_clad > 0)) { c->err = "permittivities must be positive"; return PLFEM_EINVAL; }
+  HIP_TRY(c, hipSetDevice(c->device));
+  TRY(upload_cores(c, cores_host, ncore));
+  HIP_TRY(c, hipEventRecord(c->ev[0][0], c->stream));
+  plfem::launch_element_matrices(c, ncore, eps_core, eps_clad, k0, alpha_p);
+  plfem::launch_csr_gather(c);
+  HIP_TRY(c, hipEventRecord(c->ev[0][1], c->stream));
+  c->ev_used[0] = true;
+  TRY(check_launch(c, "assemble"));
+  c->assembled = true;
+  c->factored = false;
+  c->k0 = k0;
+  return PLFEM_OK;
+}
+
+extern "C" int plfem_block_values_dev(plfem_ctx* c, int32_t block, const double** values_dev) {
+  if (!c || !values_dev || block < 0 || block >= PLFEM_BLK_COUNT) return PLFEM_EINVAL;
+  *values_dev = c->d_vals[block];
+  return PLFEM_OK;
+}
+
+extern "C" int plfem_block_values_host(plfem_ctx* c, int32_t block, double* values_host) {
+  if (!c || !values_host || block < 0 || block >= PLFEM_BLK_COUNT) return PLFEM_EINVAL;
+  if (!c->assembled) { c->err = "plfem_block_values_host before plfem_assemble_hfield"; return PLFEM_ESTATE; }
+  HIP_TRY(c, hipMemcpyAsync(values_host, c->d_vals[block], sizeof(double) * c->nnz, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return PLFEM_OK;
+}
+
+extern "C" int plfem_spmv(plfem_ctx* c, int32_t which, const double* x_dev, double* y_dev) {
+  if (!c || !x_dev || !y_dev || (which != 0 && which != 1)) return PLFEM_EINVAL;
+  if (!c->assembled) { c->err = "plfem_spmv before plfem_assemble_hfield"; return PLFEM_ESTATE; }
+  plfem::launch_spmv(c, which, x_dev, y_dev);
+  return check_launch(c, "spmv");
+}
+
+extern "C" int plfem_factor(plfem_ctx* c, double sigma) {
+  if (!c) return PLFEM_EINVAL;
+  if (!c->assembled) { c->err = "plfem_factor before plfem_assemble_hfield"; return PLFEM_ESTATE; }
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipEventRecord(c->ev[1][0], c->stream));
+  plfem::launch_factor(c, sigma);
+  HIP_TRY(c, hipEventRecord(c->ev[1][1], c->stream));
+  c->ev_used[1] = true;
+  TRY(check_launch(c, "factor"));
+  c->sigma = sigma;
+  c->factored = true;
+  return PLFEM_OK;
+}
+
+extern "C" int plfem_solve(plfem_ctx* c, const double* rhs_dev, double* x_dev, int32_t refine_steps) {
+  if (!c || !rhs_dev || !x_dev || refine_steps < 0) return PLFEM_EINVAL;
+  if (!c->factored) { c->err = "plfem_solve before plfem_factor"; return PLFEM_ESTATE; }
+  plfem::launch_solve(c, rhs_dev, x_dev);
+  for (int it = 0; it < refine_steps; ++it) {
+    // r = rhs - (A - sigma B) x ; x += K^-1 r
+    plfem::launch_spmv(c, 0, x_dev, c->d_t1);
+    plfem::launch_spmv(c, 1, x_dev, c->d_t2);
+    plfem::launch_axpby(c, -1.0, c->d_t1, c->sigma, c->d_t2, c->d_t1);   // t1 = -A x + sigma B x
+    plfem::launch_axpby(c, 1.0, rhs_dev, 1.0, c->d_t1, c->d_t1);          // t1 = rhs + t1
+    plfem::launch_solve(c, c->d_t1, c->d_t2);
+    plfem::launch_axpby(c, 1.0, x_dev, 1.0, c->d_t2, x_dev);
+  }
+  return check_launch(c, "solve");
+}
+
+// ------------------------------------------------------------------------------------------------
+// thick-restart Lanczos, shift-invert, B inner product
+// ------------------------------------------------------------------------------------------------
+extern "C" int plfem_lanczos_shift_invert(plfem_ctx* c, int32_t k, int32_t ncv, double tol, int32_t maxiter,
+                                          double sigma, double* evals_host, double* evecs_dev, double* stats_host) {
+  if (!c || !evals_host || !evecs_dev) return PLFEM_EINVAL;
+  if (!c->factored || c->sigma != sigma) { c->err = "plfem_lanczos_shift_invert: call plfem_factor(sigma) first"; return PLFEM_ESTATE; }
+  const int64_t n = c->n2;
+  if (k < 1 || ncv <= k || ncv > c->max_ncv || ncv > 2 * c->nsolve) { c->err = "need 1 <= k < ncv <= max_ncv"; return PLFEM_EINVAL; }
+  if (tol <= 0) tol = 2.2e-16;
+  HIP_TRY(c, hipSetDevice(c->device));
+  hipStream_t st = c->stream;
+  HIP_TRY(c, hipEventRecord(c->ev[2][0], st));
+  const int m = ncv;
+  const int ld = m + 1;
+  std::vector<double> T((size_t)ld * ld, 0.0);   // projected matrix (upper triangle authoritative)
+  double* hH = c->h_pinned + 8192;                // pinned mirror of d_Hcols
+  int nop = 0, restarts = 0;
+
+  // start vector: fixed pseudo-random interior field pushed through OP once (as ARPACK does for mode 3)
+  {
+    std::vector<double> v0((size_t)n, 0.0);
+    uint64_t s = 0x9E3779B97F4A7C15ull;
+    const Symbolic& S = *c->S;
+    for (int comp = 0; comp < 2; ++comp)
+      for (int q = 0; q < S.nsolve; ++q) {
+        s = s * 6364136223846793005ull + 1442695040888963407ull;
+        v0[(size_t)comp * S.N + S.interior[q]] = ((double)(s >> 11) / 9007199254740992.0) * 2.0 - 1.0;
+      }
+    HIP_TRY(c, hipMemcpyAsync(c->d_t1, v0.data(), sizeof(double) * n, hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipStreamSynchronize(st));
+    plfem::launch_spmv(c, 1, c->d_t1, c->d_bw);
+    plfem::launch_solve(c, c->d_bw, c->d_w);
+    ++nop;
+    plfem::launch_spmv(c, 1, c->d_w, c->d_bw);
+    plfem::launch_dot(c, c->d_w, c->d_bw, c->d_scal);
+    plfem::launch_scale_store(c, c->d_w, c->d_bw, c->d_scal, c->d_V, c->d_BV, nullptr);
+  }
+  HIP_TRY(c, hipMemsetAsync(c->d_Hcols, 0, sizeof(double) * ld * ld, st));
+
+  int j0 = 0;        // first Lanczos column to compute in this cycle
+  std::vector<double> theta, Svec, Tm;
+  std::vector<int> order;
+  int nconv = 0;
+  double max_rel_res = 0.0;
+  bool done = false;
+  while (true) {
+    for (int j = j0; j < m; ++j) {
+      double* Vj1 = c->d_V + (size_t)(j + 1) * n;
+      double* BVj1 = c->d_BV + (size_t)(j + 1) * n;
+      plfem::launch_solve(c, c->d_BV + (size_t)j * n, c->d_w);          // w = OP v_j = K^-1 B v_j
+      ++nop;
+      double* hcol = c->d_Hcols + (size_t)j * ld;
+      plfem::launch_panel_dot(c, c->d_BV, j + 1, c->d_w, hcol);          // h = V^T B w
+      plfem::launch_panel_axpy(c, c->d_V, j + 1, hcol, c->d_w);
+      plfem::launch_panel_dot(c, c->d_BV, j + 1, c->d_w, c->d_h);        // CGS2 second pass
+      plfem::launch_panel_axpy(c, c->d_V, j + 1, c->d_h, c->d_w);
+      plfem::launch_vec_add(c, hcol, c->d_h, j + 1);
+      plfem::launch_spmv(c, 1, c->d_w, c->d_bw);
+      plfem::launch_dot(c, c->d_w, c->d_bw, c->d_scal);
+      plfem::launch_scale_store(c, c->d_w, c->d_bw, c->d_scal, Vj1, BVj1, hcol + (j + 1));
+    }
+    TRY(check_launch(c, "lanczos step"));
+    HIP_TRY(c, hipMemcpyAsync(hH, c->d_Hcols, sizeof(double) * ld * ld, hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipStreamSynchronize(st));
+    for (int j = j0; j < m; ++j)
+      for (int i = 0; i <= j + 1 && i < ld; ++i) T[(size_t)j * ld + i] = hH[(size_t)j * ld + i];
+    const double beta_m = T[(size_t)(m - 1) * ld + m];
+    if (!std::isfinite(beta_m)) { c->err = "Lanczos breakdown: non-finite residual norm (is sigma an eigenvalue?)"; return PLFEM_ESINGULAR; }
+    // symmetric m x m projected matrix from the upper triangle
+    Tm.assign((size_t)m * m, 0.0);
+    for (int j = 0; j < m; ++j)
+      for (int i = 0; i <= j; ++i) {
+        double v = T[(size_t)j * ld + i];
+        Tm[(size_t)j * m + i] = v;
+        Tm[(size_t)i * m + j] = v;
+      }
+    jacobi_eigh(m, Tm, Svec, theta);
+    order.resize(m);
+    std::iota(order.begin(), order.end(), 0);
+    std::sort(order.begin(), order.end(), [&](int a, int b) { return std::fabs(theta[a]) > std::fabs(theta[b]); });
+    nconv = 0;
+    max_rel_res = 0.0;
+    for (int q = 0; q < k; ++q) {
+      int id = order[q];
+      double res = std::fabs(beta_m * Svec[(size_t)id * m + (m - 1)]);
+      double rel = res / std::max(std::fabs(theta[id]), 3.7e-11);
+      max_rel_res = std::max(max_rel_res, rel);
+      if (rel <= tol) ++nconv;
+    }
+    if (nconv >= k || restarts >= maxiter) { done = nconv >= k; break; }
+    // thick restart: keep the k wanted pairs plus some of the next ones (ARPACK: kev + min(nconv, np/2))
+    int p = k + std::min(nconv, (m - k) / 2);
+    p = std::max(p, k + (m - k) / 4);
+    p = std::min(p, m - 2);
+    std::vector<double> Ssel((size_t)m * p);
+    for (int q = 0; q < p; ++q)
+      std::memcpy(&Ssel[(size_t)q * m], &Svec[(size_t)order[q] * m], sizeof(double) * m);
+    std::memcpy(hH, Ssel.data(), sizeof(double) * m * p);
+    HIP_TRY(c, hipMemcpyAsync(c->d_S, hH, sizeof(double) * m * p, hipMemcpyHostToDevice, st));
+    plfem::launch_rotate(c, c->d_V, m, c->d_S, m, p, c->d_V2);
+    plfem::launch_rotate(c, c->d_BV, m, c->d_S, m, p, c->d_BV2);
+    HIP_TRY(c, hipMemcpyAsync(c->d_V2 + (size_t)p * n, c->d_V + (size_t)m * n, sizeof(double) * n, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(c, hipMemcpyAsync(c->d_BV2 + (size_t)p * n, c->d_BV + (size_t)m * n, sizeof(double) * n, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(c, hipStreamSynchronize(st));   // hH is reused below
+    std::swap(c->d_V, c->d_V2);
+    std::swap(c->d_BV, c->d_BV2);
+    std::fill(T.begin(), T.end(), 0.0);
+    for (int q = 0; q < p; ++q) T[(size_t)q * ld + q] = theta[order[q]];
+    HIP_TRY(c, hipMemsetAsync(c->d_Hcols, 0, sizeof(double) * ld * ld, st));
+    j0 = p;
+    ++restarts;
+  }
+  // wanted Ritz pairs, ascending lambda = sigma + 1/theta
+  std::vector<int> want(order.begin(), order.begin() + k);
+  std::vector<double> lam(m);
+  for (int i = 0; i < m; ++i) lam[i] = sigma + 1.0 / theta[i];
+  std::sort(want.begin(), want.end(), [&](int a, int b) { return lam[a] < lam[b]; });
+  for (int q = 0; q < k; ++q) {
+    evals_host[q] = lam[want[q]];
+    std::memcpy(hH + (size_t)q * m, &Svec[(size_t)want[q] * m], sizeof(double) * m);
+  }
+  HIP_TRY(c, hipMemcpyAsync(c->d_S, hH, sizeof(double) * m * k, hipMemcpyHostToDevice, st));
+  plfem::launch_rotate(c, c->d_V, m, c->d_S, m, k, evecs_dev);
+  HIP_TRY(c, hipEventRecord(c->ev[2][1], st));
+  c->ev_used[2] = true;
+  TRY(check_launch(c, "ritz rotation"));
+  HIP_TRY(c, hipStreamSynchronize(st));
+  if (stats_host) {
+    stats_host[0] = nconv;
+    stats_host[1] = nop;
+    stats_host[2] = restarts;
+    stats_host[3] = max_rel_res;
+  }
+  if (!done) {
+    c->err = "Lanczos: no convergence within maxiter restarts";
+    return PLFEM_ENOCONV;
+  }
+  return PLFEM_OK;
+}
+
+extern "C" int plfem_postprocess(plfem_ctx* c, int32_t k, double* evecs_dev, const double* cores_host, int32_t ncore,
+                                 double* out_host, double* frac_core_host, double* modes_int_dev) {
+  if (!c || !evecs_dev || !out_host || k < 1 || k > c->max_ncv) return PLFEM_EINVAL;
+  if (!c->assembled) { c->err = "plfem_postprocess before plfem_assemble_hfield"; return PLFEM_ESTATE; }
+  HIP_TRY(c, hipSetDevice(c->device));
+  TRY(upload_cores(c, cores_host, ncore));
+  HIP_TRY(c, hipEventRecord(c->ev[3][0], c->stream));
+  plfem::launch_post(c, k, evecs_dev, ncore, out_host, frac_core_host, modes_int_dev);
+  HIP_TRY(c, hipEventRecord(c->ev[3][1], c->stream));
+  c->ev_used[3] = true;
+  TRY(check_launch(c, "postprocess"));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return PLFEM_OK;
+}
+
+extern "C" int plfem_timings(plfem_ctx* c, double* out_host) {
+  if (!c || !out_host) return PLFEM_EINVAL;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  int32_t cnt[4] = {0, 0, 0, 0};
+  HIP_TRY(c, hipMemcpy(cnt, c->d_counters, sizeof(cnt), hipMemcpyDeviceToHost));
+  for (int q = 0; q < 5; ++q) {
+    float ms = 0;
+    if (c->ev_used[q] && hipEventElapsedTime(&ms, c->ev[q][0], c->ev[q][1]) == hipSuccess) c->timings[q] = ms * 1e3;
+  }
+  for (int i = 0; i < 8; ++i) out_host[i] = c->timings[i];
+  out_host[5] = cnt[0];
+  return PLFEM_OK;
+}

@@ -1,0 +1,120 @@
+// C-ABI of the host-only symbolic phase (include/plfem.h, "Symbolic phase").  No HIP here.
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+
+#include "../../include/plfem.h"
+#include "internal.h"
+
+using plfem::Symbolic;
+
+static void set_err(char* err, int32_t errlen, const std::string& msg) {
+  if (err && errlen > 0) {
+    std::snprintf(err, (size_t)errlen, "%s", msg.c_str());
+  }
+}
+
+extern "C" int plfem_symbolic_create(int32_t nv, int32_t ne, const double* p_host, const int32_t* t_host,
+                                     int32_t leaf_elems, int32_t nthreads, plfem_symbolic** out,
+                                     char* err, int32_t errlen) {
+  if (!out) return PLFEM_EINVAL;
+  *out = nullptr;
+  if (!p_host || !t_host || nv < 3 || ne < 1) {
+    set_err(err, errlen, "plfem_symbolic_create: empty mesh or null pointer");
+    return PLFEM_EINVAL;
+  }
+  plfem_symbolic* h = new (std::nothrow) plfem_symbolic();
+  if (!h) { set_err(err, errlen, "out of memory"); return PLFEM_EINVAL; }
+  std::string msg;
+  try {
+    msg = plfem::build_symbolic(nv, ne, p_host, t_host, leaf_elems <= 0 ? 24 : leaf_elems,
+                                nthreads <= 0 ? 1 : nthreads, h->S);
+  } catch (const std::exception& e) {
+    msg = std::string("exception in symbolic analysis: ") + e.what();
+  }
+  if (!msg.empty()) {
+    set_err(err, errlen, msg);
+    delete h;
+    return PLFEM_EMESH;
+  }
+  *out = h;
+  return PLFEM_OK;
+}
+
+extern "C" void plfem_symbolic_destroy(plfem_symbolic* sym) { delete sym; }
+
+extern "C" int plfem_symbolic_info(const plfem_symbolic* sym, int64_t* info) {
+  if (!sym || !info) return PLFEM_EINVAL;
+  const Symbolic& S = sym->S;
+  info[PLFEM_INFO_NV] = S.nv;
+  info[PLFEM_INFO_NE] = S.ne;
+  info[PLFEM_INFO_NEDGES] = S.nedges;
+  info[PLFEM_INFO_N] = S.N;
+  info[PLFEM_INFO_NSOLVE] = S.nsolve;
+  info[PLFEM_INFO_NNZ] = (int64_t)S.colind.size();
+  info[PLFEM_INFO_LEVELS] = S.L;
+  info[PLFEM_INFO_NFRONTS] = S.nfronts;
+  info[PLFEM_INFO_FRONT_DOUBLES] = S.foff.empty() ? 0 : S.foff.back();
+  info[PLFEM_INFO_MAX_FRONT] = S.max_m;
+  info[PLFEM_INFO_SOLVE_ENTRIES] = S.solve_entries;
+  info[PLFEM_INFO_FACTOR_FLOPS] = (int64_t)S.factor_flops;
+  info[PLFEM_INFO_T_NUMBERING_US] = (int64_t)(S.t_numbering * 1e6);
+  info[PLFEM_INFO_T_PATTERN_US] = (int64_t)(S.t_pattern * 1e6);
+  info[PLFEM_INFO_T_TREE_US] = (int64_t)(S.t_tree * 1e6);
+  info[PLFEM_INFO_T_FRONTS_US] = (int64_t)(S.t_fronts * 1e6);
+  return PLFEM_OK;
+}
+
+namespace {
+struct ArrayRef { const void* ptr; int64_t bytes; };
+template <class T>
+ArrayRef ref(const std::vector<T>& v) { return {v.data(), (int64_t)(v.size() * sizeof(T))}; }
+
+bool lookup(const Symbolic& S, const char* name, ArrayRef& r) {
+  std::string n(name ? name : "");
+  if (n == "edof") r = ref(S.edof);
+  else if (n == "tsorted") r = ref(S.tsorted);
+  else if (n == "edges") r = ref(S.edges);
+  else if (n == "doflocs") r = ref(S.doflocs);
+  else if (n == "bmask") r = ref(S.bmask);
+  else if (n == "interior") r = ref(S.interior);
+  else if (n == "int_index") r = ref(S.int_index);
+  else if (n == "rowptr") r = ref(S.rowptr);
+  else if (n == "colind") r = ref(S.colind);
+  else if (n == "srcptr") r = ref(S.srcptr);
+  else if (n == "src") r = ref(S.src);
+  else if (n == "leaf_of_elem") r = ref(S.leaf_of_elem);
+  else if (n == "leaf_elem_ptr") r = ref(S.leaf_elem_ptr);
+  else if (n == "leaf_elems") r = ref(S.leaf_elems);
+  else if (n == "epos") r = ref(S.epos);
+  else if (n == "owner") r = ref(S.owner);
+  else if (n == "fs") r = ref(S.fs);
+  else if (n == "fb") r = ref(S.fb);
+  else if (n == "fs_true") r = ref(S.fs_true);
+  else if (n == "fb_true") r = ref(S.fb_true);
+  else if (n == "fnode_ptr") r = ref(S.fnode_ptr);
+  else if (n == "fnodes") r = ref(S.fnodes);
+  else if (n == "cinv0") r = ref(S.cinv0);
+  else if (n == "cinv1") r = ref(S.cinv1);
+  else if (n == "foff") r = ref(S.foff);
+  else return false;
+  return true;
+}
+}  // namespace
+
+extern "C" int64_t plfem_symbolic_array_bytes(const plfem_symbolic* sym, const char* name) {
+  if (!sym) return PLFEM_EINVAL;
+  ArrayRef r;
+  if (!lookup(sym->S, name, r)) return PLFEM_EINVAL;
+  return r.bytes;
+}
+
+extern "C" int plfem_symbolic_get(const plfem_symbolic* sym, const char* name, void* out_host, int64_t nbytes) {
+  if (!sym || !out_host) return PLFEM_EINVAL;
+  ArrayRef r;
+  if (!lookup(sym->S, name, r)) return PLFEM_EINVAL;
+  if (r.bytes != nbytes) return PLFEM_EINVAL;
+  std::memcpy(out_host, r.ptr, (size_t)nbytes);
+  return PLFEM_OK;
+}

@@ -1,0 +1,93 @@
+// Device-side context of libplfem_hip.so (gfx950).  Internal header.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/plfem.h"
+#include "internal.h"
+
+namespace plfem {
+
+constexpr int NB = 32;          // pivot-block width of the block Gauss-Jordan sweep
+constexpr int ELEM_FORMS = 8;   // Axx Axy Ayx Ayy Minv Dxx Dxy Dyy
+constexpr int ELEM_STRIDE = ELEM_FORMS * 36;
+
+struct LevelInfo {
+  int first = 0;    // first front id of the level (heap order)
+  int count = 0;
+  int max_m = 0;    // DOFs
+  int max_s2 = 0;
+  int max_b2 = 0;
+};
+
+}  // namespace plfem
+
+struct plfem_ctx {
+  const plfem::Symbolic* S = nullptr;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  std::string err;
+  // sizes
+  int nv = 0, ne = 0, N = 0, nnz = 0, nsolve = 0, L = 0, nfronts = 0, max_ncv = 0;
+  int64_t n2 = 0;   // 2N
+  std::vector<plfem::LevelInfo> levels;
+  // ---- index structures on the device
+  int32_t *d_tsorted = nullptr, *d_edof = nullptr, *d_rowptr = nullptr, *d_colind = nullptr;
+  int32_t *d_srcptr = nullptr, *d_src = nullptr, *d_interior = nullptr;
+  uint8_t* d_bmask = nullptr;
+  double* d_doflocs = nullptr;
+  int32_t *d_fs2 = nullptr, *d_fm = nullptr;          // per front: owned DOFs (2 fs), front order m = 2 (fs + fb)
+  int64_t *d_fnode_ptr = nullptr, *d_foff = nullptr;
+  int32_t *d_fnodes = nullptr, *d_cinv0 = nullptr, *d_cinv1 = nullptr;
+  int32_t *d_epos = nullptr, *d_leaf_elem_ptr = nullptr, *d_leaf_elems = nullptr;
+  // ---- numeric data
+  double* d_cores = nullptr;      // [64][3]
+  double* d_elem = nullptr;       // [ne][8][36]
+  double* d_vals[PLFEM_BLK_COUNT] = {nullptr};
+  double* d_front = nullptr;      // dense fronts
+  double* d_fvec = nullptr;       // per-front solve vectors, offset 2*fnode_ptr[f]
+  double *d_wbuf = nullptr, *d_rbuf = nullptr;   // per-front panels m x NB, offset 2*fnode_ptr[f]*NB
+  double* d_dinv = nullptr;       // per-front NB x NB
+  int32_t* d_counters = nullptr;  // [0] pivot perturbations
+  // ---- Lanczos workspace
+  double *d_V = nullptr, *d_BV = nullptr, *d_V2 = nullptr, *d_BV2 = nullptr;   // n2 x (max_ncv+1), column major
+  double *d_w = nullptr, *d_bw = nullptr, *d_t1 = nullptr, *d_t2 = nullptr;    // n2
+  double *d_h = nullptr, *d_hacc = nullptr, *d_partial = nullptr, *d_scal = nullptr, *d_S = nullptr;
+  double* d_Hcols = nullptr;      // (max_ncv+1) x (max_ncv+1) projected matrix columns
+  uint8_t* d_coremask = nullptr;  // [N]
+  double* d_post = nullptr;       // post-processing partial sums
+  int npartial = 0;
+  double* h_pinned = nullptr;     // pinned staging
+  // state
+  bool assembled = false, factored = false;
+  double sigma = 0.0, k0 = 0.0;
+  hipEvent_t ev[5][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
+  bool ev_used[5] = {false, false, false, false, false};
+  double timings[8] = {0};
+};
+
+namespace plfem {
+
+// kernels_assembly.hip
+void launch_element_matrices(plfem_ctx* c, int ncore, double eps_core, double eps_clad, double k0, double alpha_p);
+void launch_csr_gather(plfem_ctx* c);
+void launch_spmv(plfem_ctx* c, int which, const double* x, double* y);
+// kernels_front.hip
+void launch_factor(plfem_ctx* c, double sigma);
+void launch_solve(plfem_ctx* c, const double* rhs, double* x);
+// kernels_lanczos.hip
+void launch_panel_dot(plfem_ctx* c, const double* P, int ncols, const double* w, double* h);   // h = P^T w
+void launch_panel_axpy(plfem_ctx* c, const double* P, int ncols, const double* h, double* w);  // w -= P h
+void launch_dot(plfem_ctx* c, const double* a, const double* b, double* out);                  // *out = a.b
+void launch_vec_add(plfem_ctx* c, double* acc, const double* h, int n);                        // acc += h
+void launch_scale_store(plfem_ctx* c, const double* w, const double* bw, const double* beta2, double* v, double* bv,
+                        double* beta_out);  // v = w/sqrt(beta2), bv = bw/sqrt(beta2)
+void launch_axpby(plfem_ctx* c, double a, const double* x, double b, const double* y, double* z);  // z = a x + b y
+void launch_rotate(plfem_ctx* c, const double* V, int m, const double* Smat, int ldS, int p, double* out);  // out = V[:, :m] S
+void launch_post(plfem_ctx* c, int k, double* evecs, int ncore, double* out_host, double* frac_core, double* modes_int);
+
+}  // namespace plfem

@@ -1,0 +1,205 @@
+// gfx950 kernels: P2 element-batch bilinear forms, ordered COO->CSR gather, block CSR SpMV.
+//
+// Replaces the nine scikit-fem BilinearForm closures + asm() calls of the reference
+// (solver_fem.py:131-156), geometry.epsilon at the quadrature points (geometry_unified.py:325-336,
+// real part only) and the block build solver_fem.py:158-167.
+#include "device.h"
+
+namespace plfem {
+namespace {
+
+// 6-point degree-4 rule on the reference triangle (weights sum to 1/2) — scikit-fem's default
+// intorder = 2*maxdeg = 4 for ElementTriP2.
+__constant__ double c_qx[6] = {0.445948490915965, 0.10810301816807, 0.445948490915965,
+                               0.091576213509771, 0.816847572980458, 0.091576213509771};
+__constant__ double c_qy[6] = {0.445948490915965, 0.445948490915965, 0.10810301816807,
+                               0.091576213509771, 0.091576213509771, 0.816847572980458};
+__constant__ double c_qw[6] = {0.1116907948390055, 0.1116907948390055, 0.1116907948390055,
+                               0.054975871827661, 0.054975871827661, 0.054975871827661};
+
+constexpr int EPB = 7;   // elements per 256-thread block: 7*36 = 252 (i,j) pairs
+
+// One block = EPB elements.  Phase 1 (element, quadrature point) lanes stage the physical
+// gradients of the six P2 basis functions and the two quadrature weights (plain and 1/eps) in LDS;
+// phase 2 (element, local pair) lanes reduce the six quadrature points into the eight element
+// matrices the pencil needs and store them as contiguous 288-B runs.
+__global__ __launch_bounds__(256) void k_element_matrices(
+    int ne, int N, const int32_t* __restrict__ tsorted, const double* __restrict__ doflocs,
+    const double* __restrict__ cores, int ncore, double inv_eps_core, double inv_eps_clad, double k0sq,
+    double alpha_p, double* __restrict__ elem) {
+  __shared__ double s_phi[6][6];            // [basis][qp]
+  __shared__ double s_gx[EPB][6][6];        // [el][basis][qp]
+  __shared__ double s_gy[EPB][6][6];
+  __shared__ double s_w1[EPB][6];
+  __shared__ double s_we[EPB][6];
+  const int tid = threadIdx.x;
+  const int e0 = blockIdx.x * EPB;
+  if (tid < 36) {
+    int i = tid / 6, q = tid % 6;
+    double x = c_qx[q], y = c_qy[q], v;
+    switch (i) {
+      case 0: v = 1 - 3 * x - 3 * y + 2 * x * x + 4 * x * y + 2 * y * y; break;
+      case 1: v = 2 * x * x - x; break;
+      case 2: v = 2 * y * y - y; break;
+      case 3: v = 4 * x - 4 * x * x - 4 * x * y; break;
+      case 4: v = 4 * x * y; break;
+      default: v = 4 * y - 4 * x * y - 4 * y * y; break;
+    }
+    s_phi[i][q] = v;
+  }
+  if (tid < EPB * 6) {
+    int el = tid / 6, q = tid % 6;
+    int e = e0 + el;
+    if (e < ne) {
+      int v0 = tsorted[e], v1 = tsorted[ne + e], v2 = tsorted[2 * (size_t)ne + e];
+      double x0 = doflocs[v0], y0 = doflocs[N + v0];
+      double j00 = doflocs[v1] - x0, j10 = doflocs[N + v1] - y0;      // J = [p1-p0, p2-p0]
+      double j01 = doflocs[v2] - x0, j11 = doflocs[N + v2] - y0;
+      double det = j00 * j11 - j01 * j10;
+      double idet = 1.0 / det;
+      // J^-1 = 1/det [[j11, -j01], [-j10, j00]];  grad = J^-T grad_hat
+      double i00 = j11 * idet, i01 = -j01 * idet, i10 = -j10 * idet, i11 = j00 * idet;
+      double xi = c_qx[q], eta = c_qy[q];
+      double X = x0 + j00 * xi + j01 * eta, Y = y0 + j10 * xi + j11 * eta;
+      bool in_core = false;
+      for (int c = 0; c < ncore; ++c) {
+        double dx = X - cores[3 * c], dy = Y - cores[3 * c + 1], r = cores[3 * c + 2];
+        in_core |= (dx * dx + dy * dy <= r * r);
+      }
+      double w1 = fabs(det) * c_qw[q];
+      s_w1[el][q] = w1;
+      s_we[el][q] = w1 * (in_core ? inv_eps_core : inv_eps_clad);
+      double dxh[6] = {-3 + 4 * xi + 4 * eta, 4 * xi - 1, 0.0, 4 - 8 * xi - 4 * eta, 4 * eta, -4 * eta};
+      double dyh[6] = {-3 + 4 * xi + 4 * eta, 0.0, 4 * eta - 1, -4 * xi, 4 * xi, 4 - 4 * xi - 8 * eta};
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        s_gx[el][i][q] = i00 * dxh[i] + i10 * dyh[i];
+        s_gy[el][i][q] = i01 * dxh[i] + i11 * dyh[i];
+      }
+    }
+  }
+  __syncthreads();
+  if (tid < EPB * 36) {
+    int el = tid / 36, ab = tid % 36;
+    int e = e0 + el;
+    if (e < ne) {
+      int a = ab / 6, b = ab % 6;   // a = test / row i, b = trial / column j
+      double m1 = 0, me = 0, xx1 = 0, yy1 = 0, xy1 = 0, yx1 = 0, xxe = 0, yye = 0, xye = 0, yxe = 0;
+#pragma unroll
+      for (int q = 0; q < 6; ++q) {
+        double w1 = s_w1[el][q], we = s_we[el][q];
+        double pa = s_phi[a][q], pb = s_phi[b][q];
+        double gxa = s_gx[el][a][q], gya = s_gy[el][a][q];
+        double gxb = s_gx[el][b][q], gyb = s_gy[el][b][q];
+        double pp = pa * pb;
+        m1 += pp * w1;
+        me += pp * we;
+        double txx = gxb * gxa, tyy = gyb * gya, txy = gxb * gya, tyx = gyb * gxa;   // d?phi_b(trial) d?phi_a(test)
+        xx1 += txx * w1; yy1 += tyy * w1; xy1 += txy * w1; yx1 += tyx * w1;
+        xxe += txx * we; yye += tyy * we; xye += txy * we; yxe += tyx * we;
+      }
+      double* o = elem + (size_t)e * ELEM_STRIDE + ab;
+      // kxx = e^-1 u_y v_y, kyy = e^-1 u_x v_x, kxy = -e^-1 u_y v_x, kyx = -e^-1 u_x v_y  (solver_fem.py:132-138)
+      // div_xx = u_x v_x, div_yy = u_y v_y, div_xy = u_x v_y                                (solver_fem.py:141-145)
+      o[PLFEM_BLK_AXX * 36] = yye + alpha_p * xx1 - k0sq * m1;     // Kxx + a Dxx - k0^2 M
+      o[PLFEM_BLK_AXY * 36] = -yxe + alpha_p * xy1;                // Kxy + a Dxy
+      o[PLFEM_BLK_AYX * 36] = -xye + alpha_p * yx1;                // Kyx + a Dxy^T
+      o[PLFEM_BLK_AYY * 36] = xxe + alpha_p * yy1 - k0sq * m1;     // Kyy + a Dyy - k0^2 M
+      o[PLFEM_BLK_MINV * 36] = me;
+      o[PLFEM_BLK_DXX * 36] = xx1;
+      o[PLFEM_BLK_DXY * 36] = xy1;
+      o[PLFEM_BLK_DYY * 36] = yy1;
+    }
+  }
+}
+
+// Ordered gather of the element-matrix entries into the shared scalar CSR pattern: one lane per CSR
+// slot sums its contribution list in a fixed (element-ascending) order — deterministic, no float
+// atomics.  Replaces coo_matrix(...).tocsr() duplicate summation.
+__global__ __launch_bounds__(256) void k_csr_gather(int nnz, const int32_t* __restrict__ srcptr,
+                                                    const int32_t* __restrict__ src, const double* __restrict__ elem,
+                                                    double* __restrict__ v0, double* __restrict__ v1,
+                                                    double* __restrict__ v2, double* __restrict__ v3,
+                                                    double* __restrict__ v4, double* __restrict__ v5,
+                                                    double* __restrict__ v6, double* __restrict__ v7) {
+  int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= nnz) return;
+  double acc[ELEM_FORMS] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int q0 = srcptr[k], q1 = srcptr[k + 1];
+  for (int q = q0; q < q1; ++q) {
+    int s = src[q];
+    int e = s / 36, ab = s - e * 36;
+    const double* p = elem + (size_t)e * ELEM_STRIDE + ab;
+#pragma unroll
+    for (int f = 0; f < ELEM_FORMS; ++f) acc[f] += p[f * 36];
+  }
+  v0[k] = acc[0]; v1[k] = acc[1]; v2[k] = acc[2]; v3[k] = acc[3];
+  v4[k] = acc[4]; v5[k] = acc[5]; v6[k] = acc[6]; v7[k] = acc[7];
+}
+
+// y = A_int x (which = 0) or y = B_int x (which = 1) on 2N-vectors; Dirichlet rows forced to zero,
+// Dirichlet columns are zero in x by construction.  8 lanes per scalar row (avg 11.5 nnz / row),
+// both field components of the row computed in the same pass over the shared pattern.
+template <int WHICH>
+__global__ __launch_bounds__(256) void k_spmv(int N, const int32_t* __restrict__ rowptr,
+                                              const int32_t* __restrict__ colind, const uint8_t* __restrict__ bmask,
+                                              const double* __restrict__ vxx, const double* __restrict__ vxy,
+                                              const double* __restrict__ vyx, const double* __restrict__ vyy,
+                                              const double* __restrict__ x, double* __restrict__ y) {
+  int gt = blockIdx.x * blockDim.x + threadIdx.x;
+  int row = gt >> 3, sub = gt & 7;
+  double sx = 0, sy = 0;
+  if (row < N && !bmask[row]) {
+    int q0 = rowptr[row], q1 = rowptr[row + 1];
+    for (int q = q0 + sub; q < q1; q += 8) {
+      int c = colind[q];
+      double xx = x[c], xy = x[N + c];
+      if (WHICH == 0) {
+        sx += vxx[q] * xx + vxy[q] * xy;
+        sy += vyx[q] * xx + vyy[q] * xy;
+      } else {
+        double mv = vxx[q];
+        sx += mv * xx;
+        sy += mv * xy;
+      }
+    }
+  }
+#pragma unroll
+  for (int off = 4; off >= 1; off >>= 1) {
+    sx += __shfl_xor(sx, off, 8);
+    sy += __shfl_xor(sy, off, 8);
+  }
+  if (row < N && sub == 0) {
+    y[row] = sx;
+    y[N + row] = sy;
+  }
+}
+
+}  // namespace
+
+void launch_element_matrices(plfem_ctx* c, int ncore, double eps_core, double eps_clad, double k0, double alpha_p) {
+  int grid = (c->ne + EPB - 1) / EPB;
+  hipLaunchKernelGGL(k_element_matrices, dim3(grid), dim3(256), 0, c->stream, c->ne, c->N, c->d_tsorted,
+                     c->d_doflocs, c->d_cores, ncore, 1.0 / eps_core, 1.0 / eps_clad, k0 * k0, alpha_p, c->d_elem);
+}
+
+void launch_csr_gather(plfem_ctx* c) {
+  int grid = (c->nnz + 255) / 256;
+  hipLaunchKernelGGL(k_csr_gather, dim3(grid), dim3(256), 0, c->stream, c->nnz, c->d_srcptr, c->d_src, c->d_elem,
+                     c->d_vals[0], c->d_vals[1], c->d_vals[2], c->d_vals[3], c->d_vals[4], c->d_vals[5],
+                     c->d_vals[6], c->d_vals[7]);
+}
+
+void launch_spmv(plfem_ctx* c, int which, const double* x, double* y) {
+  int64_t threads = (int64_t)c->N * 8;
+  int grid = (int)((threads + 255) / 256);
+  if (which == 0)
+    hipLaunchKernelGGL(k_spmv<0>, dim3(grid), dim3(256), 0, c->stream, c->N, c->d_rowptr, c->d_colind, c->d_bmask,
+                       c->d_vals[PLFEM_BLK_AXX], c->d_vals[PLFEM_BLK_AXY], c->d_vals[PLFEM_BLK_AYX],
+                       c->d_vals[PLFEM_BLK_AYY], x, y);
+  else
+    hipLaunchKernelGGL(k_spmv<1>, dim3(grid), dim3(256), 0, c->stream, c->N, c->d_rowptr, c->d_colind, c->d_bmask,
+                       c->d_vals[PLFEM_BLK_MINV], nullptr, nullptr, nullptr, x, y);
+}
+
+}  // namespace plfem

@@ -1,0 +1,287 @@
+// gfx950 kernels: tall-skinny panel products for the B-orthogonal Lanczos basis, Ritz rotation,
+// per-mode post-processing.  All reductions are two-stage with a fixed summation order
+// (deterministic; no float atomics).
+//
+// Replaces the re-orthogonalisation / Ritz-vector work ARPACK does inside dsaupd / dseupd
+// (scipy arpack.py:542-602, reached from reference solver_fem.py:197) and the per-mode loop of
+// reference solver_fem.py:200-225.
+#include "device.h"
+
+namespace plfem {
+namespace {
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+constexpr int CHUNK = 2048;   // rows per partial sum
+
+// partial[c * nchunks + chunk] = sum_{i in chunk} P[i, c] * w[i];  one wave per (chunk, column)
+__global__ __launch_bounds__(256) void k_panel_dot(int64_t n, int ncols, int nchunks, const double* __restrict__ P,
+                                                   const double* __restrict__ w, double* __restrict__ partial) {
+  const int c = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (c >= ncols) return;
+  const int lane = threadIdx.x & 63;
+  const int64_t i0 = (int64_t)blockIdx.x * CHUNK;
+  const int64_t i1 = min(n, i0 + CHUNK);
+  const double* col = P + (int64_t)c * n;
+  double acc = 0.0;
+  for (int64_t i = i0 + lane; i < i1; i += 64) acc += col[i] * w[i];
+  for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
+  if (lane == 0) partial[(int64_t)c * nchunks + blockIdx.x] = acc;
+}
+
+__global__ __launch_bounds__(256) void k_panel_dot_finish(int ncols, int nchunks, const double* __restrict__ partial,
+                                                          double* __restrict__ h) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= ncols) return;
+  double acc = 0.0;
+  for (int q = 0; q < nchunks; ++q) acc += partial[(int64_t)c * nchunks + q];
+  h[c] = acc;
+}
+
+// w[i] -= sum_c P[i, c] h[c]
+__global__ __launch_bounds__(256) void k_panel_axpy(int64_t n, int ncols, const double* __restrict__ P,
+                                                    const double* __restrict__ h, double* __restrict__ w) {
+  __shared__ double sh[192];
+  for (int c = threadIdx.x; c < ncols; c += 256) sh[c] = h[c];
+  __syncthreads();
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  double acc = 0.0;
+  for (int c = 0; c < ncols; ++c) acc += P[(int64_t)c * n + i] * sh[c];
+  w[i] -= acc;
+}
+
+__global__ void k_vec_add(int n, double* __restrict__ acc, const double* __restrict__ h) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) acc[i] += h[i];
+}
+
+// v = w / sqrt(beta2), bv = bw / sqrt(beta2); beta written to *beta_out
+__global__ __launch_bounds__(256) void k_scale_store(int64_t n, const double* __restrict__ w,
+                                                     const double* __restrict__ bw, const double* __restrict__ beta2,
+                                                     double* __restrict__ v, double* __restrict__ bv,
+                                                     double* __restrict__ beta_out) {
+  const double b2 = *beta2;
+  const double beta = sqrt(fmax(b2, 0.0));
+  const double inv = beta > 0.0 ? 1.0 / beta : 0.0;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i == 0 && beta_out) *beta_out = beta;
+  if (i >= n) return;
+  v[i] = w[i] * inv;
+  bv[i] = bw[i] * inv;
+}
+
+__global__ __launch_bounds__(256) void k_axpby(int64_t n, double a, const double* __restrict__ x, double b,
+                                               const double* __restrict__ y, double* __restrict__ z) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) z[i] = a * x[i] + b * y[i];
+}
+
+// Ritz rotation out[:, 0:p] = V[:, 0:m] S[0:m, 0:p] on the matrix cores: one wave per 16 rows,
+// v_mfma_f64_16x16x4_f64 tiles (A <- V rows, B <- S), S staged in LDS.  m, p <= 144.
+__global__ __launch_bounds__(256) void k_rotate(int64_t n, int m, int p, const double* __restrict__ V,
+                                                const double* __restrict__ Smat, int ldS, double* __restrict__ out) {
+  extern __shared__ double sS[];   // [mpad][ppad], mpad multiple of 4, ppad multiple of 16
+  const int mpad = (m + 3) & ~3, ppad = (p + 15) & ~15;
+  for (int k = threadIdx.x; k < mpad * ppad; k += 256) {
+    int r = k / ppad, c = k % ppad;
+    sS[k] = (r < m && c < p) ? Smat[(int64_t)c * ldS + r] : 0.0;
+  }
+  __syncthreads();
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t i0 = ((int64_t)blockIdx.x * 4 + wave) * 16;
+  if (i0 >= n) return;
+  const int lr = lane & 15, lk = lane >> 4;
+  const int64_t row = i0 + lr;
+  const bool rv = row < n;
+  // out^T tile: A <- S^T (MFMA row = output column), B <- V^T (MFMA col = vector row), so that the
+  // accumulator register r of lane l is out[i0 + (l&15), c0 + (l>>4) + 4 r]: 128-B runs per column.
+  for (int c0 = 0; c0 < ppad; c0 += 16) {
+    v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
+    for (int kk = 0; kk < mpad; kk += 4) {
+      int k = kk + lk;
+      double a = sS[k * ppad + c0 + lr];
+      double b = (rv && k < m) ? V[(int64_t)k * n + row] : 0.0;
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      int oc = c0 + lk + 4 * r;
+      if (rv && oc < p) out[(int64_t)oc * n + row] = acc[r];
+    }
+  }
+}
+
+// ---- post-processing ------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_core_mask(int N, const double* __restrict__ doflocs,
+                                                   const double* __restrict__ cores, int ncore,
+                                                   const uint8_t* __restrict__ bmask, uint8_t* __restrict__ mask,
+                                                   int32_t* __restrict__ counters) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  bool in = false;
+  if (i < N) {
+    double X = doflocs[i], Y = doflocs[N + i];
+    for (int c = 0; c < ncore; ++c) {
+      double dx = X - cores[3 * c], dy = Y - cores[3 * c + 1], r = cores[3 * c + 2];
+      in |= (dx * dx + dy * dy <= r * r);
+    }
+    mask[i] = in ? 1 : 0;
+  }
+  // integer count of interior DOF nodes inside a core (order independent => deterministic)
+  unsigned long long b = __ballot(i < N && in && !bmask[i]);
+  if ((threadIdx.x & 63) == 0 && b) atomicAdd(&counters[1], (int)__popcll(b));
+}
+
+// per (row chunk, mode) partial sums: [0] sum vx^2, [1] sum vy^2, [2] core vx^2, [3] core vy^2,
+// [4] vx.Dxx vx + 2 vx.Dxy vy + vy.Dyy vy.   8 lanes per row.
+constexpr int POST_ROWS = 256;   // rows per block
+__global__ __launch_bounds__(256) void k_post_sums(int N, int nblocks, const int32_t* __restrict__ rowptr,
+                                                   const int32_t* __restrict__ colind, const double* __restrict__ dxx,
+                                                   const double* __restrict__ dxy, const double* __restrict__ dyy,
+                                                   const uint8_t* __restrict__ mask, const double* __restrict__ evecs,
+                                                   double* __restrict__ partial) {
+  const int mode = blockIdx.y;
+  const double* vx = evecs + (int64_t)mode * 2 * N;
+  const double* vy = vx + N;
+  __shared__ double red[4][5];
+  double acc[5] = {0, 0, 0, 0, 0};
+  const int sub = threadIdx.x & 7;
+  for (int rr = threadIdx.x >> 3; rr < POST_ROWS; rr += 32) {
+    int row = blockIdx.x * POST_ROWS + rr;
+    if (row >= N) break;
+    double px = 0, py = 0;   // (Dxx vx + Dxy vy)_row, (Dyy vy)_row
+    int q1 = rowptr[row + 1];
+    for (int q = rowptr[row] + sub; q < q1; q += 8) {
+      int c = colind[q];
+      double ux = vx[c], uy = vy[c];
+      px += dxx[q] * ux + 2.0 * dxy[q] * uy;
+      py += dyy[q] * uy;
+    }
+    double x = vx[row], y = vy[row];
+    acc[4] += x * px + y * py;
+    if (sub == 0) {
+      acc[0] += x * x;
+      acc[1] += y * y;
+      if (mask[row]) { acc[2] += x * x; acc[3] += y * y; }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    double v = acc[k];
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][k] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 5)
+    partial[((int64_t)mode * nblocks + blockIdx.x) * 5 + threadIdx.x] =
+        red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+__global__ void k_post_finish(int k, int nblocks, const double* __restrict__ partial, double* __restrict__ out) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= k * 5) return;
+  const int mode = t / 5, q = t % 5;
+  double acc = 0.0;
+  for (int b = 0; b < nblocks; ++b) acc += partial[((int64_t)mode * nblocks + b) * 5 + q];
+  out[t] = acc;
+}
+
+// normalise each mode in place (solver_fem.py:213)
+__global__ __launch_bounds__(256) void k_post_scale(int N, const double* __restrict__ sums, double* __restrict__ evecs) {
+  const int mode = blockIdx.y;
+  const double nrm = sqrt(sums[mode * 5 + 0] + sums[mode * 5 + 1]) + 1e-30;
+  const double inv = 1.0 / nrm;
+  double* v = evecs + (int64_t)mode * 2 * N;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < 2 * (int64_t)N) v[i] *= inv;
+}
+
+__global__ __launch_bounds__(256) void k_gather_interior(int N, int nsolve, const int32_t* __restrict__ interior,
+                                                         const double* __restrict__ evecs,
+                                                         double* __restrict__ modes_int) {
+  const int mode = blockIdx.y;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= 2 * (int64_t)nsolve) return;
+  int comp = i >= nsolve ? 1 : 0;
+  int q = (int)(i - (int64_t)comp * nsolve);
+  modes_int[(int64_t)mode * 2 * nsolve + i] = evecs[(int64_t)mode * 2 * N + (int64_t)comp * N + interior[q]];
+}
+
+}  // namespace
+
+void launch_panel_dot(plfem_ctx* c, const double* P, int ncols, const double* w, double* h) {
+  const int nchunks = c->npartial;
+  hipLaunchKernelGGL(k_panel_dot, dim3(nchunks, (ncols + 3) / 4), dim3(256), 0, c->stream, c->n2, ncols, nchunks, P,
+                     w, c->d_partial);
+  hipLaunchKernelGGL(k_panel_dot_finish, dim3((ncols + 255) / 256), dim3(256), 0, c->stream, ncols, nchunks,
+                     c->d_partial, h);
+}
+
+void launch_panel_axpy(plfem_ctx* c, const double* P, int ncols, const double* h, double* w) {
+  hipLaunchKernelGGL(k_panel_axpy, dim3((unsigned)((c->n2 + 255) / 256)), dim3(256), 0, c->stream, c->n2, ncols, P, h,
+                     w);
+}
+
+void launch_dot(plfem_ctx* c, const double* a, const double* b, double* out) { launch_panel_dot(c, a, 1, b, out); }
+
+void launch_vec_add(plfem_ctx* c, double* acc, const double* h, int n) {
+  hipLaunchKernelGGL(k_vec_add, dim3((n + 255) / 256), dim3(256), 0, c->stream, n, acc, h);
+}
+
+void launch_scale_store(plfem_ctx* c, const double* w, const double* bw, const double* beta2, double* v, double* bv,
+                        double* beta_out) {
+  hipLaunchKernelGGL(k_scale_store, dim3((unsigned)((c->n2 + 255) / 256)), dim3(256), 0, c->stream, c->n2, w, bw,
+                     beta2, v, bv, beta_out);
+}
+
+void launch_axpby(plfem_ctx* c, double a, const double* x, double b, const double* y, double* z) {
+  hipLaunchKernelGGL(k_axpby, dim3((unsigned)((c->n2 + 255) / 256)), dim3(256), 0, c->stream, c->n2, a, x, b, y, z);
+}
+
+void launch_rotate(plfem_ctx* c, const double* V, int m, const double* Smat, int ldS, int p, double* out) {
+  const int mpad = (m + 3) & ~3, ppad = (p + 15) & ~15;
+  size_t lds = sizeof(double) * mpad * ppad;
+  unsigned grid = (unsigned)((c->n2 + 63) / 64);
+  hipLaunchKernelGGL(k_rotate, dim3(grid), dim3(256), lds, c->stream, c->n2, m, p, V, Smat, ldS, out);
+}
+
+void launch_post(plfem_ctx* c, int k, double* evecs, int ncore, double* out_host, double* frac_core,
+                 double* modes_int) {
+  hipStream_t st = c->stream;
+  const int N = c->N;
+  hipMemsetAsync(c->d_counters + 1, 0, sizeof(int32_t), st);
+  hipLaunchKernelGGL(k_core_mask, dim3((N + 255) / 256), dim3(256), 0, st, N, c->d_doflocs, c->d_cores, ncore,
+                     c->d_bmask, c->d_coremask, c->d_counters);
+  const int nblocks = (N + POST_ROWS - 1) / POST_ROWS;
+  double* partial = c->d_post;                       // [k][nblocks][5]
+  double* sums = c->d_post + (int64_t)k * nblocks * 5;   // [k][5]
+  hipLaunchKernelGGL(k_post_sums, dim3(nblocks, k), dim3(256), 0, st, N, nblocks, c->d_rowptr, c->d_colind,
+                     c->d_vals[PLFEM_BLK_DXX], c->d_vals[PLFEM_BLK_DXY], c->d_vals[PLFEM_BLK_DYY], c->d_coremask, evecs,
+                     partial);
+  hipLaunchKernelGGL(k_post_finish, dim3((k * 5 + 63) / 64), dim3(64), 0, st, k, nblocks, partial, sums);
+  hipLaunchKernelGGL(k_post_scale, dim3((unsigned)((2 * (int64_t)N + 255) / 256), k), dim3(256), 0, st, N, sums, evecs);
+  if (modes_int)
+    hipLaunchKernelGGL(k_gather_interior, dim3((unsigned)((2 * (int64_t)c->nsolve + 255) / 256), k), dim3(256), 0, st,
+                       N, c->nsolve, c->d_interior, evecs, modes_int);
+  // results to the host
+  double* hs = c->h_pinned;
+  hipMemcpyAsync(hs, sums, sizeof(double) * k * 5, hipMemcpyDeviceToHost, st);
+  int32_t* hc = reinterpret_cast<int32_t*>(c->h_pinned + 4096);
+  hipMemcpyAsync(hc, c->d_counters, sizeof(int32_t) * 4, hipMemcpyDeviceToHost, st);
+  hipStreamSynchronize(st);
+  for (int mode = 0; mode < k; ++mode) {
+    const double* s = hs + mode * 5;
+    double nrm2 = s[0] + s[1];
+    double nrm = std::sqrt(nrm2) + 1e-30;
+    double inv2 = 1.0 / (nrm * nrm);
+    double* o = out_host + (size_t)mode * PLFEM_POST_COUNT;
+    o[PLFEM_POST_NORM] = nrm;
+    o[PLFEM_POST_DIV_ENERGY] = s[4] * inv2;
+    o[PLFEM_POST_CORE_X] = s[2] * inv2;
+    o[PLFEM_POST_CORE_Y] = s[3] * inv2;
+    o[PLFEM_POST_ALL_X] = s[0] * inv2;
+    o[PLFEM_POST_ALL_Y] = s[1] * inv2;
+  }
+  if (frac_core) *frac_core = (double)hc[1] / (double)c->nsolve;
+}
+
+}  // namespace plfem

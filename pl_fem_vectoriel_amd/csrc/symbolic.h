@@ -1,0 +1,59 @@
+// Host-side symbolic analysis for the P2 H-field eigenmode path (mesh-only; reusable across
+// wavelengths / core indices of a sweep).  Pure C++17, no HIP: unit-testable without a GPU.
+//
+// Replaces, for this path, what the reference obtains from scikit-fem / SciPy:
+//   * Basis(mesh, ElementTriP2())  DOF numbering, doflocs          (reference solver_fem.py:126)
+//   * basis.get_dofs().all()       Dirichlet set                   (reference solver_fem.py:179)
+//   * coo_matrix(...).tocsr()      sparsity pattern of asm()       (reference solver_fem.py:153-156)
+//   * splu's ordering + symbolic factorisation of (A - sigma B)    (scipy arpack.py:915, via
+//     reference solver_fem.py:197) -- here: element-based geometric nested dissection producing a
+//     complete binary tree of dense frontal matrices.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace plfem {
+
+struct Symbolic {
+  // ---- mesh / P2 numbering (scikit-fem compatible) ------------------------------------------
+  int nv = 0, ne = 0, nedges = 0, N = 0, nsolve = 0;
+  std::vector<int32_t> tsorted;    // [3][ne]  vertex ids, each column ascending
+  std::vector<int32_t> edof;       // [6][ne]  element_dofs: rows 0-2 vertices, 3-5 edges (0,1),(1,2),(0,2)
+  std::vector<int32_t> edges;      // [2][nedges] sorted vertex pairs in lexicographic order
+  std::vector<double> doflocs;     // [2][N]
+  std::vector<uint8_t> bmask;      // [N] 1 = on the outer boundary (Dirichlet H = 0)
+  std::vector<int32_t> interior;   // [nsolve] ascending DOF ids
+  std::vector<int32_t> int_index;  // [N] DOF -> interior index or -1
+  // ---- scalar CSR pattern (full N x N, shared by every block of A and B) ----------------------
+  std::vector<int32_t> rowptr;     // [N+1]
+  std::vector<int32_t> colind;     // [nnz]
+  std::vector<int32_t> srcptr;     // [nnz+1]  contribution lists: slot -> element-matrix entries
+  std::vector<int32_t> src;        // [36 ne]  e*36 + a*6 + b   (a = local row/test, b = local col/trial)
+  // ---- nested-dissection front tree ----------------------------------------------------------
+  int L = 0;                       // leaves at level L; fronts in heap order, nfronts = 2^(L+1)-1
+  int nfronts = 0;
+  std::vector<int32_t> leaf_of_elem;   // [ne]
+  std::vector<int32_t> leaf_elem_ptr;  // [2^L + 1]
+  std::vector<int32_t> leaf_elems;     // [ne] element ids grouped by leaf
+  std::vector<int32_t> epos;           // [6][ne] local node index of each element node in its leaf front, -1 = Dirichlet
+  std::vector<int32_t> fs, fb;         // [nfronts] padded (multiple of 8) counts of owned / boundary nodes
+  std::vector<int32_t> fs_true, fb_true;
+  std::vector<int64_t> fnode_ptr;      // [nfronts+1] offsets into fnodes/cinv*
+  std::vector<int32_t> fnodes;         // node (scalar DOF) id per local node, -1 = padding
+  std::vector<int32_t> cinv0, cinv1;   // per local node of an internal front: index in child's boundary list or -1
+  std::vector<int64_t> foff;           // [nfronts+1] offsets (in doubles) of the dense front matrices, m = 2(fs+fb)
+  std::vector<int32_t> owner;          // [N] front that eliminates the node, -1 for Dirichlet nodes
+  // statistics
+  double factor_flops = 0.0;           // sum over fronts of 2 * s2 * m^2  (block Gauss-Jordan sweep)
+  int64_t solve_entries = 0;           // sum over fronts of s2 * (m + (m - s2)) matrix entries read per solve
+  int max_m = 0;
+  double t_numbering = 0, t_pattern = 0, t_tree = 0, t_fronts = 0;  // seconds
+};
+
+// p: [2][nv] (x row then y row), t: [3][ne].  leaf_elems: target elements per leaf front.
+// Returns empty string on success, error message otherwise.
+std::string build_symbolic(int nv, int ne, const double* p, const int32_t* t, int leaf_elems,
+                           int nthreads, Symbolic& S);
+
+}  // namespace plfem

@@ -1,0 +1,260 @@
+"""Drop-in for the vectorial half of the reference ``solver_fem.py`` on MI355X.
+
+Class / method surface follows the reference code (``solver_fem.py:113-239``):
+
+* ``TrueVectorialMaxwellSolver(geometry, use_pml=False)``; attributes ``geometry``, ``k0``, ``use_pml``;
+* ``assemble_hfield_system(mesh) -> (A, B, basis, Dxx, Dyy, Dxy, M_inv)`` — SciPy CSR matrices
+  (``A``, ``B`` 2N x 2N in the block order Hx then Hy; the others N x N) and a basis object exposing
+  ``N``, ``doflocs``, ``element_dofs`` and ``get_dofs().all()``;
+* ``solve_vectorial_modes(mesh, n_modes_target=20) -> List[Dict]`` with the dict keys of
+  ``solver_fem.py:222-225`` (``Ex_dofs`` / ``Ey_dofs`` hold the Hx / Hy interior DOF vectors);
+
+plus the documented convenience form of the reference README (``README.md:137-160``):
+``TrueVectorialMaxwellSolver(geom, n_modes=10).solve()`` with attribute access on the modes.
+
+All arithmetic of the path runs in ``libplfem_hip.so`` (``include/plfem.h``); this file only holds
+the host logic the reference also keeps in Python: the shift estimate, the request size, the n_eff
+window, the divergence / radiation filters and the ordering (``solver_fem.py:187-196,205-239``).
+"""
+from __future__ import annotations
+
+import logging
+import time
+from typing import Dict, List, Optional
+
+import numpy as np
+
+from . import _native
+from .mesh import TriMesh, generate_mesh
+
+logger = logging.getLogger("pl_v18.solver_fem")   # same logger name as the reference (solver_fem.py:40)
+
+
+class ModeDict(dict):
+    """Mode record: a ``dict`` (code form) that also answers attribute access (README form)."""
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError as e:
+            raise AttributeError(k) from e
+
+
+class _DofsView:
+    def __init__(self, dofs):
+        self._d = dofs
+
+    def all(self):
+        return self._d
+
+
+class P2BasisView:
+    """What the reference reads of ``Basis(mesh, ElementTriP2())`` (``solver_fem.py:127,179,183``)."""
+
+    def __init__(self, sym: "_native.Symbolic"):
+        self.N = sym.N
+        self.nvertices = sym.nv
+        self.doflocs = sym.array("doflocs").reshape(2, sym.N)
+        self.element_dofs = sym.array("edof").reshape(6, sym.ne)
+        self._boundary = np.nonzero(sym.array("bmask"))[0]
+        self.interior_dofs = sym.array("interior").astype(np.int64)
+
+    def get_dofs(self):
+        return _DofsView(self._boundary)
+
+
+def shift_estimate(geometry) -> float:
+    """LP01 b-V estimate of the shift (``solver_fem.py:187-193``)."""
+    n_core, n_clad = geometry.n_core, geometry.n_clad
+    NA = np.sqrt(max(n_core ** 2 - n_clad ** 2, 1e-6))
+    r_mean = np.mean(geometry.core_radii)
+    V_geom = geometry.k0 * r_mean * NA
+    b_approx = max((1.0 - 2.405 / max(V_geom, 2.41)) ** 2, 0.05)
+    n_eff_est = np.sqrt(n_clad ** 2 + b_approx * (n_core ** 2 - n_clad ** 2))
+    return float((geometry.k0 * float(np.clip(n_eff_est, n_clad + 0.05, n_core - 0.005))) ** 2)
+
+
+def _core_table(geometry) -> np.ndarray:
+    pos = np.atleast_2d(np.asarray(geometry.positions, dtype=np.float64))
+    rad = np.asarray(geometry.core_radii, dtype=np.float64).reshape(-1)
+    return np.ascontiguousarray(np.column_stack([pos, rad]))
+
+
+def _classify(ratio: float) -> str:
+    # solver_fem.py:100-105
+    if ratio > 10.0:
+        return "TE-like"
+    if ratio > 2.5:
+        return "HE-like"
+    if ratio > 0.4:
+        return "Hybrid"
+    if ratio > 0.1:
+        return "EH-like"
+    return "TM-like"
+
+
+class TrueVectorialMaxwellSolver:
+    """Vectorial H-field eigenmode solver, MI355X backend.
+
+    Extra keyword arguments (not in the reference) are all optional: ``n_modes`` (README form),
+    ``device`` (HIP device index), ``eig_tol`` (Ritz residual tolerance, default tighter than the
+    reference's 1e-7 so the vectors are not the limiting error), ``leaf_elems`` (front-tree leaf
+    size), ``reuse_symbolic`` (keep the mesh-only analysis and the device context between calls on
+    the same mesh object — e.g. a wavelength sweep), ``mesh_levels`` / ``mesh_refinement`` for
+    ``solve()``.
+    """
+
+    ALPHA_P = 1.0            # solver_fem.py:158
+    REF_TOL = 1e-7           # solver_fem.py:197
+    MAXITER = 12000          # solver_fem.py:197
+    OVERSAMPLE = 12          # solver_fem.py:196
+
+    def __init__(self, geometry, use_pml: bool = False, n_modes: Optional[int] = None, device: Optional[int] = None,
+                 eig_tol: float = 1e-10, leaf_elems: int = 0, reuse_symbolic: bool = True, mesh_refinement: float = 1.0,
+                 mesh_levels: int = 1, refine_steps: int = 0):
+        _native.load_library()           # fail loudly: the reference raises RuntimeError when its backend is missing
+        self.geometry = geometry
+        self.k0 = geometry.k0
+        self.use_pml = use_pml           # stored, never read — as in the reference
+        self.n_modes = n_modes
+        self.device = device
+        self.eig_tol = float(eig_tol)
+        self.leaf_elems = int(leaf_elems)
+        self.reuse_symbolic = bool(reuse_symbolic)
+        self.mesh_refinement = mesh_refinement
+        self.mesh_levels = mesh_levels
+        self.refine_steps = int(refine_steps)
+        self._cache = {}
+        self.last_stats: Dict = {}
+        logger.info(f"Solveur H-field initialisé - k₀={self.k0:.4f} µm⁻¹")
+
+    # -- symbolic / context management -------------------------------------------------------------
+    def _analysis(self, mesh, need_ctx: bool, max_ncv: int = 65):
+        key = (id(mesh), mesh.p.shape[1], mesh.t.shape[1])
+        ent = self._cache.get(key) if self.reuse_symbolic else None
+        if ent is None:
+            t0 = time.perf_counter()
+            sym = _native.Symbolic(mesh.p, mesh.t, leaf_elems=self.leaf_elems)
+            ent = {"sym": sym, "ctx": None, "basis": None, "t_symbolic": time.perf_counter() - t0, "mesh": mesh}
+            if self.reuse_symbolic:
+                self._cache.clear()          # one mesh at a time: contexts own GBs of HBM
+                self._cache[key] = ent
+        if need_ctx and (ent["ctx"] is None or ent["ctx"].max_ncv < max_ncv):
+            if ent["ctx"] is not None:
+                ent["ctx"].close()
+            t0 = time.perf_counter()
+            ent["ctx"] = _native.Context(ent["sym"], self.device, max_ncv=max(max_ncv, 65))
+            ent["t_context"] = time.perf_counter() - t0
+        return ent
+
+    def clear_cache(self):
+        for ent in self._cache.values():
+            if ent["ctx"] is not None:
+                ent["ctx"].close()
+        self._cache.clear()
+
+    def _assemble_device(self, ctx):
+        g = self.geometry
+        ctx.assemble(_core_table(g), g.n_core ** 2, g.n_clad ** 2, self.k0, self.ALPHA_P)
+
+    # -- reference surface ---------------------------------------------------------------------------
+    def assemble_hfield_system(self, mesh):
+        """Assemblage des matrices H-field 2N×2N (``solver_fem.py:122-169``), computed on the GPU."""
+        import scipy.sparse as sp
+
+        ent = self._analysis(mesh, need_ctx=True)
+        sym, ctx = ent["sym"], ent["ctx"]
+        self._assemble_device(ctx)
+        N = sym.N
+        rowptr = sym.array("rowptr")
+        colind = sym.array("colind")
+
+        def blk(name):
+            return sp.csr_matrix((ctx.block_values(name), colind, rowptr), shape=(N, N))
+
+        A = sp.bmat([[blk("Axx"), blk("Axy")], [blk("Ayx"), blk("Ayy")]], format="csr")
+        M_inv = blk("Minv")
+        B = sp.bmat([[M_inv, None], [None, M_inv]], format="csr")
+        if ent["basis"] is None:
+            ent["basis"] = P2BasisView(sym)
+        logger.info(f"Assemblage terminé - {N} DOFs P2, matrice {2 * N}×{2 * N}")
+        return A, B, ent["basis"], blk("Dxx"), blk("Dyy"), blk("Dxy"), M_inv
+
+    def solve_vectorial_modes(self, mesh, n_modes_target: int = 20) -> List[Dict]:
+        """Résout [A]{Ht} = β² [B]{Ht} (``solver_fem.py:171-239``) on the GPU."""
+        g = self.geometry
+        t_start = time.perf_counter()
+        # request size and Lanczos basis: solver_fem.py:196 and scipy's default ncv = max(2k+1, 20)
+        nv, ne = mesh.p.shape[1], mesh.t.shape[1]
+        n_req_guess = n_modes_target + self.OVERSAMPLE
+        ent = self._analysis(mesh, need_ctx=True, max_ncv=max(2 * n_req_guess + 1, 20))
+        sym, ctx = ent["sym"], ent["ctx"]
+        N_solve = sym.nsolve
+        n_req = min(n_modes_target + self.OVERSAMPLE, 2 * N_solve - 4)
+        if n_req < 1:
+            raise ValueError("mesh too small for the requested number of modes")
+        ncv = min(max(2 * n_req + 1, 20), 2 * N_solve)
+        cores = _core_table(g)
+        t0 = time.perf_counter()
+        self._assemble_device(ctx)
+        sigma = shift_estimate(g)
+        ctx.factor(sigma)
+        evals, evecs, st = ctx.lanczos(n_req, ncv, self.eig_tol, self.MAXITER, sigma)
+        post, frac_core, modes_int = ctx.postprocess(evecs, cores, want_interior=True)
+        t1 = time.perf_counter()
+        vecs = modes_int.cpu().numpy()        # (k, 2 N_solve): the caller owns NumPy copies, as in the reference
+        t2 = time.perf_counter()
+
+        n_core, n_clad = g.n_core, g.n_clad
+        modes_raw = []
+        for i in range(len(evals)):
+            b2 = float(evals[i])
+            if b2 <= 0:
+                continue
+            beta = np.sqrt(b2)
+            ne_ = beta / self.k0
+            if ne_ <= n_clad or ne_ >= n_core * 1.01:
+                continue
+            div_energy, cx, cy, ax, ay = post[i, 1], post[i, 2], post[i, 3], post[i, 4], post[i, 5]
+            div_ratio = float(div_energy / max(b2, 1e-12))
+            conf_raw = float((cx + cy) / (ax + ay))
+            # _polarization_from_interp (solver_fem.py:88-107); whole-domain fallback if no core DOF
+            if frac_core > 0:
+                P_x, P_y = float(cx) + 1e-30, float(cy) + 1e-30
+            else:
+                P_x, P_y = float(ax) + 1e-30, float(ay) + 1e-30
+            PDL = float(np.clip(10.0 * np.log10(max(P_x, P_y) / min(P_x, P_y)), 0.0, 50.0))
+            modes_raw.append(ModeDict({
+                "n_eff": float(ne_), "beta": float(beta),
+                "Ex_dofs": vecs[i, :N_solve], "Ey_dofs": vecs[i, N_solve:],
+                "P_x": P_x, "P_y": P_y, "PDL_dB": PDL, "polarization": _classify(P_x / P_y),
+                "confinement": conf_raw, "core_overlap": conf_raw, "div_ratio": div_ratio,
+                "is_vectorial": True, "method": "H-field_V18.10"}))
+        self.last_stats = dict(st, sigma=sigma, n_req=n_req, ncv=ncv, N=sym.N, N_solve=N_solve, n=2 * N_solve,
+                               t_symbolic=ent.get("t_symbolic", 0.0), t_context=ent.get("t_context", 0.0),
+                               t_device=t1 - t0, t_copy_out=t2 - t1, frac_core=frac_core, **ctx.timings())
+        if not modes_raw:
+            self.last_stats["t_total"] = time.perf_counter() - t_start
+            return []       # the reference would raise on np.median([]) (solver_fem.py:229); SURVEY.md §5
+        # divergence filter, solver_fem.py:228-231
+        dr = np.array([m["div_ratio"] for m in modes_raw])
+        dr_thresh = max(np.median(dr) * 10, dr.min() * 50, 1e-6)
+        modes_phys = [m for m in modes_raw if m["div_ratio"] <= dr_thresh]
+        # radiation filter with fallback, solver_fem.py:234-236
+        conf_threshold_rad = max(5.0 * frac_core, 0.05)
+        modes_guided = [m for m in modes_phys if m["confinement"] >= conf_threshold_rad]
+        if not modes_guided:
+            modes_guided = modes_phys
+        modes_guided.sort(key=lambda x: x["n_eff"], reverse=True)
+        self.last_stats["t_total"] = time.perf_counter() - t_start
+        return modes_guided
+
+    # -- documented convenience form (reference README.md:149-160) -----------------------------------
+    def solve(self, mesh=None) -> List[Dict]:
+        if mesh is None:
+            mesh = generate_mesh(self.geometry, self.mesh_refinement, self.mesh_levels)
+        n = self.n_modes if self.n_modes is not None else 20
+        return self.solve_vectorial_modes(mesh, n_modes_target=n)
+
+
+__all__ = ["TrueVectorialMaxwellSolver", "ModeDict", "P2BasisView", "shift_estimate", "TriMesh"]
