@@ -76,7 +76,7 @@ int plfem_symbolic_get(const plfem_symbolic* sym, const char* name, void* out_ho
 /* ---------------------------------------------------------------------------------------------
  * Context: binds a symbolic analysis to a device and stream, uploads the index structures and
  * allocates every workspace (nothing is allocated later, so calls are graph-capturable).
- * hip_stream: a hipStream_t (e.g. torch.cuda.current_stream().cuda_stream) or NULL for a private one.
+ * hip_stream: a hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL = the default (null) stream.
  * max_ncv: largest Lanczos basis the context must hold.
  * ------------------------------------------------------------------------------------------- */
 int plfem_create(const plfem_symbolic* sym, int32_t device, void* hip_stream, int32_t max_ncv,
@@ -161,6 +161,14 @@ int plfem_postprocess(plfem_ctx* ctx, int32_t k, double* evecs_dev, const double
  * [0] assemble, [1] factor, [2] lanczos, [3] postprocess, [4] upload; plus counters
  * [5] pivot perturbations in the last factorisation. */
 int plfem_timings(plfem_ctx* ctx, double* out_host /* [8] */);
+
+/* ---------------------------------------------------------------------------------------------
+ * Debugging aids for the test-suite (no reference counterpart): run the factorisation only up to
+ * a given (tree level, sweep step, stage: 0 assembled, 1 diag, 2 panel, 3 update, 4 level done),
+ * and copy a slice of a named device workspace ("front","fvec","wbuf","rbuf","dinv","elem").
+ * ------------------------------------------------------------------------------------------- */
+int plfem_debug_factor_until(plfem_ctx* ctx, double sigma, int32_t level, int32_t step, int32_t stage);
+int plfem_debug_copy(plfem_ctx* ctx, const char* name, int64_t offset, int64_t count, double* out_host);
 
 #ifdef __cplusplus
 }

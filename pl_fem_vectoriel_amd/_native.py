@@ -29,6 +29,7 @@ EXPORTS = (
     "plfem_symbolic_get", "plfem_create", "plfem_destroy", "plfem_last_error", "plfem_synchronize",
     "plfem_assemble_hfield", "plfem_block_values_dev", "plfem_block_values_host", "plfem_spmv", "plfem_factor",
     "plfem_solve", "plfem_lanczos_shift_invert", "plfem_postprocess", "plfem_timings",
+    "plfem_debug_factor_until", "plfem_debug_copy",
 )
 
 _ARRAY_DTYPES = {
@@ -92,6 +93,9 @@ def load_library() -> ctypes.CDLL:
     lib.plfem_postprocess.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p,
                                       ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
     lib.plfem_timings.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    lib.plfem_debug_factor_until.argtypes = [ctypes.c_void_p, ctypes.c_double, ctypes.c_int32, ctypes.c_int32,
+                                             ctypes.c_int32]
+    lib.plfem_debug_copy.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p]
     _lib = lib
     return lib
 
@@ -245,6 +249,16 @@ class Context:
         self._check(self._lib.plfem_timings(self._h, _ptr(t)), "plfem_timings")
         return {"assemble_us": t[0], "factor_us": t[1], "lanczos_us": t[2], "post_us": t[3], "upload_us": t[4],
                 "pivot_perturbations": int(t[5])}
+
+    def debug_factor_until(self, sigma, level, step, stage):
+        self._check(self._lib.plfem_debug_factor_until(self._h, float(sigma), int(level), int(step), int(stage)),
+                    "plfem_debug_factor_until")
+
+    def debug_copy(self, name: str, offset: int, count: int) -> np.ndarray:
+        out = np.empty(int(count), dtype=np.float64)
+        self._check(self._lib.plfem_debug_copy(self._h, name.encode(), ctypes.c_int64(int(offset)),
+                                               ctypes.c_int64(int(count)), _ptr(out)), "plfem_debug_copy")
+        return out
 
     def synchronize(self):
         self._check(self._lib.plfem_synchronize(self._h), "plfem_synchronize")

@@ -101,7 +101,7 @@ void free_all(plfem_ctx* c) {
   F(c->d_cinv0); F(c->d_cinv1); F(c->d_epos); F(c->d_leaf_elem_ptr); F(c->d_leaf_elems); F(c->d_cores);
   F(c->d_elem);
   for (auto& p : c->d_vals) F(p);
-  F(c->d_front); F(c->d_fvec); F(c->d_wbuf); F(c->d_rbuf); F(c->d_dinv); F(c->d_counters);
+  F(c->d_front); F(c->d_fvec); F(c->d_wbuf); F(c->d_rbuf); F(c->d_dinv); F(c->d_delta); F(c->d_tbuf); F(c->d_fvec2); F(c->d_counters);
   F(c->d_V); F(c->d_BV); F(c->d_V2); F(c->d_BV2); F(c->d_w); F(c->d_bw); F(c->d_t1); F(c->d_t2);
   F(c->d_h); F(c->d_hacc); F(c->d_partial); F(c->d_scal); F(c->d_S); F(c->d_Hcols); F(c->d_coremask); F(c->d_post);
   if (c->h_pinned) (void)hipHostFree(c->h_pinned);
@@ -116,12 +116,7 @@ int create_impl(plfem_ctx* c, const plfem_symbolic* sym, int device, void* strea
   c->S = &S;
   c->device = device;
   HIP_TRY(c, hipSetDevice(device));
-  if (stream) {
-    c->stream = (hipStream_t)stream;
-  } else {
-    HIP_TRY(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    c->own_stream = true;
-  }
+  c->stream = (hipStream_t)stream;   // NULL = the device's default (null) stream
   for (int q = 0; q < 5; ++q)
     for (int r = 0; r < 2; ++r) HIP_TRY(c, hipEventCreate(&c->ev[q][r]));
   HIP_TRY(c, hipEventRecord(c->ev[4][0], c->stream));
@@ -170,6 +165,9 @@ int create_impl(plfem_ctx* c, const plfem_symbolic* sym, int device, void* strea
   TRY(dalloc(c, &c->d_wbuf, (size_t)2 * fnodes_total * plfem::NB));
   TRY(dalloc(c, &c->d_rbuf, (size_t)2 * fnodes_total * plfem::NB));
   TRY(dalloc(c, &c->d_dinv, (size_t)S.nfronts * plfem::NB * plfem::NB));
+  TRY(dalloc(c, &c->d_delta, (size_t)2 * fnodes_total));
+  TRY(dalloc(c, &c->d_tbuf, (size_t)2 * fnodes_total * plfem::NB));
+  TRY(dalloc(c, &c->d_fvec2, (size_t)2 * fnodes_total));
   TRY(dalloc(c, &c->d_counters, 4));
   HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, 4 * sizeof(int32_t), c->stream));
   const size_t n2 = (size_t)c->n2, nc1 = (size_t)max_ncv + 1;
@@ -490,5 +488,32 @@ extern "C" int plfem_timings(plfem_ctx* c, double* out_host) {
   }
   for (int i = 0; i < 8; ++i) out_host[i] = c->timings[i];
   out_host[5] = cnt[0];
+  return PLFEM_OK;
+}
+
+// ---- debugging aids (used by tests/ only; not part of the reference-facing surface) --------------
+extern "C" int plfem_debug_factor_until(plfem_ctx* c, double sigma, int32_t level, int32_t step, int32_t stage) {
+  if (!c) return PLFEM_EINVAL;
+  if (!c->assembled) { c->err = "debug factor before assemble"; return PLFEM_ESTATE; }
+  plfem::launch_factor(c, sigma, level, step, stage);
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return check_launch(c, "debug factor");
+}
+
+extern "C" int plfem_debug_copy(plfem_ctx* c, const char* name, int64_t offset, int64_t count, double* out_host) {
+  if (!c || !name || !out_host || offset < 0 || count < 0) return PLFEM_EINVAL;
+  std::string n(name);
+  const double* src = nullptr;
+  if (n == "front") src = c->d_front;
+  else if (n == "fvec") src = c->d_fvec;
+  else if (n == "wbuf") src = c->d_wbuf;
+  else if (n == "rbuf") src = c->d_rbuf;
+  else if (n == "dinv") src = c->d_dinv;
+  else if (n == "delta") src = c->d_delta;
+  else if (n == "fvec2") src = c->d_fvec2;
+  else if (n == "elem") src = c->d_elem;
+  else return PLFEM_EINVAL;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, hipMemcpy(out_host, src + offset, sizeof(double) * count, hipMemcpyDeviceToHost));
   return PLFEM_OK;
 }

@@ -51,7 +51,10 @@ struct plfem_ctx {
   double* d_front = nullptr;      // dense fronts
   double* d_fvec = nullptr;       // per-front solve vectors, offset 2*fnode_ptr[f]
   double *d_wbuf = nullptr, *d_rbuf = nullptr;   // per-front panels m x NB, offset 2*fnode_ptr[f]*NB
-  double* d_dinv = nullptr;       // per-front NB x NB
+  double* d_dinv = nullptr;       // per-front NB x NB (inverse of the current unit-lower pivot block)
+  double* d_delta = nullptr;      // per-front D of the LDL^T (offset 2*fnode_ptr[f])
+  double* d_tbuf = nullptr;       // per-front NB x s2 scratch (block row of L11), offset 2*fnode_ptr[f]*NB
+  double* d_fvec2 = nullptr;      // second per-front solve vector
   int32_t* d_counters = nullptr;  // [0] pivot perturbations
   // ---- Lanczos workspace
   double *d_V = nullptr, *d_BV = nullptr, *d_V2 = nullptr, *d_BV2 = nullptr;   // n2 x (max_ncv+1), column major
@@ -77,7 +80,7 @@ void launch_element_matrices(plfem_ctx* c, int ncore, double eps_core, double ep
 void launch_csr_gather(plfem_ctx* c);
 void launch_spmv(plfem_ctx* c, int which, const double* x, double* y);
 // kernels_front.hip
-void launch_factor(plfem_ctx* c, double sigma);
+void launch_factor(plfem_ctx* c, double sigma, int stop_level = -1, int stop_step = 0, int stop_stage = 0);
 void launch_solve(plfem_ctx* c, const double* rhs, double* x);
 // kernels_lanczos.hip
 void launch_panel_dot(plfem_ctx* c, const double* P, int ncols, const double* w, double* h);   // h = P^T w

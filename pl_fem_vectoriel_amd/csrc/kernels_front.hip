@@ -4,12 +4,15 @@
 // eigsh(..., sigma=...) (reference solver_fem.py:197 -> scipy arpack.py:915, 920-928).
 //
 // Every front F (order m, column major, symmetric) holds [F11 F12; F21 F22] with the first s2 DOFs
-// fully summed.  The factorisation applies the symmetric sweep operator to the first s2 indices,
-// NB columns at a time (block Gauss-Jordan with partial pivoting inside each NB x NB pivot block):
-//     F  ->  [ -F11^-1      F11^-1 F12 ;  F21 F11^-1     F22 - F21 F11^-1 F12 ]
-// i.e. the explicit inverse of the pivot block, the coupling panel X and the Schur complement that
-// the parent front gathers.  With explicit inverses both solve sweeps are batched dense
-// column-times-vector products (no triangular dependency chains inside a front).
+// fully summed.  The factorisation is a right-looking block LDL^T of those s2 pivots, NB at a time:
+//     F11 = L11 D L11^T,   L21 = F21 L11^-T D^-1,   S = F22 - L21 D L21^T   (S: gathered by the parent)
+// and, interleaved with it, the explicit inverse of the unit lower triangular L11 (a triangular
+// inverse is benign numerically, unlike F11^-1: the stiffness scale of near-degenerate elements
+// stays in the diagonal D).  What is left in F for the solves:
+//     lower(F11) = L11^-1, upper(F11) = L11^-T, F21 = L21, F12 = L21^T, delta = D
+// so both solve sweeps are batched dense column-times-vector products over contiguous columns
+// (no triangular dependency chain inside a front).  A block Gauss-Jordan sweep (explicit F11^-1)
+// was tried first and is unstable on meshes with sliver elements ("numerics").
 #include "device.h"
 
 namespace plfem {
@@ -95,25 +98,35 @@ __global__ __launch_bounds__(256) void k_front_gather(
 }
 
 // ------------------------------------------------------------------------------------------------
-// block Gauss-Jordan sweep, step kb of a level:  diag -> panel -> update
+// block LDL^T, step kb of a level:  diag -> invrow -> panel -> update
 // ------------------------------------------------------------------------------------------------
-// Explicit inverse of the NB x NB pivot block (in-place Gauss-Jordan, partial pivoting restricted
-// to the block, static perturbation of vanishing pivots).
-__global__ __launch_bounds__(256) void k_sweep_diag(int first_front, int kb, const int32_t* __restrict__ fs2,
-                                                    const int32_t* __restrict__ fm, const int64_t* __restrict__ foff,
-                                                    const double* __restrict__ front, double* __restrict__ dinv,
-                                                    int32_t* __restrict__ counters) {
+// Pivot block: unpivoted LDL^T of the NB x NB block in LDS (static perturbation of vanishing pivots),
+// X = L^-1 by forward substitution.  Writes X (dinv), D (delta), the block itself (lower X, upper
+// X^T) and saves the block row L[k, <k] of L11 for the triangular-inverse update (tbuf).
+__global__ __launch_bounds__(256) void k_ldl_diag(int first_front, int kb, const int32_t* __restrict__ fs2,
+                                                  const int32_t* __restrict__ fm, const int64_t* __restrict__ foff,
+                                                  const int64_t* __restrict__ fnode_ptr, double* __restrict__ front,
+                                                  double* __restrict__ dinv, double* __restrict__ delta,
+                                                  double* __restrict__ tbuf, int32_t* __restrict__ counters) {
   const int f = first_front + blockIdx.x;
   const int s2 = fs2[f];
   const int k0 = kb * NB;
   if (k0 >= s2) return;
   const int nbk = min(NB, s2 - k0);
   const int m = fm[f];
-  const double* F = front + foff[f];
+  double* F = front + foff[f];
   __shared__ double a[NB][NB + 1];
-  __shared__ int piv[NB];
+  __shared__ double x[NB][NB + 1];
+  __shared__ double lk[NB];
+  __shared__ double dl[NB];
   __shared__ double s_red[4];
   const int tid = threadIdx.x;
+  // save the block row of L11 left of the pivot block: tbuf[q + j*NB] = L[k0+q, j], j < k0
+  double* T = tbuf + 2 * fnode_ptr[f] * NB;
+  for (int k = tid; k < NB * k0; k += 256) {
+    int q = k % NB, j = k / NB;
+    T[k] = (q < nbk) ? F[(int64_t)j * m + (k0 + q)] : 0.0;
+  }
   double amax = 0.0;
   for (int k = tid; k < NB * NB; k += 256) {
     int r = k % NB, c = k / NB;
@@ -125,163 +138,193 @@ __global__ __launch_bounds__(256) void k_sweep_diag(int first_front, int kb, con
   if ((tid & 63) == 0) s_red[tid >> 6] = amax;
   __syncthreads();
   amax = fmax(fmax(s_red[0], s_red[1]), fmax(s_red[2], s_red[3]));
-  const double thr = 1e-13 * amax;
-  const int i = tid >> 3, cg = tid & 7;   // elimination: row i, columns cg*4 .. cg*4+3
+  const double thr = fmax(1e-13 * amax, 1e-300);
+  const int i = tid >> 3, cg = tid & 7;   // trailing update: row i, columns cg*4 .. cg*4+3
   for (int k = 0; k < NB; ++k) {
-    if (tid < 64) {
-      double v = (tid < NB && tid >= k) ? fabs(a[tid][k]) : -1.0;
-      int idx = tid;
-      for (int off = 32; off >= 1; off >>= 1) {
-        double ov = __shfl_xor(v, off);
-        int oi = __shfl_xor(idx, off);
-        if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
-      }
-      if (tid == 0) piv[k] = idx;
-    }
-    __syncthreads();
-    const int p = piv[k];
-    if (p != k && tid < NB) {
-      double t = a[k][tid];
-      a[k][tid] = a[p][tid];
-      a[p][tid] = t;
-    }
-    __syncthreads();
-    double pv = a[k][k];
-    if (fabs(pv) < thr || pv == 0.0) {
-      pv = (pv < 0.0) ? -fmax(thr, 1e-300) : fmax(thr, 1e-300);
+    double dk = a[k][k];
+    if (!(fabs(dk) >= thr)) {
+      dk = (dk < 0.0) ? -thr : thr;
       if (tid == 0) atomicAdd(&counters[0], 1);
     }
-    const double f_ik = a[i][k];
+    if (tid < NB) {
+      lk[tid] = (tid > k) ? a[tid][k] / dk : 0.0;
+      if (tid == k) dl[k] = dk;
+    }
     __syncthreads();
-    if (tid < NB) a[k][tid] = ((tid == k) ? 1.0 : a[k][tid]) / pv;
-    __syncthreads();
-    if (i != k) {
+    if (i > k) {
+      const double li = lk[i];
 #pragma unroll
       for (int cc = 0; cc < 4; ++cc) {
         int c = cg * 4 + cc;
-        double v = (c == k) ? 0.0 : a[i][c];
-        a[i][c] = v - f_ik * a[k][c];
+        if (c > k) a[i][c] -= li * dk * lk[c];
       }
     }
     __syncthreads();
-  }
-  for (int k = NB - 1; k >= 0; --k) {
-    const int p = piv[k];
-    if (p != k && tid < NB) {
-      double t = a[tid][k];
-      a[tid][k] = a[tid][p];
-      a[tid][p] = t;
-    }
+    if (tid < NB && tid > k) a[tid][k] = lk[tid];
     __syncthreads();
   }
+  // X = L^-1 (unit lower): column j by forward substitution
+  if (tid < NB) {
+    const int j = tid;
+    for (int r = 0; r < NB; ++r) {
+      double v = (r == j) ? 1.0 : 0.0;
+      for (int k = j; k < r; ++k) v -= a[r][k] * x[k][j];
+      x[r][j] = (r >= j) ? v : 0.0;
+    }
+  }
+  __syncthreads();
   double* D = dinv + (int64_t)f * NB * NB;
-  for (int k = tid; k < NB * NB; k += 256) D[k] = a[k % NB][k / NB];
+  for (int k = tid; k < NB * NB; k += 256) {
+    int r = k % NB, c = k / NB;
+    D[k] = x[r][c];
+    if (r < nbk && c < nbk) F[(int64_t)(k0 + c) * m + (k0 + r)] = (r >= c) ? x[r][c] : x[c][r];
+  }
+  if (tid < nbk) delta[2 * fnode_ptr[f] + k0 + tid] = dl[tid];
 }
 
-// Panel: W = R * Dinv for all rows outside the pivot block, R = F[:, pivot columns].  Saves R and W
-// for the update kernel and writes the swept pivot columns / rows back into F.
-__global__ __launch_bounds__(256) void k_sweep_panel(int first_front, int kb, const int32_t* __restrict__ fs2,
-                                                     const int32_t* __restrict__ fm, const int64_t* __restrict__ foff,
-                                                     const int64_t* __restrict__ fnode_ptr, double* __restrict__ front,
-                                                     const double* __restrict__ dinv, double* __restrict__ wbuf,
-                                                     double* __restrict__ rbuf) {
+// Triangular-inverse update: with X<k the inverse of the leading k0 x k0 block of L11,
+//   X[k, <k] = -X[k,k] * ( L[k, <k] * X<k ).
+// One lane per column c (coalesced reads of the mirrored X<k^T), NB accumulators per lane.
+__global__ __launch_bounds__(256) void k_ldl_invrow(int first_front, int kb, const int32_t* __restrict__ fs2,
+                                                    const int32_t* __restrict__ fm, const int64_t* __restrict__ foff,
+                                                    const int64_t* __restrict__ fnode_ptr, double* __restrict__ front,
+                                                    const double* __restrict__ dinv, const double* __restrict__ tbuf) {
+  const int f = first_front + blockIdx.y;
+  const int s2 = fs2[f];
+  const int k0 = kb * NB;
+  if (k0 >= s2 || k0 == 0) return;
+  const int c0 = blockIdx.x * 256;
+  if (c0 >= k0) return;
+  const int nbk = min(NB, s2 - k0);
+  const int m = fm[f];
+  double* F = front + foff[f];
+  const double* T = tbuf + 2 * fnode_ptr[f] * NB;
+  const double* D = dinv + (int64_t)f * NB * NB;
+  __shared__ double sL[NB][NB];       // [j in tile][q]
+  __shared__ double sX[NB][NB + 1];   // X[k,k]
+  const int tid = threadIdx.x;
+  for (int k = tid; k < NB * NB; k += 256) sX[k % NB][k / NB] = D[k];
+  const int c = c0 + tid;
+  const bool cv = c < k0;
+  double acc[NB];
+#pragma unroll
+  for (int q = 0; q < NB; ++q) acc[q] = 0.0;
+  for (int j0 = (c0 / NB) * NB; j0 < k0; j0 += NB) {
+    __syncthreads();
+    for (int k = tid; k < NB * NB; k += 256) sL[k / NB][k % NB] = T[(int64_t)j0 * NB + k];   // [j][q]
+    __syncthreads();
+    for (int jj = 0; jj < NB; ++jj) {
+      const int j = j0 + jj;
+      double xv = (cv && j >= c) ? F[(int64_t)j * m + c] : 0.0;   // X<k[j, c] from the upper mirror
+#pragma unroll
+      for (int q = 0; q < NB; ++q) acc[q] += sL[jj][q] * xv;
+    }
+  }
+  if (!cv) return;
+  for (int r = 0; r < nbk; ++r) {
+    double v = 0.0;
+#pragma unroll
+    for (int q = 0; q < NB; ++q) v += sX[r][q] * acc[q];
+    v = -v;
+    F[(int64_t)c * m + (k0 + r)] = v;
+    F[(int64_t)(k0 + r) * m + c] = v;
+  }
+}
+
+// Panel below the pivot block: Y = R X^T (= R L^-T), W = Y D^-1 (= the L panel).  Saves W, Y for the
+// update kernel and writes W into F (columns of the pivot block) and mirrored (rows).
+__global__ __launch_bounds__(256) void k_ldl_panel(int first_front, int kb, const int32_t* __restrict__ fs2,
+                                                   const int32_t* __restrict__ fm, const int64_t* __restrict__ foff,
+                                                   const int64_t* __restrict__ fnode_ptr, double* __restrict__ front,
+                                                   const double* __restrict__ dinv, const double* __restrict__ delta,
+                                                   double* __restrict__ wbuf, double* __restrict__ rbuf) {
   const int f = first_front + blockIdx.y;
   const int s2 = fs2[f];
   const int k0 = kb * NB;
   if (k0 >= s2) return;
   const int m = fm[f];
-  const int i0 = blockIdx.x * 64;
-  if (i0 >= m) return;
   const int nbk = min(NB, s2 - k0);
+  const int i0 = k0 + nbk + blockIdx.x * 64;
+  if (i0 >= m) return;
   double* F = front + foff[f];
   const double* D = dinv + (int64_t)f * NB * NB;
+  const double* dl = delta + 2 * fnode_ptr[f] + k0;
   double* W = wbuf + 2 * fnode_ptr[f] * NB;
-  double* R = rbuf + 2 * fnode_ptr[f] * NB;
-  __shared__ double sD[NB][NB + 1];
+  double* Y = rbuf + 2 * fnode_ptr[f] * NB;
+  __shared__ double sXT[NB][NB + 1];   // sXT[j][c] = X[c][j]
   __shared__ double sR[64][NB + 1];
+  __shared__ double sdi[NB];
   const int tid = threadIdx.x;
-  for (int k = tid; k < NB * NB; k += 256) sD[k % NB][k / NB] = D[k];
-  const int r = tid & 63, cq = tid >> 6;   // row r, column group cq (8 columns)
+  for (int k = tid; k < NB * NB; k += 256) sXT[k / NB][k % NB] = D[k];   // D[r + c*NB] = X[r][c] -> sXT[c][r]
+  if (tid < NB) sdi[tid] = (tid < nbk) ? 1.0 / dl[tid] : 0.0;
+  const int r = tid & 63, cq = tid >> 6;
   const int i = i0 + r;
   const bool valid = i < m;
-  const bool inpiv = valid && i >= k0 && i < k0 + nbk;
   for (int cc = 0; cc < 8; ++cc) {
     int c = cq * 8 + cc;
-    sR[r][c] = (valid && !inpiv && c < nbk) ? F[(int64_t)(k0 + c) * m + i] : 0.0;
+    sR[r][c] = (valid && c < nbk) ? F[(int64_t)(k0 + c) * m + i] : 0.0;
   }
   __syncthreads();
   if (!valid) return;
   for (int cc = 0; cc < 8; ++cc) {
     int c = cq * 8 + cc;
-    if (c >= nbk) {
-      W[(int64_t)c * m + i] = 0.0;
-      R[(int64_t)c * m + i] = 0.0;
-      continue;
-    }
-    double w = 0.0;
-    if (!inpiv) {
+    double y = 0.0;
+    if (c < nbk) {
 #pragma unroll 8
-      for (int k = 0; k < NB; ++k) w += sR[r][k] * sD[k][c];
+      for (int j = 0; j < NB; ++j) y += sR[r][j] * sXT[j][c];
     }
+    double w = y * sdi[c];
     W[(int64_t)c * m + i] = w;
-    R[(int64_t)c * m + i] = sR[r][c];
-    if (inpiv) {
-      F[(int64_t)(k0 + c) * m + i] = -sD[i - k0][c];
-    } else {
+    Y[(int64_t)c * m + i] = y;
+    if (c < nbk) {
       F[(int64_t)(k0 + c) * m + i] = w;
       F[(int64_t)i * m + (k0 + c)] = w;
     }
   }
 }
 
-// Update: F[i,j] -= sum_k W[i,k] R[j,k] for all i, j outside the pivot block, one 32x32 tile per
-// wave as 2x2 v_mfma_f64_16x16x4_f64 tiles.  MFMA operand map (gfx950): A[row = l&15][k = l>>4],
-// B[k = l>>4][col = l&15], D[row = (l>>4) + 4 r][col = l&15].  With A <- R rows (j) and B <- W rows
+// Trailing update: F[i,j] -= sum_c W[i,c] Y[j,c] for i, j >= k0 + nbk, one 32x32 tile per wave as 2x2
+// v_mfma_f64_16x16x4_f64 tiles.  MFMA operand map (gfx950): A[row = l&15][k = l>>4],
+// B[k = l>>4][col = l&15], D[row = (l>>4) + 4 r][col = l&15].  With A <- Y rows (j) and B <- W rows
 // (i) the accumulator register r of lane l is F[i0 + (l&15), j0 + (l>>4) + 4 r]: 128-B runs.
-__global__ __launch_bounds__(256) void k_sweep_update(int first_front, int kb, const int32_t* __restrict__ fs2,
-                                                      const int32_t* __restrict__ fm, const int64_t* __restrict__ foff,
-                                                      const int64_t* __restrict__ fnode_ptr, double* __restrict__ front,
-                                                      const double* __restrict__ wbuf, const double* __restrict__ rbuf) {
+__global__ __launch_bounds__(256) void k_ldl_update(int first_front, int kb, const int32_t* __restrict__ fs2,
+                                                    const int32_t* __restrict__ fm, const int64_t* __restrict__ foff,
+                                                    const int64_t* __restrict__ fnode_ptr, double* __restrict__ front,
+                                                    const double* __restrict__ wbuf, const double* __restrict__ rbuf) {
   const int f = first_front + blockIdx.z;
   const int s2 = fs2[f];
   const int k0 = kb * NB;
   if (k0 >= s2) return;
   const int m = fm[f];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int i0 = (blockIdx.x * 2 + (wave & 1)) * 32;
-  const int j0 = (blockIdx.y * 2 + (wave >> 1)) * 32;
-  if (i0 >= m || j0 >= m) return;
   const int nbk = min(NB, s2 - k0);
+  const int t0 = k0 + nbk;                 // first trailing index (multiple of 16)
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int i0 = t0 + (blockIdx.x * 2 + (wave & 1)) * 32;
+  const int j0 = t0 + (blockIdx.y * 2 + (wave >> 1)) * 32;
+  if (i0 >= m || j0 >= m) return;
   double* F = front + foff[f];
   const double* W = wbuf + 2 * fnode_ptr[f] * NB;
-  const double* R = rbuf + 2 * fnode_ptr[f] * NB;
+  const double* Y = rbuf + 2 * fnode_ptr[f] * NB;
   const int lr = lane & 15, lk = lane >> 4;
-  // 16-wide sub-tiles that are entirely inside the pivot block, or beyond m, are skipped
-  bool iv[2], jv[2];
-  for (int t = 0; t < 2; ++t) {
-    int ii = i0 + 16 * t, jj = j0 + 16 * t;
-    iv[t] = ii < m && !(ii >= k0 && ii < k0 + nbk);
-    jv[t] = jj < m && !(jj >= k0 && jj < k0 + nbk);
-  }
-  if (!((iv[0] || iv[1]) && (jv[0] || jv[1]))) return;
+  const bool iv1 = i0 + 16 < m, jv1 = j0 + 16 < m;
   v4d acc[2][2];
   for (int tj = 0; tj < 2; ++tj)
     for (int ti = 0; ti < 2; ++ti) acc[tj][ti] = (v4d){0.0, 0.0, 0.0, 0.0};
   for (int kk = 0; kk < nbk; kk += 4) {
     const int64_t col = (int64_t)(kk + lk) * m;
-    double a0 = jv[0] ? R[col + j0 + lr] : 0.0;
-    double a1 = jv[1] ? R[col + j0 + 16 + lr] : 0.0;
-    double b0 = iv[0] ? W[col + i0 + lr] : 0.0;
-    double b1 = iv[1] ? W[col + i0 + 16 + lr] : 0.0;
+    double a0 = Y[col + j0 + lr];
+    double a1 = jv1 ? Y[col + j0 + 16 + lr] : 0.0;
+    double b0 = W[col + i0 + lr];
+    double b1 = iv1 ? W[col + i0 + 16 + lr] : 0.0;
     acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
     acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
     acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
     acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
   }
   for (int tj = 0; tj < 2; ++tj) {
-    if (!jv[tj]) continue;
+    if (tj == 1 && !jv1) continue;
     for (int ti = 0; ti < 2; ++ti) {
-      if (!iv[ti]) continue;
+      if (ti == 1 && !iv1) continue;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         int64_t idx = (int64_t)(j0 + 16 * tj + lk + 4 * r) * m + (i0 + 16 * ti + lr);
@@ -292,7 +335,7 @@ __global__ __launch_bounds__(256) void k_sweep_update(int first_front, int kb, c
 }
 
 // ------------------------------------------------------------------------------------------------
-// solve sweeps
+// solve sweeps (all: one wave per DOF, dot product down a contiguous column of F)
 // ------------------------------------------------------------------------------------------------
 // forward, step 1: local right-hand side = global rhs at owned DOFs + children's updates
 __global__ __launch_bounds__(256) void k_fwd_gather(int first_front, int N, int leaf_level,
@@ -317,59 +360,95 @@ __global__ __launch_bounds__(256) void k_fwd_gather(int first_front, int N, int 
   fvec[2 * np + i] = v;
 }
 
-// forward, step 2: u = w_b - X^T z, one wave per boundary DOF (column of X)
-__global__ __launch_bounds__(256) void k_fwd_gemv(int first_front, const int32_t* __restrict__ fs2,
-                                                  const int32_t* __restrict__ fm, const int64_t* __restrict__ foff,
-                                                  const int64_t* __restrict__ fnode_ptr, const double* __restrict__ front,
-                                                  double* __restrict__ fvec) {
+// forward, step 2: y = L11^-1 r_own  (column i of the upper mirror holds row i of L11^-1)
+__global__ __launch_bounds__(256) void k_fwd_own(int first_front, const int32_t* __restrict__ fs2,
+                                                 const int32_t* __restrict__ fm, const int64_t* __restrict__ foff,
+                                                 const int64_t* __restrict__ fnode_ptr, const double* __restrict__ front,
+                                                 const double* __restrict__ fvec, double* __restrict__ fvec2) {
+  const int f = first_front + blockIdx.y;
+  const int m = fm[f], s2 = fs2[f];
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= s2) return;
+  const int lane = threadIdx.x & 63;
+  const double* col = front + foff[f] + (int64_t)i * m;
+  const double* w = fvec + 2 * fnode_ptr[f];
+  double acc = 0.0;
+  for (int j = lane; j <= i; j += 64) acc += col[j] * w[j];
+  for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
+  if (lane == 0) fvec2[2 * fnode_ptr[f] + i] = acc;
+}
+
+// forward, step 3: u = w_b - L21 y   (column s2+b of F12 = row b of L21)
+__global__ __launch_bounds__(256) void k_fwd_bnd(int first_front, const int32_t* __restrict__ fs2,
+                                                 const int32_t* __restrict__ fm, const int64_t* __restrict__ foff,
+                                                 const int64_t* __restrict__ fnode_ptr, const double* __restrict__ front,
+                                                 double* __restrict__ fvec, const double* __restrict__ fvec2) {
   const int f = first_front + blockIdx.y;
   const int m = fm[f], s2 = fs2[f];
   const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (s2 + j >= m) return;
   const int lane = threadIdx.x & 63;
   const double* col = front + foff[f] + (int64_t)(s2 + j) * m;
-  double* w = fvec + 2 * fnode_ptr[f];
+  const double* y = fvec2 + 2 * fnode_ptr[f];
   double acc = 0.0;
-  for (int i = lane; i < s2; i += 64) acc += col[i] * w[i];
+  for (int i = lane; i < s2; i += 64) acc += col[i] * y[i];
   for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
-  if (lane == 0) w[s2 + j] -= acc;
+  if (lane == 0) fvec[2 * fnode_ptr[f] + s2 + j] -= acc;
 }
 
-// backward: x_own = -[F11' ; X^T]^T [z ; x_b] = F11^-1 z - X x_b, one wave per owned DOF
-__global__ __launch_bounds__(256) void k_bwd_gemv(int first_front, int N, const int32_t* __restrict__ fs2,
-                                                  const int32_t* __restrict__ fm, const int64_t* __restrict__ foff,
-                                                  const int64_t* __restrict__ fnode_ptr,
-                                                  const int32_t* __restrict__ fnodes, const double* __restrict__ front,
-                                                  const double* __restrict__ fvec, double* __restrict__ x) {
+// backward, step 1: t = D^-1 y - L21^T x_b   (column j of F21 = column j of L21)
+__global__ __launch_bounds__(256) void k_bwd_t(int first_front, int N, const int32_t* __restrict__ fs2,
+                                               const int32_t* __restrict__ fm, const int64_t* __restrict__ foff,
+                                               const int64_t* __restrict__ fnode_ptr, const int32_t* __restrict__ fnodes,
+                                               const double* __restrict__ front, const double* __restrict__ delta,
+                                               double* __restrict__ fvec, const double* __restrict__ fvec2,
+                                               const double* __restrict__ x) {
   const int f = first_front + blockIdx.y;
   const int m = fm[f], s2 = fs2[f];
-  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (i >= s2) return;
+  const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (j >= s2) return;
   const int64_t np = fnode_ptr[f];
-  const int node_i = fnodes[np + (i >> 1)];
-  if (node_i < 0) return;
   const int lane = threadIdx.x & 63;
-  const double* col = front + foff[f] + (int64_t)i * m;
-  const double* w = fvec + 2 * np;
+  const double* col = front + foff[f] + (int64_t)j * m;
   double acc = 0.0;
-  for (int j = lane; j < m; j += 64) {
-    double v;
-    if (j < s2) v = w[j];
-    else {
-      int node = fnodes[np + (j >> 1)];
-      v = node >= 0 ? x[(int64_t)(j & 1) * N + node] : 0.0;
-    }
-    acc += col[j] * v;
+  for (int i = s2 + lane; i < m; i += 64) {
+    int node = fnodes[np + (i >> 1)];
+    double v = node >= 0 ? x[(int64_t)(i & 1) * N + node] : 0.0;
+    acc += col[i] * v;
   }
   for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
-  if (lane == 0) x[(int64_t)(i & 1) * N + node_i] = -acc;
+  if (lane == 0) fvec[2 * np + j] = fvec2[2 * np + j] / delta[2 * np + j] - acc;
+}
+
+// backward, step 2: x_own = L11^-T t   (column j of the lower triangle holds column j of L11^-1)
+__global__ __launch_bounds__(256) void k_bwd_x(int first_front, int N, const int32_t* __restrict__ fs2,
+                                               const int32_t* __restrict__ fm, const int64_t* __restrict__ foff,
+                                               const int64_t* __restrict__ fnode_ptr, const int32_t* __restrict__ fnodes,
+                                               const double* __restrict__ front, const double* __restrict__ fvec,
+                                               double* __restrict__ x) {
+  const int f = first_front + blockIdx.y;
+  const int m = fm[f], s2 = fs2[f];
+  const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (j >= s2) return;
+  const int64_t np = fnode_ptr[f];
+  const int node_j = fnodes[np + (j >> 1)];
+  if (node_j < 0) return;
+  const int lane = threadIdx.x & 63;
+  const double* col = front + foff[f] + (int64_t)j * m;
+  const double* t = fvec + 2 * np;
+  double acc = 0.0;
+  for (int i = j + lane; i < s2; i += 64) acc += col[i] * t[i];
+  for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
+  if (lane == 0) x[(int64_t)(j & 1) * N + node_j] = acc;
 }
 
 }  // namespace
 
-void launch_factor(plfem_ctx* c, double sigma) {
+void launch_factor(plfem_ctx* c, double sigma, int stop_level, int stop_step, int stop_stage) {
+  // stop_*: debugging aid (plfem_debug_factor_until); stop_level < 0 = run to completion.
+  // stages: 0 assembled, 1 diag, 2 invrow, 3 panel, 4 update, 5 level done
   hipStream_t st = c->stream;
-  hipMemsetAsync(c->d_counters, 0, 4 * sizeof(int32_t), st);
+  (void)hipMemsetAsync(c->d_counters, 0, 4 * sizeof(int32_t), st);
   for (int lev = c->L; lev >= 0; --lev) {
     const LevelInfo& li = c->levels[lev];
     if (lev == c->L) {
@@ -381,36 +460,57 @@ void launch_factor(plfem_ctx* c, double sigma) {
       hipLaunchKernelGGL(k_front_gather, grid, dim3(256), 0, st, li.first, c->d_fs2, c->d_fm, c->d_foff,
                          c->d_fnode_ptr, c->d_fnodes, c->d_cinv0, c->d_cinv1, c->d_front);
     }
+    if (lev == stop_level && stop_stage == 0) return;
     const int steps = (li.max_s2 + NB - 1) / NB;
     for (int kb = 0; kb < steps; ++kb) {
-      hipLaunchKernelGGL(k_sweep_diag, dim3(li.count), dim3(256), 0, st, li.first, kb, c->d_fs2, c->d_fm, c->d_foff,
-                         c->d_front, c->d_dinv, c->d_counters);
-      hipLaunchKernelGGL(k_sweep_panel, dim3((li.max_m + 63) / 64, li.count), dim3(256), 0, st, li.first, kb,
-                         c->d_fs2, c->d_fm, c->d_foff, c->d_fnode_ptr, c->d_front, c->d_dinv, c->d_wbuf, c->d_rbuf);
-      dim3 ug((li.max_m + 63) / 64, (li.max_m + 63) / 64, li.count);
-      hipLaunchKernelGGL(k_sweep_update, ug, dim3(256), 0, st, li.first, kb, c->d_fs2, c->d_fm, c->d_foff,
-                         c->d_fnode_ptr, c->d_front, c->d_wbuf, c->d_rbuf);
+      const bool stop_here = (lev == stop_level && kb == stop_step);
+      const int k0 = kb * NB;
+      const int max_trail = li.max_m - k0 - 16;   // upper bound of the trailing order after this step
+      hipLaunchKernelGGL(k_ldl_diag, dim3(li.count), dim3(256), 0, st, li.first, kb, c->d_fs2, c->d_fm, c->d_foff,
+                         c->d_fnode_ptr, c->d_front, c->d_dinv, c->d_delta, c->d_tbuf, c->d_counters);
+      if (stop_here && stop_stage == 1) return;
+      if (kb > 0)
+        hipLaunchKernelGGL(k_ldl_invrow, dim3((k0 + 255) / 256, li.count), dim3(256), 0, st, li.first, kb, c->d_fs2,
+                           c->d_fm, c->d_foff, c->d_fnode_ptr, c->d_front, c->d_dinv, c->d_tbuf);
+      if (stop_here && stop_stage == 2) return;
+      if (max_trail > 0) {
+        hipLaunchKernelGGL(k_ldl_panel, dim3((max_trail + 63) / 64, li.count), dim3(256), 0, st, li.first, kb,
+                           c->d_fs2, c->d_fm, c->d_foff, c->d_fnode_ptr, c->d_front, c->d_dinv, c->d_delta, c->d_wbuf,
+                           c->d_rbuf);
+        if (stop_here && stop_stage == 3) return;
+        dim3 ug((max_trail + 63) / 64, (max_trail + 63) / 64, li.count);
+        hipLaunchKernelGGL(k_ldl_update, ug, dim3(256), 0, st, li.first, kb, c->d_fs2, c->d_fm, c->d_foff,
+                           c->d_fnode_ptr, c->d_front, c->d_wbuf, c->d_rbuf);
+      }
+      if (stop_here && stop_stage == 4) return;
     }
+    if (lev == stop_level && stop_stage == 5) return;
   }
 }
 
 void launch_solve(plfem_ctx* c, const double* rhs, double* x) {
   hipStream_t st = c->stream;
-  hipMemsetAsync(x, 0, sizeof(double) * c->n2, st);
+  (void)hipMemsetAsync(x, 0, sizeof(double) * c->n2, st);
   for (int lev = c->L; lev >= 0; --lev) {
     const LevelInfo& li = c->levels[lev];
     hipLaunchKernelGGL(k_fwd_gather, dim3((li.max_m + 255) / 256, li.count), dim3(256), 0, st, li.first, c->N,
                        lev == c->L ? 1 : 0, c->d_fs2, c->d_fm, c->d_fnode_ptr, c->d_fnodes, c->d_cinv0, c->d_cinv1,
                        rhs, c->d_fvec);
-    if (li.max_b2 > 0)
-      hipLaunchKernelGGL(k_fwd_gemv, dim3((li.max_b2 + 3) / 4, li.count), dim3(256), 0, st, li.first, c->d_fs2,
-                         c->d_fm, c->d_foff, c->d_fnode_ptr, c->d_front, c->d_fvec);
+    if (li.max_s2 > 0)
+      hipLaunchKernelGGL(k_fwd_own, dim3((li.max_s2 + 3) / 4, li.count), dim3(256), 0, st, li.first, c->d_fs2,
+                         c->d_fm, c->d_foff, c->d_fnode_ptr, c->d_front, c->d_fvec, c->d_fvec2);
+    if (li.max_b2 > 0 && li.max_s2 > 0)
+      hipLaunchKernelGGL(k_fwd_bnd, dim3((li.max_b2 + 3) / 4, li.count), dim3(256), 0, st, li.first, c->d_fs2,
+                         c->d_fm, c->d_foff, c->d_fnode_ptr, c->d_front, c->d_fvec, c->d_fvec2);
   }
   for (int lev = 0; lev <= c->L; ++lev) {
     const LevelInfo& li = c->levels[lev];
-    if (li.max_s2 > 0)
-      hipLaunchKernelGGL(k_bwd_gemv, dim3((li.max_s2 + 3) / 4, li.count), dim3(256), 0, st, li.first, c->N, c->d_fs2,
-                         c->d_fm, c->d_foff, c->d_fnode_ptr, c->d_fnodes, c->d_front, c->d_fvec, x);
+    if (li.max_s2 <= 0) continue;
+    hipLaunchKernelGGL(k_bwd_t, dim3((li.max_s2 + 3) / 4, li.count), dim3(256), 0, st, li.first, c->N, c->d_fs2,
+                       c->d_fm, c->d_foff, c->d_fnode_ptr, c->d_fnodes, c->d_front, c->d_delta, c->d_fvec, c->d_fvec2,
+                       x);
+    hipLaunchKernelGGL(k_bwd_x, dim3((li.max_s2 + 3) / 4, li.count), dim3(256), 0, st, li.first, c->N, c->d_fs2,
+                       c->d_fm, c->d_foff, c->d_fnode_ptr, c->d_fnodes, c->d_front, c->d_fvec, x);
   }
 }
 
