@@ -55,7 +55,14 @@ __global__ __launch_bounds__(256) void k_element_matrices(
       double x0 = doflocs[v0], y0 = doflocs[N + v0];
       double j00 = doflocs[v1] - x0, j10 = doflocs[N + v1] - y0;      // J = [p1-p0, p2-p0]
       double j01 = doflocs[v2] - x0, j11 = doflocs[N + v2] - y0;
-      double det = j00 * j11 - j01 * j10;
+      // det J of a sliver element cancels to ~1e-8 of its terms: keep the two products individually
+      // rounded (as the reference's NumPy arithmetic does); a fused multiply-add here changes 1e9-sized
+      // element entries at the 1e-8 relative level.  hipcc's default -ffp-contract=fast ignores the
+      // contract pragma, hence the opaque multiplies.
+      double t1, t2;
+      asm volatile("v_mul_f64 %0, %1, %2" : "=v"(t1) : "v"(j00), "v"(j11));
+      asm volatile("v_mul_f64 %0, %1, %2" : "=v"(t2) : "v"(j01), "v"(j10));
+      double det = t1 - t2;
       double idet = 1.0 / det;
       // J^-1 = 1/det [[j11, -j01], [-j10, j00]];  grad = J^-T grad_hat
       double i00 = j11 * idet, i01 = -j01 * idet, i10 = -j10 * idet, i11 = j00 * idet;

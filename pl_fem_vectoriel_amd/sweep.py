@@ -1,0 +1,144 @@
+"""Parametric sweep of independent cross-sections over the GPUs of one node.
+
+The reference has no distributed code: every cross-section (arrangement, pitch,
+wavelength) is an independent call of ``solve_vectorial_modes`` (``solver_fem.py:171`` keeps no state
+between calls).  The path therefore shards across *solves* only: one process per GPU
+(``torch.distributed``, backend ``nccl`` = RCCL over xGMI), a static cost-balanced partition, no
+collective on the data path, and one all-gather of fixed-size padded records at the end
+(SURVEY.md §8e).  The four wavelengths of one mesh stay on one rank so the mesh-only analysis, the
+device context and its HBM workspaces are built once per mesh.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Callable, Dict, List, Optional, Sequence
+
+import numpy as np
+
+from .geometry import ARRANGEMENTS, MCFGeometry
+
+K_MAX = 48          # padded record width: up to 48 effective indices per solve
+REC_WIDTH = K_MAX + 4
+
+
+@dataclass(frozen=True)
+class SweepItem:
+    index: int
+    arrangement: str
+    pitch_um: float
+    wavelength_um: float
+    core_radius_um: float = 1.5
+    n_core: float = 1.535
+    n_clad: float = 1.0
+    n_modes: int = 10
+    mesh_refinement: float = 1.0
+    mesh_levels: int = 1
+
+    @property
+    def mesh_key(self):
+        return (self.arrangement, self.pitch_um, self.core_radius_um, self.mesh_refinement, self.mesh_levels)
+
+    def geometry(self) -> MCFGeometry:
+        n, variant = ARRANGEMENTS[self.arrangement]
+        return MCFGeometry(n, self.pitch_um, self.core_radius_um, self.n_core, self.n_clad,
+                           wavelength_um=self.wavelength_um, variant=variant)
+
+    def cost(self) -> float:
+        """~ N^1.5 with N ~ number of mesh points (cores dominate the point recipe)."""
+        n = ARRANGEMENTS[self.arrangement][0]
+        pts = 2000.0 + 512.0 * n
+        return (pts * 4 ** self.mesh_levels) ** 1.5
+
+
+def multiband_sweep_items(n_modes: int = 10, mesh_levels: int = 1, mesh_refinement: float = 1.0) -> List[SweepItem]:
+    """BASELINE.json config 4: 16 cross-sections x 4 wavelengths = 64 independent solves
+    (the 12 multi-core layouts at pitch 8 um + 4 pitch variants of the 7-core layout)."""
+    sections = [(a, 8.0) for a in ARRANGEMENTS if a != "single_1"]
+    sections += [("hexagonal_1plus6_7", p) for p in (6.0, 7.0, 9.0, 10.0)]
+    items = []
+    for arr, pitch in sections:
+        for lam in (1.49, 1.55, 1.60, 1.65):
+            items.append(SweepItem(len(items), arr, pitch, lam, n_modes=n_modes, mesh_levels=mesh_levels,
+                                   mesh_refinement=mesh_refinement))
+    return items
+
+
+def partition(items: Sequence[SweepItem], world_size: int) -> List[List[SweepItem]]:
+    """Static partition: groups sharing a mesh stay together; groups dealt heaviest-first to the least
+    loaded rank that still has room (longest-processing-time rule under an equal-count cap).
+    Deterministic — every rank computes the same table."""
+    groups: Dict[tuple, List[SweepItem]] = {}
+    for it in items:
+        groups.setdefault(it.mesh_key, []).append(it)
+    order = sorted(groups.values(), key=lambda g: (-sum(i.cost() for i in g), g[0].index))
+    cap = -(-len(order) // world_size)          # at most ceil(G / world_size) meshes per rank (8 solves per GPU in C4)
+    loads = [0.0] * world_size
+    counts = [0] * world_size
+    out: List[List[SweepItem]] = [[] for _ in range(world_size)]
+    for g in order:
+        r = min((q for q in range(world_size) if counts[q] < cap), key=lambda q: (loads[q], q))
+        out[r].extend(g)
+        loads[r] += sum(i.cost() for i in g)
+        counts[r] += 1
+    return out
+
+
+def default_solve(device: Optional[int] = None) -> Callable[[SweepItem, dict], np.ndarray]:
+    """Solve one item on the GPU; ``cache`` keeps one solver (symbolic analysis + context) per mesh."""
+    from .mesh import generate_mesh
+    from .solver_fem import TrueVectorialMaxwellSolver
+
+    def solve(item: SweepItem, cache: dict) -> np.ndarray:
+        g = item.geometry()
+        ent = cache.get("cur")
+        if ent is None or ent["key"] != item.mesh_key:
+            if ent is not None:
+                ent["solver"].clear_cache()
+            ent = {"key": item.mesh_key, "mesh": generate_mesh(g, item.mesh_refinement, item.mesh_levels),
+                   "solver": TrueVectorialMaxwellSolver(g, device=device)}
+            cache["cur"] = ent
+        s = ent["solver"]
+        s.geometry, s.k0 = g, g.k0
+        modes = s.solve_vectorial_modes(ent["mesh"], item.n_modes)
+        return np.array([m["n_eff"] for m in modes], dtype=np.float64)
+
+    return solve
+
+
+def run_sweep(items: Sequence[SweepItem], rank: int = 0, world_size: int = 1,
+              solve: Optional[Callable[[SweepItem, dict], np.ndarray]] = None, device=None,
+              gather: bool = True):
+    """Solve this rank's share and gather fixed-size records on every rank.
+
+    Returns ``(table, local_count)``; ``table[i]`` is the descending n_eff list of item ``i``
+    (available on all ranks after the gather).  Records are ``[index, count, rank, 0, n_eff...]``
+    padded with NaN to ``REC_WIDTH`` doubles — the only inter-GPU traffic of the whole sweep.
+    """
+    import torch
+
+    mine = partition(items, world_size)[rank]
+    if solve is None:
+        solve = default_solve(device)
+    cache: dict = {}
+    per_rank = max(len(p) for p in partition(items, world_size))
+    rec = np.full((per_rank, REC_WIDTH), np.nan)
+    rec[:, 0] = -1
+    for q, it in enumerate(mine):
+        ne = np.asarray(solve(it, cache), dtype=np.float64)[:K_MAX]
+        rec[q, 0], rec[q, 1], rec[q, 2], rec[q, 3] = it.index, len(ne), rank, 0
+        rec[q, 4:4 + len(ne)] = ne
+    table: Dict[int, np.ndarray] = {}
+    if world_size > 1 and gather:
+        import torch.distributed as dist
+
+        dev = torch.device("cuda", device) if (device is not None and dist.get_backend() == "nccl") else torch.device("cpu")
+        local = torch.from_numpy(rec).to(dev)
+        bufs = [torch.empty_like(local) for _ in range(world_size)]
+        dist.all_gather(bufs, local)
+        allrec = torch.stack(bufs).cpu().numpy().reshape(-1, REC_WIDTH)
+    else:
+        allrec = rec
+    for row in allrec:
+        if row[0] >= 0:
+            table[int(row[0])] = row[4:4 + int(row[1])].copy()
+    return table, len(mine)

@@ -1,0 +1,308 @@
+"""GPU parity tests: the HIP path, called through the C-ABI (ctypes), against the oracle on identical
+meshes.  Tolerances: north_star asks |dn_eff| < 5e-5 and field L2 < 1e-6; the matrices themselves are
+compared to 1e-13 of the assembled magnitude."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import scipy.sparse.linalg as spla
+
+import front_emulation as fe
+from oracle import hfield
+from oracle.p2 import MeshTriLite, P2Basis
+from pl_fem_vectoriel_amd import MCFGeometry, _native
+from pl_fem_vectoriel_amd.mesh import generate_mesh, unit_square_mesh
+from pl_fem_vectoriel_amd.solver_fem import TrueVectorialMaxwellSolver, _core_table, shift_estimate
+
+pytestmark = pytest.mark.gpu
+
+N_EFF_TOL = 5e-5      # north_star
+FIELD_TOL = 1e-6      # north_star
+
+
+class Problem:
+    def __init__(self, g, mesh, device, leaf_elems=0):
+        import torch
+        self.torch = torch
+        self.g, self.mesh = g, mesh
+        self.sym = _native.Symbolic(mesh.p, mesh.t, leaf_elems=leaf_elems)
+        self.ctx = _native.Context(self.sym, device, max_ncv=65)
+        self.ctx.assemble(_core_table(g), g.n_core ** 2, g.n_clad ** 2, g.k0, 1.0)
+        self.om = MeshTriLite(mesh.p, mesh.t)
+        self.basis = P2Basis(self.om)
+        self.em = hfield.element_matrices(g, self.basis)
+        self.A, self.B, _, self.Dxx, self.Dyy, self.Dxy, self.Minv = \
+            hfield.assemble_hfield_system_fused(g, self.om, eliminate_zeros=False)
+        self.N = self.basis.N
+        self.A_int, self.B_int, self.interior = hfield.restrict_interior(self.A, self.B, self.basis)
+        self.idx = np.concatenate([self.interior, self.interior + self.N])
+        self.sigma = shift_estimate(g)
+
+    def embed(self, v):
+        full = np.zeros(2 * self.N)
+        full[self.idx] = v
+        return self.torch.from_numpy(full).cuda()
+
+
+@pytest.fixture(scope="module")
+def small(c1_geometry, gpu_device, built_library):
+    return Problem(c1_geometry, generate_mesh(c1_geometry, 0.5, 0), gpu_device, leaf_elems=24)
+
+
+@pytest.fixture(scope="module")
+def medium(c1_geometry, gpu_device, built_library):
+    """C3 ladder rung L=0 of the north-star geometry (N = 22 694), contains near-degenerate triangles."""
+    return Problem(c1_geometry, generate_mesh(c1_geometry, 1.0, 0), gpu_device)
+
+
+def _abs_assembled(P, name_terms):
+    """Sum of |element entries| per CSR slot: the magnitude rounding errors are measured against."""
+    ed = P.basis.element_dofs
+    rows = np.broadcast_to(ed.T[:, :, None], (ed.shape[1], 6, 6)).ravel()
+    cols = np.broadcast_to(ed.T[:, None, :], (ed.shape[1], 6, 6)).ravel()
+    mag = sum(np.abs(t) for t in name_terms)
+    return sp.coo_matrix((mag.ravel(), (rows, cols)), shape=(P.N, P.N)).tocsr()
+
+
+@pytest.mark.parametrize("prob", ["small", "medium"])
+def test_assembled_blocks_match_oracle(prob, request):
+    P = request.getfixturevalue(prob)
+    N, em, k0sq = P.N, P.em, P.g.k0 ** 2
+    rowptr, colind = P.sym.array("rowptr"), P.sym.array("colind")
+    refs = {
+        "Axx": (P.A[:N, :N], [em["kxx"], em["div_xx"], k0sq * em["mass"]]),
+        "Axy": (P.A[:N, N:], [em["kxy"], em["div_xy"]]),
+        "Ayx": (P.A[N:, :N], [em["kyx"], em["div_xy"]]),
+        "Ayy": (P.A[N:, N:], [em["kyy"], em["div_yy"], k0sq * em["mass"]]),
+        "Minv": (P.Minv, [em["mass_eps_inv"]]), "Dxx": (P.Dxx, [em["div_xx"]]),
+        "Dxy": (P.Dxy, [em["div_xy"]]), "Dyy": (P.Dyy, [em["div_yy"]]),
+    }
+    for name, (R, terms) in refs.items():
+        G = sp.csr_matrix((P.ctx.block_values(name), colind, rowptr), shape=(N, N))
+        mag = _abs_assembled(P, terms)
+        D = abs(G - R)
+        D.eliminate_zeros()
+        # |diff| <= 1e-13 * sum|contributions| entry by entry
+        viol = D - 1e-13 * mag
+        assert viol.max() <= 0.0, (name, D.max(), mag.max())
+
+
+def test_reference_surface_assemble_hfield_system(small, gpu_device):
+    solver = TrueVectorialMaxwellSolver(small.g, device=gpu_device)
+    A, B, basis, Dxx, Dyy, Dxy, Minv = solver.assemble_hfield_system(small.mesh)
+    N = small.N
+    assert basis.N == N and A.shape == (2 * N, 2 * N) and B.shape == (2 * N, 2 * N)
+    np.testing.assert_array_equal(basis.doflocs, small.basis.doflocs)
+    np.testing.assert_array_equal(basis.get_dofs().all(), small.basis.get_dofs().all())
+    np.testing.assert_array_equal(basis.element_dofs, small.basis.element_dofs)
+    sc = abs(small.A).max()
+    assert abs(A - small.A).max() < 1e-12 * sc
+    assert abs(B - small.B).max() < 1e-13 * abs(small.B).max()
+    assert abs(Dxy - small.Dxy).max() < 1e-12 * abs(small.Dxy).max()
+    assert abs(Minv - small.Minv).max() < 1e-13 * abs(small.Minv).max()
+    assert abs(A - A.T).max() < 1e-12 * sc
+
+
+def test_spmv_matches_restricted_pencil(medium):
+    P = medium
+    x = np.random.default_rng(0).standard_normal(len(P.idx))
+    xd = P.embed(x)
+    for which, M in (("A", P.A_int), ("B", P.B_int)):
+        y = P.ctx.spmv(which, xd).cpu().numpy()
+        ref = M @ x
+        assert np.abs(y[P.idx] - ref).max() <= 1e-13 * (abs(M) @ np.abs(x)).max()
+        assert np.abs(np.delete(y, P.idx)).max() == 0.0            # Dirichlet rows masked
+
+
+def test_fronts_match_numpy_emulation(small):
+    P = small
+    T = fe.FrontTree(P.sym)
+    Ke = fe.element_K(P.em, P.g.k0 ** 2, P.sigma)
+    Fs, Ds = fe.factor(T, Ke)
+    P.ctx.factor(P.sigma)
+    P.ctx.synchronize()
+    assert P.ctx.timings()["pivot_perturbations"] == 0
+    for f in [0, 1, 2, 5, 11, T.leaf0 - 1, T.leaf0, T.leaf0 + 7, T.nf - 1] + list(range(17, T.nf, 97)):
+        m, s2 = T.m(f), T.s2(f)
+        Fg = P.ctx.debug_copy("front", T.foff[f], m * m).reshape(m, m).T
+        for name, a, b in (("F11", Fg[:s2, :s2], Fs[f][:s2, :s2]), ("L21", Fg[s2:, :s2], Fs[f][s2:, :s2]),
+                           ("L21T", Fg[:s2, s2:], Fs[f][:s2, s2:]), ("S", Fg[s2:, s2:], Fs[f][s2:, s2:])):
+            if a.size:
+                assert np.abs(a - b).max() <= 1e-8 * max(np.abs(b).max(), 1e-300), (f, name)
+        if s2:
+            dg = P.ctx.debug_copy("delta", 2 * T.fptr[f], s2)
+            assert np.abs(dg - Ds[f]).max() <= 1e-8 * np.abs(Ds[f]).max(), f
+
+
+@pytest.mark.parametrize("prob", ["small", "medium"])
+def test_shift_invert_solve_matches_splu(prob, request):
+    P = request.getfixturevalue(prob)
+    P.ctx.factor(P.sigma)
+    K = (P.A_int - P.sigma * P.B_int).tocsc()
+    lu = spla.splu(K)
+    b = np.random.default_rng(1).standard_normal(len(P.idx))
+    xs = lu.solve(b)
+    x0 = P.ctx.solve(P.embed(b), 0).cpu().numpy()
+    x1 = P.ctx.solve(P.embed(b), 1).cpu().numpy()
+    assert np.abs(np.delete(x0, P.idx)).max() == 0.0
+    assert np.linalg.norm(x0[P.idx] - xs) / np.linalg.norm(xs) < 1e-9
+    assert np.linalg.norm(x1[P.idx] - xs) / np.linalg.norm(xs) < 1e-9
+    r0 = np.linalg.norm(K @ x0[P.idx] - b) / np.linalg.norm(b)
+    r1 = np.linalg.norm(K @ x1[P.idx] - b) / np.linalg.norm(b)
+    assert r1 <= max(r0, 1e-11) and r1 < 1e-8
+
+
+def _match_fields(V, U, w, gap_tol=1e-4):
+    """Sign-invariant per-mode L2 error; cluster-wise subspace distance where eigenvalue gaps < gap_tol |lambda|."""
+    k = len(w)
+    errs = np.zeros(k)
+    i = 0
+    while i < k:
+        j = i + 1
+        while j < k and abs(w[j] - w[j - 1]) < gap_tol * abs(w[j]):
+            j += 1
+        a = V[:, i:j] / np.linalg.norm(V[:, i:j], axis=0)
+        b = U[:, i:j] / np.linalg.norm(U[:, i:j], axis=0)
+        if j - i == 1:
+            errs[i] = min(np.linalg.norm(a[:, 0] - b[:, 0]), np.linalg.norm(a[:, 0] + b[:, 0]))
+        else:
+            Qa, _ = np.linalg.qr(a)
+            Qb, _ = np.linalg.qr(b)
+            errs[i:j] = np.linalg.norm(Qa - Qb @ (Qb.T @ Qa), 2)
+        i = j
+    return errs
+
+
+def test_eigenpairs_match_scipy_eigsh(medium):
+    """k = 22 pairs nearest sigma vs eigsh with the reference's arguments (solver_fem.py:197)."""
+    P = medium
+    k, ncv = 22, 45
+    P.ctx.factor(P.sigma)
+    evals, evecs, st = P.ctx.lanczos(k, ncv, 1e-10, 12000, P.sigma)
+    assert st["nconv"] == k
+    w, U = spla.eigsh(P.A_int, k=k, M=P.B_int, sigma=P.sigma, which="LM", tol=1e-7, maxiter=12000)
+    o = np.argsort(w)
+    w, U = w[o], U[:, o]
+    assert (np.diff(evals) >= 0).all()
+    dn = np.abs(np.sqrt(evals) - np.sqrt(w)).max() / P.g.k0
+    assert dn < N_EFF_TOL and dn < 1e-10, dn
+    V = evecs.cpu().numpy()[:, P.idx].T
+    assert np.abs(np.delete(evecs.cpu().numpy(), P.idx, axis=1)).max() == 0.0
+    assert _match_fields(V, U, w).max() < FIELD_TOL
+    # B-orthonormal like eigsh's output, and true eigenpairs of the pencil
+    assert np.abs(V.T @ (P.B_int @ V) - np.eye(k)).max() < 1e-10
+    R = P.A_int @ V - (P.B_int @ V) * evals
+    assert (np.linalg.norm(R, axis=0) / np.linalg.norm(P.A_int @ V, axis=0)).max() < 1e-8
+
+
+def test_mode_records_match_oracle(medium, gpu_device):
+    P = medium
+    solver = TrueVectorialMaxwellSolver(P.g, device=gpu_device)
+    modes = solver.solve_vectorial_modes(P.mesh, n_modes_target=10)
+    ref = hfield.solve_vectorial_modes(P.g, P.om, n_modes_target=10, fused=True)
+    assert len(modes) == len(ref) == 22                            # no truncation to n_modes_target (solver_fem.py:239)
+    assert [m["n_eff"] for m in modes] == sorted((m["n_eff"] for m in modes), reverse=True)
+    for a, b in zip(modes, ref):
+        assert set(a) == set(b)
+        assert abs(a["n_eff"] - b["n_eff"]) < N_EFF_TOL and abs(a["beta"] - b["beta"]) < 1e-9
+        va = np.concatenate([a["Ex_dofs"], a["Ey_dofs"]])
+        vb = np.concatenate([b["Ex_dofs"], b["Ey_dofs"]])
+        assert a["Ex_dofs"].shape == b["Ex_dofs"].shape
+        assert min(np.linalg.norm(va - vb), np.linalg.norm(va + vb)) < FIELD_TOL
+        for key in ("P_x", "P_y", "confinement", "core_overlap", "div_ratio", "PDL_dB"):
+            assert abs(a[key] - b[key]) <= 1e-6 * max(1.0, abs(b[key])), key
+        assert a["polarization"] == b["polarization"] and a["is_vectorial"] is True and a["method"] == b["method"]
+        assert a.n_eff == a["n_eff"]                               # README-style attribute access
+    assert solver.last_stats["nconv"] == 22
+
+
+def test_wavelength_sweep_reuses_analysis_and_is_deterministic(small, gpu_device):
+    mesh = small.mesh
+    solver = TrueVectorialMaxwellSolver(small.g, device=gpu_device)
+    out = {}
+    for lam in (1.49, 1.55, 1.60, 1.65, 1.55):
+        g = MCFGeometry(7, 8.0, 1.5, 1.535, 1.0, wavelength_um=lam)
+        solver.geometry, solver.k0 = g, g.k0
+        modes = solver.solve_vectorial_modes(mesh, 6)
+        key = (lam, len(out))
+        out[key] = modes
+    assert len(solver._cache) == 1                                  # one symbolic analysis / context for the sweep
+    first, again = out[(1.55, 1)], out[(1.55, 4)]
+    for a, b in zip(first, again):                                  # bitwise reproducible (no float atomics)
+        assert a["n_eff"] == b["n_eff"]
+        np.testing.assert_array_equal(a["Ex_dofs"], b["Ex_dofs"])
+    g = MCFGeometry(7, 8.0, 1.5, 1.535, 1.0, wavelength_um=1.60)
+    ref = hfield.solve_vectorial_modes(g, small.om, 6, fused=True)
+    got = out[(1.60, 2)]
+    assert len(got) == len(ref)
+    assert max(abs(a["n_eff"] - b["n_eff"]) for a, b in zip(got, ref)) < N_EFF_TOL
+
+
+def test_edge_cases_and_errors(gpu_device, built_library):
+    # tiny mesh: request clamped to 2 N_solve - 4 (solver_fem.py:196)
+    g1 = MCFGeometry(1, 0.0, 0.3, 1.535, 1.0, wavelength_um=1.55)
+    sq = unit_square_mesh(2)                                         # 9 interior P2 DOFs -> n = 18
+    sq.p[:] = sq.p - 0.5
+    solver = TrueVectorialMaxwellSolver(g1, device=gpu_device)
+    modes = solver.solve_vectorial_modes(sq, n_modes_target=20)
+    st = solver.last_stats
+    assert st["n_req"] == 2 * st["N_solve"] - 4 == 14 and st["nconv"] == 14
+    ref = hfield.solve_vectorial_modes(g1, MeshTriLite(sq.p, sq.t), 20, fused=True)
+    assert len(modes) == len(ref)
+    for a, b in zip(modes, ref):
+        assert abs(a["n_eff"] - b["n_eff"]) < N_EFF_TOL
+    # call-order errors surface as exceptions, never as silent results
+    mesh = unit_square_mesh(4)
+    sym = _native.Symbolic(mesh.p, mesh.t)
+    ctx = _native.Context(sym, gpu_device, max_ncv=45)
+    x = ctx.empty(ctx.n2)
+    with pytest.raises(RuntimeError):
+        ctx.spmv("A", x)                                             # before assemble
+    ctx.assemble(_core_table(g1), 2.0, 1.0, 4.0, 1.0)
+    with pytest.raises(RuntimeError):
+        ctx.solve(x)                                                 # before factor
+    with pytest.raises(RuntimeError):
+        ctx.lanczos(4, 12, 1e-10, 100, 1.0)                          # before factor
+    ctx.factor(1.0)
+    with pytest.raises(ValueError):
+        ctx.lanczos(4, 60, 1e-10, 100, 1.0)                          # ncv > max_ncv
+    with pytest.raises(ValueError):
+        ctx.assemble(_core_table(g1), -1.0, 1.0, 4.0, 1.0)           # non-physical permittivity
+
+
+def test_nineteen_core_layout(gpu_device, built_library):
+    g = MCFGeometry(19, 8.0, 1.5, 1.535, 1.0, wavelength_um=1.55)
+    mesh = generate_mesh(g, 0.35, 0)
+    solver = TrueVectorialMaxwellSolver(g, device=gpu_device)
+    modes = solver.solve_vectorial_modes(mesh, n_modes_target=8)
+    ref = hfield.solve_vectorial_modes(g, MeshTriLite(mesh.p, mesh.t), 8, fused=True)
+    assert len(modes) == len(ref) > 0
+    assert max(abs(a["n_eff"] - b["n_eff"]) for a, b in zip(modes, ref)) < N_EFF_TOL
+
+
+def test_north_star_size_properties(c1_geometry, gpu_device, built_library):
+    """C1 (N = 90 639, n = 180 742, k = 22): size-independent properties instead of a CPU re-solve."""
+    import torch
+    g = c1_geometry
+    mesh = generate_mesh(g, 1.0, 1)
+    sym = _native.Symbolic(mesh.p, mesh.t)
+    assert (sym.N, 2 * sym.nsolve) == (90639, 180742)
+    ctx = _native.Context(sym, gpu_device, max_ncv=65)
+    ctx.assemble(_core_table(g), g.n_core ** 2, g.n_clad ** 2, g.k0, 1.0)
+    sigma = shift_estimate(g)
+    ctx.factor(sigma)
+    evals, V, st = ctx.lanczos(22, 45, 1e-10, 12000, sigma)
+    assert st["nconv"] == 22 and (np.diff(evals) >= 0).all()
+    n_eff = np.sqrt(evals) / g.k0
+    assert (n_eff > g.n_clad).all() and (n_eff < g.n_core).all()
+    AV = torch.stack([ctx.spmv("A", V[i]) for i in range(22)])
+    BV = torch.stack([ctx.spmv("B", V[i]) for i in range(22)])
+    lam = torch.from_numpy(evals).cuda()[:, None]
+    res = (AV - lam * BV).norm(dim=1) / AV.norm(dim=1)
+    assert res.max().item() < 1e-8                                    # eigen-residuals
+    G = V @ BV.T
+    assert (G - torch.eye(22, device=G.device, dtype=G.dtype)).abs().max().item() < 1e-10   # B-orthonormal
+    # shift-invert consistency: K^-1 (B v) = v / (lambda - sigma)
+    x = ctx.solve(BV[3], 0)
+    assert ((x - V[3] / (evals[3] - sigma)).norm() / x.norm()).item() < 1e-7
+    # n_eff band of SURVEY appendix B at L = 1: 26.122 .. 26.180
+    assert abs(evals[0] - 26.122) < 2e-3 and abs(evals[-1] - 26.180) < 2e-3

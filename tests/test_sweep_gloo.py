@@ -1,0 +1,65 @@
+"""Multi-process path of the parametric sweep on CPU: world_size 2, gloo backend, fake solver
+(the sharding, the static partition and the gather are what is under test, not the eigen-solve)."""
+import os
+import socket
+
+import numpy as np
+import torch.multiprocessing as mp
+
+from pl_fem_vectoriel_amd.sweep import K_MAX, SweepItem, multiband_sweep_items, partition, run_sweep
+
+
+def fake_solve(item: SweepItem, cache: dict) -> np.ndarray:
+    cache["calls"] = cache.get("calls", 0) + 1
+    k = 3 + item.index % 5
+    return 1.26 + 1e-3 * item.index - 1e-5 * np.arange(k) + 1e-7 * item.wavelength_um
+
+
+def test_partition_covers_everything_once_and_keeps_meshes_together():
+    items = multiband_sweep_items()
+    assert len(items) == 64                                    # BASELINE.json config 4
+    for ws in (1, 2, 4, 8):
+        parts = partition(items, ws)
+        flat = sorted(i.index for p in parts for i in p)
+        assert flat == list(range(64))
+        for p in parts:
+            keys = [i.mesh_key for i in p]
+            # the 4 wavelengths of a mesh are contiguous on one rank
+            for k in set(keys):
+                idx = [q for q, kk in enumerate(keys) if kk == k]
+                assert len(idx) == 4 and idx == list(range(idx[0], idx[0] + 4))
+        if ws == 8:
+            assert all(len(p) == 8 for p in parts)             # 8 solves per GPU
+        loads = [sum(i.cost() for i in p) for p in parts]
+        assert max(loads) / (sum(loads) / ws) < 1.6          # the 19-core mesh alone is ~1.5x the mean share at 8 ranks
+
+
+def _worker(rank, world_size, port, out_dir):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world_size))
+    dist.init_process_group("gloo", rank=rank, world_size=world_size)
+    items = multiband_sweep_items()[:24]
+    table, n_local = run_sweep(items, rank, world_size, solve=fake_solve)
+    dist.barrier()
+    np.save(os.path.join(out_dir, f"r{rank}.npy"),
+            np.array([[i, len(table[i]), table[i][0]] for i in sorted(table)]))
+    np.save(os.path.join(out_dir, f"n{rank}.npy"), np.array([n_local]))
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_sweep(tmp_path):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    items = multiband_sweep_items()[:24]
+    ref, _ = run_sweep(items, 0, 1, solve=fake_solve)
+    tabs = [np.load(tmp_path / f"r{r}.npy") for r in range(2)]
+    np.testing.assert_array_equal(tabs[0], tabs[1])           # every rank holds the full table after the gather
+    assert len(tabs[0]) == 24
+    for i, cnt, first in tabs[0]:
+        assert int(cnt) == len(ref[int(i)]) and first == ref[int(i)][0]
+    n = [int(np.load(tmp_path / f"n{r}.npy")[0]) for r in range(2)]
+    assert sum(n) == 24 and min(n) >= 8
+    assert K_MAX >= 32

@@ -1,0 +1,169 @@
+"""CPU tests of the product library's host half: the C-ABI loads and exports every declared symbol,
+the symbolic analysis reproduces the oracle's (scikit-fem compatible) numbering and sparsity, and the
+nested-dissection front tree is a valid elimination structure (checked by a NumPy emulation of the
+multifrontal LDL^T against SciPy's splu)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import scipy.sparse.linalg as spla
+
+import front_emulation as fe
+from oracle import hfield
+from oracle.p2 import MeshTriLite, P2Basis
+from pl_fem_vectoriel_amd import _native
+from pl_fem_vectoriel_amd.mesh import TriMesh, generate_mesh, unit_square_mesh
+from pl_fem_vectoriel_amd.solver_fem import shift_estimate
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol(built_library):
+    header = open(os.path.join(ROOT, "include", "plfem.h")).read()
+    declared = set(re.findall(r"\b(plfem_[a-z_]+)\s*\(", header))
+    assert declared == set(_native.EXPORTS), declared ^ set(_native.EXPORTS)
+    for name in declared:
+        assert hasattr(built_library, name), name
+
+
+def test_no_device_means_loud_failure(built_library, c1_geometry):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    mesh = unit_square_mesh(3)
+    sym = _native.Symbolic(mesh.p, mesh.t)
+    with pytest.raises(RuntimeError):
+        _native.Context(sym)
+    # the C entry point itself also refuses (no silent CPU path)
+    h = ctypes.c_void_p()
+    err = ctypes.create_string_buffer(256)
+    rc = built_library.plfem_create(sym._h, 0, None, 45, ctypes.byref(h), err, 256)
+    assert rc == _native.PLFEM_EHIP and b"no HIP device" in err.value
+
+
+@pytest.mark.parametrize("which", ["square", "lantern", "shuffled"])
+def test_numbering_and_pattern_match_oracle(built_library, c1_geometry, which):
+    if which == "square":
+        mesh = unit_square_mesh(6)
+    else:
+        mesh = generate_mesh(c1_geometry, 0.4, 1 if which == "lantern" else 0)
+    p, t = mesh.p, mesh.t.copy()
+    if which == "shuffled":                    # unsorted columns / permuted elements: sort_t must normalise
+        rng = np.random.default_rng(3)
+        t = t[:, rng.permutation(t.shape[1])]
+        for e in range(t.shape[1]):
+            t[:, e] = t[rng.permutation(3), e]
+    sym = _native.Symbolic(p, t, leaf_elems=16, nthreads=2)
+    b = P2Basis(MeshTriLite(p, t))
+    assert sym.N == b.N and sym.nedges == b.nedges
+    np.testing.assert_array_equal(sym.array("edof").reshape(6, -1), b.element_dofs)
+    np.testing.assert_array_equal(sym.array("doflocs").reshape(2, -1), b.doflocs)
+    np.testing.assert_array_equal(np.nonzero(sym.array("bmask"))[0], b.get_dofs().all())
+    interior = np.setdiff1d(np.arange(b.N), b.get_dofs().all())
+    np.testing.assert_array_equal(sym.array("interior"), interior)
+    # structural CSR pattern = pattern of sum_e |P_e| (before explicit-zero elimination)
+    ed = b.element_dofs
+    rows = np.broadcast_to(ed.T[:, :, None], (ed.shape[1], 6, 6)).ravel()
+    cols = np.broadcast_to(ed.T[:, None, :], (ed.shape[1], 6, 6)).ravel()
+    P = sp.coo_matrix((np.ones(rows.size), (rows, cols)), shape=(b.N, b.N)).tocsr()
+    P.sort_indices()
+    np.testing.assert_array_equal(sym.array("rowptr"), P.indptr)
+    np.testing.assert_array_equal(sym.array("colind"), P.indices)
+    # contribution lists: every (e, a, b) exactly once, landing in slot (edof[a,e], edof[b,e]), counts = multiplicity
+    srcptr, src = sym.array("srcptr"), sym.array("src")
+    assert np.array_equal(np.sort(src), np.arange(36 * ed.shape[1]))
+    np.testing.assert_array_equal(np.diff(srcptr), P.data.astype(np.int64))
+    slot_of = np.repeat(np.arange(len(P.indices)), np.diff(srcptr))
+    e, a, bb = src // 36, (src % 36) // 6, src % 6
+    row_of_slot = np.repeat(np.arange(b.N), np.diff(P.indptr))
+    np.testing.assert_array_equal(row_of_slot[slot_of], ed[a, e])
+    np.testing.assert_array_equal(P.indices[slot_of], ed[bb, e])
+    # contributions to one slot are summed in ascending element order (deterministic assembly)
+    for k in np.random.default_rng(0).integers(0, len(P.indices), 200):
+        seg = src[srcptr[k]:srcptr[k + 1]] // 36
+        assert (np.diff(seg) >= 0).all()
+
+
+def test_front_tree_invariants(built_library, c1_geometry):
+    mesh = generate_mesh(c1_geometry, 0.5, 0)
+    sym = _native.Symbolic(mesh.p, mesh.t, leaf_elems=24)
+    T = fe.FrontTree(sym)
+    owner = sym.array("owner")
+    bmask = sym.array("bmask").astype(bool)
+    assert (owner[bmask] == -1).all() and (owner[~bmask] >= 0).all()
+    seen = np.zeros(sym.N, dtype=int)
+    for f in range(T.nf):
+        fn = T.nodes(f)
+        own = fn[:T.fs[f]]
+        own = own[own >= 0]
+        assert (owner[own] == f).all()
+        seen[own] += 1
+        bnd = fn[T.fs[f]:]
+        bnd = bnd[bnd >= 0]
+        # boundary nodes are owned by proper ancestors
+        for v in bnd[:: max(1, len(bnd) // 8)]:
+            a = owner[v]
+            g = f
+            while g > a:
+                g = (g - 1) // 2
+            assert g == a and a != f
+        assert T.fs[f] % 8 == 0 and T.fb[f] % 8 == 0
+    assert (seen[~bmask] == 1).all() and (seen[bmask] == 0).all()
+    assert T.fb[0] == 0                                            # the root has no boundary
+    # every element sits in exactly one leaf, with all its non-Dirichlet nodes present in that front
+    epos = T.epos
+    edof = sym.array("edof").reshape(6, -1)
+    leaf = sym.array("leaf_of_elem")
+    for e in np.random.default_rng(1).integers(0, sym.ne, 300):
+        fn = T.nodes(T.leaf0 + leaf[e])
+        for a in range(6):
+            if bmask[edof[a, e]]:
+                assert epos[a, e] == -1
+            else:
+                assert fn[epos[a, e]] == edof[a, e]
+
+
+@pytest.mark.parametrize("refinement,leaf", [(0.35, 12), (0.5, 24)])
+def test_multifrontal_emulation_matches_splu(built_library, c1_geometry, refinement, leaf):
+    """The front tree + unpivoted block LDL^T with inverted L11 (what the HIP kernels execute) solves
+    (A - sigma B) x = b to the accuracy of SuperLU on a mesh that contains near-degenerate triangles."""
+    g = c1_geometry
+    mesh = generate_mesh(g, refinement, 0)
+    sym = _native.Symbolic(mesh.p, mesh.t, leaf_elems=leaf)
+    om = MeshTriLite(mesh.p, mesh.t)
+    basis = P2Basis(om)
+    sigma = shift_estimate(g)
+    Ke = fe.element_K(hfield.element_matrices(g, basis), g.k0 ** 2, sigma)
+    T = fe.FrontTree(sym)
+    Fs, Ds = fe.factor(T, Ke)
+    A, B, _, _, _, _, _ = hfield.assemble_hfield_system_fused(g, om)
+    A_int, B_int, interior = hfield.restrict_interior(A, B, basis)
+    N = sym.N
+    idx = np.concatenate([interior, interior + N])
+    K = (A_int - sigma * B_int).tocsc()
+    rhs = np.zeros(2 * N)
+    rhs[idx] = np.random.default_rng(0).standard_normal(len(idx))
+    x = fe.solve(T, Fs, Ds, rhs)
+    xs = spla.splu(K).solve(rhs[idx])
+    assert np.abs(np.delete(x, idx)).max() == 0.0
+    assert np.linalg.norm(x[idx] - xs) / np.linalg.norm(xs) < 1e-8
+
+
+def test_malformed_meshes_are_rejected(built_library):
+    p = np.array([[0, 1, 0, 1], [0, 0, 1, 1.0]])
+    with pytest.raises(ValueError):
+        _native.Symbolic(p, np.array([[0], [1], [7]]))            # vertex out of range
+    with pytest.raises(ValueError):
+        _native.Symbolic(p, np.array([[0], [1], [1]]))            # repeated vertex
+    with pytest.raises(ValueError):
+        _native.Symbolic(p[:, :2], np.zeros((3, 0), dtype=np.int32))   # empty
+    with pytest.raises(ValueError):                                # non-manifold: three triangles on one edge
+        _native.Symbolic(np.array([[0, 1, 0, 1, .5], [0, 0, 1, 1, -1.0]]),
+                         np.array([[0, 0, 0], [1, 1, 1], [2, 3, 4]]))
+    with pytest.raises(ValueError):                                # single triangle: every DOF is on the boundary
+        _native.Symbolic(p[:, :3], np.array([[0], [1], [2]]))
+    with pytest.raises(ValueError):
+        TriMesh(p, np.array([[0, 1], [1, 2]]))
