@@ -13,6 +13,8 @@
 // so both solve sweeps are batched dense column-times-vector products over contiguous columns
 // (no triangular dependency chain inside a front).  A block Gauss-Jordan sweep (explicit F11^-1)
 // was tried first and is unstable on meshes with sliver elements ("numerics").
+#include <algorithm>
+
 #include "device.h"
 
 namespace plfem {
@@ -335,110 +337,273 @@ __global__ __launch_bounds__(256) void k_ldl_update(int first_front, int kb, con
 }
 
 // ------------------------------------------------------------------------------------------------
-// solve sweeps (all: one wave per DOF, dot product down a contiguous column of F)
+// solve sweeps.  Grid = (nsplit, fronts of the level); every block stages the vector it multiplies
+// with in LDS once, then its four waves walk the front's columns (one wave per column, dot product
+// down a contiguous column of F).  No block is launched without work.
 // ------------------------------------------------------------------------------------------------
-// forward, step 1: local right-hand side = global rhs at owned DOFs + children's updates
-__global__ __launch_bounds__(256) void k_fwd_gather(int first_front, int N, int leaf_level,
-                                                    const int32_t* __restrict__ fs2, const int32_t* __restrict__ fm,
-                                                    const int64_t* __restrict__ fnode_ptr,
-                                                    const int32_t* __restrict__ fnodes, const int32_t* __restrict__ cinv0,
-                                                    const int32_t* __restrict__ cinv1, const double* __restrict__ rhs,
-                                                    double* __restrict__ fvec) {
-  const int f = first_front + blockIdx.y;
-  const int m = fm[f];
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= m) return;
-  const int64_t np = fnode_ptr[f];
+__device__ __forceinline__ double wave_sum(double v) {
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+
+// local right-hand side of local DOF i: global rhs (owned DOFs) + the children's updates
+__device__ __forceinline__ double gather_rhs(int f, int i, int s2, int N, int leaf_level, int64_t np,
+                                             const int32_t* __restrict__ fs2, const int64_t* __restrict__ fnode_ptr,
+                                             const int32_t* __restrict__ fnodes, const int32_t* __restrict__ cinv0,
+                                             const int32_t* __restrict__ cinv1, const double* __restrict__ rhs,
+                                             const double* __restrict__ fvec) {
   const int q = i >> 1, c = i & 1;
   const int node = fnodes[np + q];
-  double v = (i < fs2[f] && node >= 0) ? rhs[(int64_t)c * N + node] : 0.0;
+  double v = (i < s2 && node >= 0) ? rhs[(int64_t)c * N + node] : 0.0;
   if (!leaf_level) {
     int c0 = cinv0[np + q], c1 = cinv1[np + q];
     if (c0 >= 0) { int ch = 2 * f + 1; v += fvec[2 * fnode_ptr[ch] + fs2[ch] + 2 * c0 + c]; }
     if (c1 >= 0) { int ch = 2 * f + 2; v += fvec[2 * fnode_ptr[ch] + fs2[ch] + 2 * c1 + c]; }
   }
-  fvec[2 * np + i] = v;
+  return v;
 }
 
-// forward, step 2: y = L11^-1 r_own  (column i of the upper mirror holds row i of L11^-1)
-__global__ __launch_bounds__(256) void k_fwd_own(int first_front, const int32_t* __restrict__ fs2,
-                                                 const int32_t* __restrict__ fm, const int64_t* __restrict__ foff,
-                                                 const int64_t* __restrict__ fnode_ptr, const double* __restrict__ front,
-                                                 const double* __restrict__ fvec, double* __restrict__ fvec2) {
+// 64-row tile of a dense matrix-vector product in "axpy form": lane = row (contiguous, coalesced),
+// the four waves of the block split the columns, partial sums meet in LDS in a fixed order.
+// element (r, c) = base[r + c*ld]; tri = 0: all columns in [c0, c1); tri = 1: only c <= r; tri = 2: only c >= r.
+template <int TRI>
+__device__ __forceinline__ double tile_gemv(const double* __restrict__ base, int64_t ld, int r, bool rvalid, int c0,
+                                            int c1, const double* __restrict__ v, double (*red)[64]) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  double acc = 0.0;
+  if (rvalid) {
+    int cb = c0, ce = c1;
+    if (TRI == 1) ce = min(c1, r + 1);
+    if (TRI == 2) cb = max(c0, r);
+    // this wave's columns: c == wave (mod 4); 8 independent loads in flight per lane
+    int c = cb + ((wave - cb) & 3);
+    const double* p = base + r;
+    for (; c + 28 < ce; c += 32) {
+      double a[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a[u] = p[(int64_t)(c + 4 * u) * ld];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc += a[u] * v[c + 4 * u];
+    }
+    for (; c < ce; c += 4) acc += p[(int64_t)c * ld] * v[c];
+  }
+  __syncthreads();            // previous tile's readers are done with red
+  red[wave][lane] = acc;
+  __syncthreads();
+  return red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+}
+
+// forward, step 1: y = L11^-1 r_own  (row i of L11^-1: lower triangle, contiguous down the rows)
+__global__ __launch_bounds__(256) void k_fwd_own(int first_front, int N, int leaf_level,
+                                                 const int32_t* __restrict__ fs2, const int32_t* __restrict__ fm,
+                                                 const int64_t* __restrict__ foff, const int64_t* __restrict__ fnode_ptr,
+                                                 const int32_t* __restrict__ fnodes, const int32_t* __restrict__ cinv0,
+                                                 const int32_t* __restrict__ cinv1, const double* __restrict__ front,
+                                                 const double* __restrict__ rhs, const double* __restrict__ fvec,
+                                                 double* __restrict__ fvec2) {
+  extern __shared__ double sv[];
+  __shared__ double red[4][64];
   const int f = first_front + blockIdx.y;
   const int m = fm[f], s2 = fs2[f];
-  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (i >= s2) return;
+  if (blockIdx.x * 64 >= s2) return;
+  const int64_t np = fnode_ptr[f];
+  for (int i = threadIdx.x; i < s2; i += 256)
+    sv[i] = gather_rhs(f, i, s2, N, leaf_level, np, fs2, fnode_ptr, fnodes, cinv0, cinv1, rhs, fvec);
+  __syncthreads();
   const int lane = threadIdx.x & 63;
-  const double* col = front + foff[f] + (int64_t)i * m;
-  const double* w = fvec + 2 * fnode_ptr[f];
-  double acc = 0.0;
-  for (int j = lane; j <= i; j += 64) acc += col[j] * w[j];
-  for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
-  if (lane == 0) fvec2[2 * fnode_ptr[f] + i] = acc;
+  const double* F = front + foff[f];
+  for (int r0 = blockIdx.x * 64; r0 < s2; r0 += gridDim.x * 64) {
+    const int r = r0 + lane;
+    double y = tile_gemv<1>(F, m, r, r < s2, 0, min(s2, r0 + 64), sv, red);
+    if (threadIdx.x < 64 && r < s2) fvec2[2 * np + r] = y;
+  }
 }
 
-// forward, step 3: u = w_b - L21 y   (column s2+b of F12 = row b of L21)
-__global__ __launch_bounds__(256) void k_fwd_bnd(int first_front, const int32_t* __restrict__ fs2,
-                                                 const int32_t* __restrict__ fm, const int64_t* __restrict__ foff,
-                                                 const int64_t* __restrict__ fnode_ptr, const double* __restrict__ front,
+// forward, step 2: u = w_b - L21 y   (row b of L21: block F21, contiguous down the rows)
+__global__ __launch_bounds__(256) void k_fwd_bnd(int first_front, int N, int leaf_level,
+                                                 const int32_t* __restrict__ fs2, const int32_t* __restrict__ fm,
+                                                 const int64_t* __restrict__ foff, const int64_t* __restrict__ fnode_ptr,
+                                                 const int32_t* __restrict__ fnodes, const int32_t* __restrict__ cinv0,
+                                                 const int32_t* __restrict__ cinv1, const double* __restrict__ front,
                                                  double* __restrict__ fvec, const double* __restrict__ fvec2) {
+  extern __shared__ double sv[];
+  __shared__ double red[4][64];
   const int f = first_front + blockIdx.y;
   const int m = fm[f], s2 = fs2[f];
-  const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (s2 + j >= m) return;
+  const int b2 = m - s2;
+  if (blockIdx.x * 64 >= b2) return;
+  const int64_t np = fnode_ptr[f];
+  for (int i = threadIdx.x; i < s2; i += 256) sv[i] = fvec2[2 * np + i];
+  __syncthreads();
   const int lane = threadIdx.x & 63;
-  const double* col = front + foff[f] + (int64_t)(s2 + j) * m;
-  const double* y = fvec2 + 2 * fnode_ptr[f];
-  double acc = 0.0;
-  for (int i = lane; i < s2; i += 64) acc += col[i] * y[i];
-  for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
-  if (lane == 0) fvec[2 * fnode_ptr[f] + s2 + j] -= acc;
+  const double* F = front + foff[f] + s2;
+  for (int r0 = blockIdx.x * 64; r0 < b2; r0 += gridDim.x * 64) {
+    const int r = r0 + lane;
+    double acc = tile_gemv<0>(F, m, r, r < b2, 0, s2, sv, red);
+    if (threadIdx.x < 64 && r < b2)
+      fvec[2 * np + s2 + r] =
+          gather_rhs(f, s2 + r, s2, N, leaf_level, np, fs2, fnode_ptr, fnodes, cinv0, cinv1, nullptr, fvec) - acc;
+  }
 }
 
-// backward, step 1: t = D^-1 y - L21^T x_b   (column j of F21 = column j of L21)
+// backward, step 1: t = D^-1 y - L21^T x_b   (row j of L21^T: block F12, contiguous down the rows)
 __global__ __launch_bounds__(256) void k_bwd_t(int first_front, int N, const int32_t* __restrict__ fs2,
                                                const int32_t* __restrict__ fm, const int64_t* __restrict__ foff,
                                                const int64_t* __restrict__ fnode_ptr, const int32_t* __restrict__ fnodes,
                                                const double* __restrict__ front, const double* __restrict__ delta,
                                                double* __restrict__ fvec, const double* __restrict__ fvec2,
                                                const double* __restrict__ x) {
+  extern __shared__ double sv[];
+  __shared__ double red[4][64];
   const int f = first_front + blockIdx.y;
   const int m = fm[f], s2 = fs2[f];
-  const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (j >= s2) return;
+  if (blockIdx.x * 64 >= s2) return;
+  const int b2 = m - s2;
   const int64_t np = fnode_ptr[f];
-  const int lane = threadIdx.x & 63;
-  const double* col = front + foff[f] + (int64_t)j * m;
-  double acc = 0.0;
-  for (int i = s2 + lane; i < m; i += 64) {
-    int node = fnodes[np + (i >> 1)];
-    double v = node >= 0 ? x[(int64_t)(i & 1) * N + node] : 0.0;
-    acc += col[i] * v;
+  for (int i = threadIdx.x; i < b2; i += 256) {
+    int node = fnodes[np + ((s2 + i) >> 1)];
+    sv[i] = node >= 0 ? x[(int64_t)(i & 1) * N + node] : 0.0;     // s2 is even: parity of s2+i = parity of i
   }
-  for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
-  if (lane == 0) fvec[2 * np + j] = fvec2[2 * np + j] / delta[2 * np + j] - acc;
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const double* F = front + foff[f] + (int64_t)s2 * m;             // F12: element (j, b) at F[j + b*m]
+  for (int r0 = blockIdx.x * 64; r0 < s2; r0 += gridDim.x * 64) {
+    const int r = r0 + lane;
+    double acc = tile_gemv<0>(F, m, r, r < s2, 0, b2, sv, red);
+    if (threadIdx.x < 64 && r < s2) fvec[2 * np + r] = fvec2[2 * np + r] / delta[2 * np + r] - acc;
+  }
 }
 
-// backward, step 2: x_own = L11^-T t   (column j of the lower triangle holds column j of L11^-1)
+// backward, step 2: x_own = L11^-T t   (row j of L11^-T: upper mirror, contiguous down the rows)
 __global__ __launch_bounds__(256) void k_bwd_x(int first_front, int N, const int32_t* __restrict__ fs2,
                                                const int32_t* __restrict__ fm, const int64_t* __restrict__ foff,
                                                const int64_t* __restrict__ fnode_ptr, const int32_t* __restrict__ fnodes,
                                                const double* __restrict__ front, const double* __restrict__ fvec,
                                                double* __restrict__ x) {
+  extern __shared__ double sv[];
+  __shared__ double red[4][64];
   const int f = first_front + blockIdx.y;
   const int m = fm[f], s2 = fs2[f];
+  if (blockIdx.x * 64 >= s2) return;
+  const int64_t np = fnode_ptr[f];
+  for (int i = threadIdx.x; i < s2; i += 256) sv[i] = fvec[2 * np + i];
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const double* F = front + foff[f];
+  for (int r0 = blockIdx.x * 64; r0 < s2; r0 += gridDim.x * 64) {
+    const int r = r0 + lane;
+    double acc = tile_gemv<2>(F, m, r, r < s2, r0, s2, sv, red);
+    if (threadIdx.x < 64 && r < s2) {
+      const int node = fnodes[np + (r >> 1)];
+      if (node >= 0) x[(int64_t)(r & 1) * N + node] = acc;
+    }
+  }
+}
+
+// ---- the same four products in "dot form" (one wave per output, reduction across the lanes) for the
+// top levels of the tree: few fronts, long columns -> parallelism has to come from the outputs.
+__global__ __launch_bounds__(256) void k_fwd_own_dot(int first_front, int N, int leaf_level,
+                                                     const int32_t* __restrict__ fs2, const int32_t* __restrict__ fm,
+                                                     const int64_t* __restrict__ foff, const int64_t* __restrict__ fnode_ptr,
+                                                     const int32_t* __restrict__ fnodes, const int32_t* __restrict__ cinv0,
+                                                     const int32_t* __restrict__ cinv1, const double* __restrict__ front,
+                                                     const double* __restrict__ rhs, const double* __restrict__ fvec,
+                                                     double* __restrict__ fvec2) {
+  extern __shared__ double sv[];
+  const int f = first_front + blockIdx.y;
+  const int m = fm[f], s2 = fs2[f];
+  if (blockIdx.x * 4 >= s2) return;
+  const int64_t np = fnode_ptr[f];
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  // only rows <= i of the right-hand side are needed by this block's four outputs
+  const int need = min(s2, blockIdx.x * 4 + 4);
+  for (int q = threadIdx.x; q < need; q += 256)
+    sv[q] = gather_rhs(f, q, s2, N, leaf_level, np, fs2, fnode_ptr, fnodes, cinv0, cinv1, rhs, fvec);
+  __syncthreads();
+  if (i >= s2) return;
+  const int lane = threadIdx.x & 63;
+  const double* col = front + foff[f] + (int64_t)i * m;     // upper mirror: column i = row i of L11^-1
+  double acc = 0.0;
+  for (int j = lane; j <= i; j += 64) acc += col[j] * sv[j];
+  acc = wave_sum(acc);
+  if (lane == 0) fvec2[2 * np + i] = acc;
+}
+
+__global__ __launch_bounds__(256) void k_fwd_bnd_dot(int first_front, int N, int leaf_level,
+                                                     const int32_t* __restrict__ fs2, const int32_t* __restrict__ fm,
+                                                     const int64_t* __restrict__ foff, const int64_t* __restrict__ fnode_ptr,
+                                                     const int32_t* __restrict__ fnodes, const int32_t* __restrict__ cinv0,
+                                                     const int32_t* __restrict__ cinv1, const double* __restrict__ front,
+                                                     double* __restrict__ fvec, const double* __restrict__ fvec2) {
+  extern __shared__ double sv[];
+  const int f = first_front + blockIdx.y;
+  const int m = fm[f], s2 = fs2[f];
+  const int b2 = m - s2;
+  if (blockIdx.x * 4 >= b2) return;
+  const int64_t np = fnode_ptr[f];
+  for (int q = threadIdx.x; q < s2; q += 256) sv[q] = fvec2[2 * np + q];
+  __syncthreads();
+  const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (j >= b2) return;
+  const int lane = threadIdx.x & 63;
+  const double* col = front + foff[f] + (int64_t)(s2 + j) * m;   // F12 column = row j of L21
+  double acc = 0.0;
+  for (int i = lane; i < s2; i += 64) acc += col[i] * sv[i];
+  acc = wave_sum(acc);
+  if (lane == 0)
+    fvec[2 * np + s2 + j] =
+        gather_rhs(f, s2 + j, s2, N, leaf_level, np, fs2, fnode_ptr, fnodes, cinv0, cinv1, nullptr, fvec) - acc;
+}
+
+__global__ __launch_bounds__(256) void k_bwd_t_dot(int first_front, int N, const int32_t* __restrict__ fs2,
+                                                   const int32_t* __restrict__ fm, const int64_t* __restrict__ foff,
+                                                   const int64_t* __restrict__ fnode_ptr,
+                                                   const int32_t* __restrict__ fnodes, const double* __restrict__ front,
+                                                   const double* __restrict__ delta, double* __restrict__ fvec,
+                                                   const double* __restrict__ fvec2, const double* __restrict__ x) {
+  extern __shared__ double sv[];
+  const int f = first_front + blockIdx.y;
+  const int m = fm[f], s2 = fs2[f];
+  if (blockIdx.x * 4 >= s2) return;
+  const int b2 = m - s2;
+  const int64_t np = fnode_ptr[f];
+  for (int q = threadIdx.x; q < b2; q += 256) {
+    int node = fnodes[np + ((s2 + q) >> 1)];
+    sv[q] = node >= 0 ? x[(int64_t)(q & 1) * N + node] : 0.0;
+  }
+  __syncthreads();
   const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (j >= s2) return;
+  const int lane = threadIdx.x & 63;
+  const double* col = front + foff[f] + (int64_t)j * m + s2;     // F21 column j = column j of L21
+  double acc = 0.0;
+  for (int i = lane; i < b2; i += 64) acc += col[i] * sv[i];
+  acc = wave_sum(acc);
+  if (lane == 0) fvec[2 * np + j] = fvec2[2 * np + j] / delta[2 * np + j] - acc;
+}
+
+__global__ __launch_bounds__(256) void k_bwd_x_dot(int first_front, int N, const int32_t* __restrict__ fs2,
+                                                   const int32_t* __restrict__ fm, const int64_t* __restrict__ foff,
+                                                   const int64_t* __restrict__ fnode_ptr,
+                                                   const int32_t* __restrict__ fnodes, const double* __restrict__ front,
+                                                   const double* __restrict__ fvec, double* __restrict__ x) {
+  extern __shared__ double sv[];
+  const int f = first_front + blockIdx.y;
+  const int m = fm[f], s2 = fs2[f];
+  if (blockIdx.x * 4 >= s2) return;
   const int64_t np = fnode_ptr[f];
+  const int jlo = blockIdx.x * 4;
+  for (int q = jlo + threadIdx.x; q < s2; q += 256) sv[q] = fvec[2 * np + q];
+  __syncthreads();
+  const int j = jlo + (threadIdx.x >> 6);
+  if (j >= s2) return;
   const int node_j = fnodes[np + (j >> 1)];
   if (node_j < 0) return;
   const int lane = threadIdx.x & 63;
-  const double* col = front + foff[f] + (int64_t)j * m;
-  const double* t = fvec + 2 * np;
+  const double* col = front + foff[f] + (int64_t)j * m;          // lower triangle: column j of L11^-1
   double acc = 0.0;
-  for (int i = j + lane; i < s2; i += 64) acc += col[i] * t[i];
-  for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
+  for (int i = j + lane; i < s2; i += 64) acc += col[i] * sv[i];
+  acc = wave_sum(acc);
   if (lane == 0) x[(int64_t)(j & 1) * N + node_j] = acc;
 }
 
@@ -491,26 +656,56 @@ void launch_factor(plfem_ctx* c, double sigma, int stop_level, int stop_step, in
 void launch_solve(plfem_ctx* c, const double* rhs, double* x) {
   hipStream_t st = c->stream;
   (void)hipMemsetAsync(x, 0, sizeof(double) * c->n2, st);
+  constexpr int TARGET_BLOCKS = 2048;   // ~8 blocks per CU
+  constexpr int DOT_FORM_MAX_FRONTS = 32;   // levels with at most this many fronts use the dot-form kernels
+  auto split = [&](const LevelInfo& li, int rows) {
+    int want = (TARGET_BLOCKS + li.count - 1) / li.count;
+    return std::max(1, std::min(want, (rows + 63) / 64));
+  };
   for (int lev = c->L; lev >= 0; --lev) {
     const LevelInfo& li = c->levels[lev];
-    hipLaunchKernelGGL(k_fwd_gather, dim3((li.max_m + 255) / 256, li.count), dim3(256), 0, st, li.first, c->N,
-                       lev == c->L ? 1 : 0, c->d_fs2, c->d_fm, c->d_fnode_ptr, c->d_fnodes, c->d_cinv0, c->d_cinv1,
-                       rhs, c->d_fvec);
-    if (li.max_s2 > 0)
-      hipLaunchKernelGGL(k_fwd_own, dim3((li.max_s2 + 3) / 4, li.count), dim3(256), 0, st, li.first, c->d_fs2,
-                         c->d_fm, c->d_foff, c->d_fnode_ptr, c->d_front, c->d_fvec, c->d_fvec2);
-    if (li.max_b2 > 0 && li.max_s2 > 0)
-      hipLaunchKernelGGL(k_fwd_bnd, dim3((li.max_b2 + 3) / 4, li.count), dim3(256), 0, st, li.first, c->d_fs2,
-                         c->d_fm, c->d_foff, c->d_fnode_ptr, c->d_front, c->d_fvec, c->d_fvec2);
+    const int leaf = lev == c->L ? 1 : 0;
+    const bool dot = li.count <= DOT_FORM_MAX_FRONTS;
+    if (li.max_s2 > 0) {
+      if (dot)
+        hipLaunchKernelGGL(k_fwd_own_dot, dim3((li.max_s2 + 3) / 4, li.count), dim3(256), sizeof(double) * li.max_s2,
+                           st, li.first, c->N, leaf, c->d_fs2, c->d_fm, c->d_foff, c->d_fnode_ptr, c->d_fnodes,
+                           c->d_cinv0, c->d_cinv1, c->d_front, rhs, c->d_fvec, c->d_fvec2);
+      else
+        hipLaunchKernelGGL(k_fwd_own, dim3(split(li, li.max_s2), li.count), dim3(256), sizeof(double) * li.max_s2, st,
+                           li.first, c->N, leaf, c->d_fs2, c->d_fm, c->d_foff, c->d_fnode_ptr, c->d_fnodes, c->d_cinv0,
+                           c->d_cinv1, c->d_front, rhs, c->d_fvec, c->d_fvec2);
+    }
+    if (li.max_b2 > 0) {
+      if (dot)
+        hipLaunchKernelGGL(k_fwd_bnd_dot, dim3((li.max_b2 + 3) / 4, li.count), dim3(256), sizeof(double) * li.max_s2,
+                           st, li.first, c->N, leaf, c->d_fs2, c->d_fm, c->d_foff, c->d_fnode_ptr, c->d_fnodes,
+                           c->d_cinv0, c->d_cinv1, c->d_front, c->d_fvec, c->d_fvec2);
+      else
+        hipLaunchKernelGGL(k_fwd_bnd, dim3(split(li, li.max_b2), li.count), dim3(256), sizeof(double) * li.max_s2, st,
+                           li.first, c->N, leaf, c->d_fs2, c->d_fm, c->d_foff, c->d_fnode_ptr, c->d_fnodes, c->d_cinv0,
+                           c->d_cinv1, c->d_front, c->d_fvec, c->d_fvec2);
+    }
   }
   for (int lev = 0; lev <= c->L; ++lev) {
     const LevelInfo& li = c->levels[lev];
     if (li.max_s2 <= 0) continue;
-    hipLaunchKernelGGL(k_bwd_t, dim3((li.max_s2 + 3) / 4, li.count), dim3(256), 0, st, li.first, c->N, c->d_fs2,
-                       c->d_fm, c->d_foff, c->d_fnode_ptr, c->d_fnodes, c->d_front, c->d_delta, c->d_fvec, c->d_fvec2,
-                       x);
-    hipLaunchKernelGGL(k_bwd_x, dim3((li.max_s2 + 3) / 4, li.count), dim3(256), 0, st, li.first, c->N, c->d_fs2,
-                       c->d_fm, c->d_foff, c->d_fnode_ptr, c->d_fnodes, c->d_front, c->d_fvec, x);
+    const bool dot = li.count <= DOT_FORM_MAX_FRONTS;
+    if (dot) {
+      hipLaunchKernelGGL(k_bwd_t_dot, dim3((li.max_s2 + 3) / 4, li.count), dim3(256), sizeof(double) * (li.max_b2 + 1),
+                         st, li.first, c->N, c->d_fs2, c->d_fm, c->d_foff, c->d_fnode_ptr, c->d_fnodes, c->d_front,
+                         c->d_delta, c->d_fvec, c->d_fvec2, x);
+      hipLaunchKernelGGL(k_bwd_x_dot, dim3((li.max_s2 + 3) / 4, li.count), dim3(256), sizeof(double) * li.max_s2, st,
+                         li.first, c->N, c->d_fs2, c->d_fm, c->d_foff, c->d_fnode_ptr, c->d_fnodes, c->d_front,
+                         c->d_fvec, x);
+    } else {
+      hipLaunchKernelGGL(k_bwd_t, dim3(split(li, li.max_s2), li.count), dim3(256), sizeof(double) * (li.max_b2 + 1),
+                         st, li.first, c->N, c->d_fs2, c->d_fm, c->d_foff, c->d_fnode_ptr, c->d_fnodes, c->d_front,
+                         c->d_delta, c->d_fvec, c->d_fvec2, x);
+      hipLaunchKernelGGL(k_bwd_x, dim3(split(li, li.max_s2), li.count), dim3(256), sizeof(double) * li.max_s2, st,
+                         li.first, c->N, c->d_fs2, c->d_fm, c->d_foff, c->d_fnode_ptr, c->d_fnodes, c->d_front,
+                         c->d_fvec, x);
+    }
   }
 }
 

@@ -28,13 +28,15 @@ __global__ __launch_bounds__(256) void k_panel_dot(int64_t n, int ncols, int nch
   if (lane == 0) partial[(int64_t)c * nchunks + blockIdx.x] = acc;
 }
 
-__global__ __launch_bounds__(256) void k_panel_dot_finish(int ncols, int nchunks, const double* __restrict__ partial,
-                                                          double* __restrict__ h) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
+// h[c] = sum over chunks of partial[c][*]: one wave per column, fixed (lane-strided, then butterfly) order
+__global__ __launch_bounds__(64) void k_panel_dot_finish(int ncols, int nchunks, const double* __restrict__ partial,
+                                                         double* __restrict__ h) {
+  const int c = blockIdx.x;
   if (c >= ncols) return;
   double acc = 0.0;
-  for (int q = 0; q < nchunks; ++q) acc += partial[(int64_t)c * nchunks + q];
-  h[c] = acc;
+  for (int q = threadIdx.x; q < nchunks; q += 64) acc += partial[(int64_t)c * nchunks + q];
+  for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
+  if (threadIdx.x == 0) h[c] = acc;
 }
 
 // w[i] -= sum_c P[i, c] h[c]
@@ -212,8 +214,7 @@ void launch_panel_dot(plfem_ctx* c, const double* P, int ncols, const double* w,
   const int nchunks = c->npartial;
   hipLaunchKernelGGL(k_panel_dot, dim3(nchunks, (ncols + 3) / 4), dim3(256), 0, c->stream, c->n2, ncols, nchunks, P,
                      w, c->d_partial);
-  hipLaunchKernelGGL(k_panel_dot_finish, dim3((ncols + 255) / 256), dim3(256), 0, c->stream, ncols, nchunks,
-                     c->d_partial, h);
+  hipLaunchKernelGGL(k_panel_dot_finish, dim3(ncols), dim3(64), 0, c->stream, ncols, nchunks, c->d_partial, h);
 }
 
 void launch_panel_axpy(plfem_ctx* c, const double* P, int ncols, const double* h, double* w) {
