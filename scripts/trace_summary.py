@@ -10,7 +10,7 @@ def nm(s):
 names = [nm(r['Kernel_Name']) for r in rows]
 dur = [int(r['End_Timestamp']) - int(r['Start_Timestamp']) for r in rows]
 grid = [(int(r['Grid_Size_X']) // int(r['Workgroup_Size_X']), int(r['Grid_Size_Y']), int(r['Grid_Size_Z'])) for r in rows]
-S = ('k_fwd_gather', 'k_fwd_own', 'k_fwd_bnd', 'k_bwd_t', 'k_bwd_x', 'k_fwd_front', 'k_bwd_front')
+S = ('k_fwd_gather', 'k_fwd_own', 'k_fwd_bnd', 'k_bwd_t', 'k_bwd_x', 'k_fwd_own_dot', 'k_fwd_bnd_dot', 'k_bwd_t_dot', 'k_bwd_x_dot')
 starts = [i for i in range(1, len(names)) if names[i] in S and names[i - 1] not in S]
 if starts:
     s = starts[len(starts) // 2]
