@@ -142,6 +142,9 @@ __global__ __launch_bounds__(256) void k_ldl_diag(int first_front, int kb, const
   amax = fmax(fmax(s_red[0], s_red[1]), fmax(s_red[2], s_red[3]));
   const double thr = fmax(1e-13 * amax, 1e-300);
   const int i = tid >> 3, cg = tid & 7;   // trailing update: row i, columns cg*4 .. cg*4+3
+  for (int k = tid; k < NB * NB; k += 256) x[k % NB][k / NB] = (k % NB == k / NB) ? 1.0 : 0.0;
+  // The row operations of the elimination are applied to the identity at the same time, so that
+  // x = L^-1 when the loop ends (row k of x is final when step k starts).
   for (int k = 0; k < NB; ++k) {
     double dk = a[k][k];
     if (!(fabs(dk) >= thr)) {
@@ -159,22 +162,11 @@ __global__ __launch_bounds__(256) void k_ldl_diag(int first_front, int kb, const
       for (int cc = 0; cc < 4; ++cc) {
         int c = cg * 4 + cc;
         if (c > k) a[i][c] -= li * dk * lk[c];
+        else x[i][c] -= li * x[k][c];
       }
     }
     __syncthreads();
-    if (tid < NB && tid > k) a[tid][k] = lk[tid];
-    __syncthreads();
   }
-  // X = L^-1 (unit lower): column j by forward substitution
-  if (tid < NB) {
-    const int j = tid;
-    for (int r = 0; r < NB; ++r) {
-      double v = (r == j) ? 1.0 : 0.0;
-      for (int k = j; k < r; ++k) v -= a[r][k] * x[k][j];
-      x[r][j] = (r >= j) ? v : 0.0;
-    }
-  }
-  __syncthreads();
   double* D = dinv + (int64_t)f * NB * NB;
   for (int k = tid; k < NB * NB; k += 256) {
     int r = k % NB, c = k / NB;
@@ -186,7 +178,10 @@ __global__ __launch_bounds__(256) void k_ldl_diag(int first_front, int kb, const
 
 // Triangular-inverse update: with X<k the inverse of the leading k0 x k0 block of L11,
 //   X[k, <k] = -X[k,k] * ( L[k, <k] * X<k ).
-// One lane per column c (coalesced reads of the mirrored X<k^T), NB accumulators per lane.
+// One wave per 16 columns c, both products on v_mfma_f64_16x16x4_f64:
+//   T (32 x 16) = L[k, j>=c0] (A: tbuf, contiguous in q) * X<k[j, c] (B: upper mirror, contiguous in c);
+//   the accumulator register r of lane (lr, lk) holds T[lk + 4 r][lr], which is exactly the B operand
+//   of k-step r of the second product  Xnew = -X[k,k] * T  -- no cross-lane movement.
 __global__ __launch_bounds__(256) void k_ldl_invrow(int first_front, int kb, const int32_t* __restrict__ fs2,
                                                     const int32_t* __restrict__ fm, const int64_t* __restrict__ foff,
                                                     const int64_t* __restrict__ fnode_ptr, double* __restrict__ front,
@@ -195,41 +190,47 @@ __global__ __launch_bounds__(256) void k_ldl_invrow(int first_front, int kb, con
   const int s2 = fs2[f];
   const int k0 = kb * NB;
   if (k0 >= s2 || k0 == 0) return;
-  const int c0 = blockIdx.x * 256;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int c0 = (blockIdx.x * 4 + wave) * 16;
   if (c0 >= k0) return;
   const int nbk = min(NB, s2 - k0);
   const int m = fm[f];
   double* F = front + foff[f];
-  const double* T = tbuf + 2 * fnode_ptr[f] * NB;
-  const double* D = dinv + (int64_t)f * NB * NB;
-  __shared__ double sL[NB][NB];       // [j in tile][q]
-  __shared__ double sX[NB][NB + 1];   // X[k,k]
-  const int tid = threadIdx.x;
-  for (int k = tid; k < NB * NB; k += 256) sX[k % NB][k / NB] = D[k];
-  const int c = c0 + tid;
-  const bool cv = c < k0;
-  double acc[NB];
-#pragma unroll
-  for (int q = 0; q < NB; ++q) acc[q] = 0.0;
-  for (int j0 = (c0 / NB) * NB; j0 < k0; j0 += NB) {
-    __syncthreads();
-    for (int k = tid; k < NB * NB; k += 256) sL[k / NB][k % NB] = T[(int64_t)j0 * NB + k];   // [j][q]
-    __syncthreads();
-    for (int jj = 0; jj < NB; ++jj) {
-      const int j = j0 + jj;
-      double xv = (cv && j >= c) ? F[(int64_t)j * m + c] : 0.0;   // X<k[j, c] from the upper mirror
-#pragma unroll
-      for (int q = 0; q < NB; ++q) acc[q] += sL[jj][q] * xv;
-    }
+  const double* T = tbuf + 2 * fnode_ptr[f] * NB;      // T[q + j*NB] = L[k0+q, j]
+  const double* D = dinv + (int64_t)f * NB * NB;       // D[r + q*NB] = X[k,k][r][q]
+  const int lr = lane & 15, lk = lane >> 4;
+  const int c = c0 + lr;
+  v4d t0 = (v4d){0.0, 0.0, 0.0, 0.0}, t1 = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+  for (int j0 = c0; j0 < k0; j0 += 4) {
+    const int j = j0 + lk;
+    const double a0 = T[(int64_t)j * NB + lr];
+    const double a1 = T[(int64_t)j * NB + 16 + lr];
+    const double b = (j >= c) ? F[(int64_t)j * m + c] : 0.0;    // X<k[j, c] (unit diagonal stored)
+    t0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b, t0, 0, 0, 0);
+    t1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b, t1, 0, 0, 0);
   }
-  if (!cv) return;
-  for (int r = 0; r < nbk; ++r) {
-    double v = 0.0;
+  v4d x0 = (v4d){0.0, 0.0, 0.0, 0.0}, x1 = (v4d){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int q = 0; q < NB; ++q) v += sX[r][q] * acc[q];
-    v = -v;
-    F[(int64_t)c * m + (k0 + r)] = v;
-    F[(int64_t)(k0 + r) * m + c] = v;
+  for (int kk = 0; kk < 8; ++kk) {
+    const int q = 4 * kk + lk;
+    const double a0 = -D[(int64_t)q * NB + lr];          // -X[k,k][lr][q]
+    const double a1 = -D[(int64_t)q * NB + 16 + lr];
+    const double b = kk < 4 ? t0[kk & 3] : t1[kk & 3];   // T[q][c]
+    x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b, x0, 0, 0, 0);
+    x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b, x1, 0, 0, 0);
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int r0 = lk + 4 * r, r1 = 16 + lk + 4 * r;
+    if (r0 < nbk) {
+      F[(int64_t)c * m + (k0 + r0)] = x0[r];
+      F[(int64_t)(k0 + r0) * m + c] = x0[r];
+    }
+    if (r1 < nbk) {
+      F[(int64_t)c * m + (k0 + r1)] = x1[r];
+      F[(int64_t)(k0 + r1) * m + c] = x1[r];
+    }
   }
 }
 
@@ -635,7 +636,7 @@ void launch_factor(plfem_ctx* c, double sigma, int stop_level, int stop_step, in
                          c->d_fnode_ptr, c->d_front, c->d_dinv, c->d_delta, c->d_tbuf, c->d_counters);
       if (stop_here && stop_stage == 1) return;
       if (kb > 0)
-        hipLaunchKernelGGL(k_ldl_invrow, dim3((k0 + 255) / 256, li.count), dim3(256), 0, st, li.first, kb, c->d_fs2,
+        hipLaunchKernelGGL(k_ldl_invrow, dim3((k0 + 63) / 64, li.count), dim3(256), 0, st, li.first, kb, c->d_fs2,
                            c->d_fm, c->d_foff, c->d_fnode_ptr, c->d_front, c->d_dinv, c->d_tbuf);
       if (stop_here && stop_stage == 2) return;
       if (max_trail > 0) {
