@@ -66,7 +66,8 @@ int plfem_symbolic_info(const plfem_symbolic* sym, int64_t* info /* [PLFEM_INFO_
 
 /* Copy a named host array out of the analysis (for the Python compatibility surface and tests).
  * names: "edof"[6][ne] i32, "doflocs"[2][N] f64, "bmask"[N] u8, "interior"[nsolve] i32,
- * "rowptr"[N+1] i32, "colind"[nnz] i32, "srcptr"[nnz+1] i32, "src"[36 ne] i32, "edges"[2][nedges] i32,
+ * "rowptr"[N+1] i32, "colind"[nnz] i32, "slot_row"[nnz] i32, "nptr"[N+1] / "nadj"[6 ne] i32 / "nloc"[6 ne] u8
+ * (node -> adjacent elements), "edges"[2][nedges] i32,
  * "leaf_of_elem"[ne] i32, "owner"[N] i32, "fs","fb"[nfronts] i32, "fnode_ptr","foff"[nfronts+1] i64,
  * "fnodes","cinv0","cinv1"[fnode_ptr[nfronts]] i32, "epos"[6][ne] i32.
  * plfem_symbolic_array_bytes returns the size in bytes or a negative error. */

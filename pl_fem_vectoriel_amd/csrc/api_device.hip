@@ -96,7 +96,7 @@ void jacobi_eigh(int n, std::vector<double>& A, std::vector<double>& V, std::vec
 
 void free_all(plfem_ctx* c) {
   auto F = [](void* p) { if (p) (void)hipFree(p); };
-  F(c->d_tsorted); F(c->d_edof); F(c->d_rowptr); F(c->d_colind); F(c->d_srcptr); F(c->d_src); F(c->d_interior);
+  F(c->d_tsorted); F(c->d_edof); F(c->d_rowptr); F(c->d_colind); F(c->d_slot_row); F(c->d_nptr); F(c->d_nadj); F(c->d_nloc); F(c->d_interior);
   F(c->d_bmask); F(c->d_doflocs); F(c->d_fs2); F(c->d_fm); F(c->d_fnode_ptr); F(c->d_foff); F(c->d_fnodes);
   F(c->d_cinv0); F(c->d_cinv1); F(c->d_epos); F(c->d_leaf_elem_ptr); F(c->d_leaf_elems); F(c->d_cores);
   F(c->d_elem);
@@ -141,8 +141,10 @@ int create_impl(plfem_ctx* c, const plfem_symbolic* sym, int device, void* strea
   TRY(upload(c, &c->d_edof, S.edof));
   TRY(upload(c, &c->d_rowptr, S.rowptr));
   TRY(upload(c, &c->d_colind, S.colind));
-  TRY(upload(c, &c->d_srcptr, S.srcptr));
-  TRY(upload(c, &c->d_src, S.src));
+  TRY(upload(c, &c->d_slot_row, S.slot_row));
+  TRY(upload(c, &c->d_nptr, S.nptr));
+  TRY(upload(c, &c->d_nadj, S.nadj));
+  TRY(upload(c, &c->d_nloc, S.nloc));
   TRY(upload(c, &c->d_interior, S.interior));
   TRY(upload(c, &c->d_bmask, S.bmask));
   TRY(upload(c, &c->d_doflocs, S.doflocs));

@@ -82,8 +82,10 @@ bool lookup(const Symbolic& S, const char* name, ArrayRef& r) {
   else if (n == "int_index") r = ref(S.int_index);
   else if (n == "rowptr") r = ref(S.rowptr);
   else if (n == "colind") r = ref(S.colind);
-  else if (n == "srcptr") r = ref(S.srcptr);
-  else if (n == "src") r = ref(S.src);
+  else if (n == "slot_row") r = ref(S.slot_row);
+  else if (n == "nptr") r = ref(S.nptr);
+  else if (n == "nadj") r = ref(S.nadj);
+  else if (n == "nloc") r = ref(S.nloc);
   else if (n == "leaf_of_elem") r = ref(S.leaf_of_elem);
   else if (n == "leaf_elem_ptr") r = ref(S.leaf_elem_ptr);
   else if (n == "leaf_elems") r = ref(S.leaf_elems);

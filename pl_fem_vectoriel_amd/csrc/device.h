@@ -37,7 +37,8 @@ struct plfem_ctx {
   std::vector<plfem::LevelInfo> levels;
   // ---- index structures on the device
   int32_t *d_tsorted = nullptr, *d_edof = nullptr, *d_rowptr = nullptr, *d_colind = nullptr;
-  int32_t *d_srcptr = nullptr, *d_src = nullptr, *d_interior = nullptr;
+  int32_t *d_slot_row = nullptr, *d_nptr = nullptr, *d_nadj = nullptr, *d_interior = nullptr;
+  uint8_t* d_nloc = nullptr;
   uint8_t* d_bmask = nullptr;
   double* d_doflocs = nullptr;
   int32_t *d_fs2 = nullptr, *d_fm = nullptr;          // per front: owned DOFs (2 fs), front order m = 2 (fs + fb)

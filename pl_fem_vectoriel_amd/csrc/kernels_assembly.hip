@@ -121,22 +121,30 @@ __global__ __launch_bounds__(256) void k_element_matrices(
 }
 
 // Ordered gather of the element-matrix entries into the shared scalar CSR pattern: one lane per CSR
-// slot sums its contribution list in a fixed (element-ascending) order — deterministic, no float
-// atomics.  Replaces coo_matrix(...).tocsr() duplicate summation.
-__global__ __launch_bounds__(256) void k_csr_gather(int nnz, const int32_t* __restrict__ srcptr,
-                                                    const int32_t* __restrict__ src, const double* __restrict__ elem,
+// slot (i, j) walks the elements adjacent to node i in ascending order and adds the entry of every
+// element that also contains node j -- deterministic, no float atomics, every value written once.
+// Replaces coo_matrix(...).tocsr() duplicate summation.
+__global__ __launch_bounds__(256) void k_csr_gather(int nnz, int ne, const int32_t* __restrict__ slot_row,
+                                                    const int32_t* __restrict__ colind, const int32_t* __restrict__ nptr,
+                                                    const int32_t* __restrict__ nadj, const uint8_t* __restrict__ nloc,
+                                                    const int32_t* __restrict__ edof, const double* __restrict__ elem,
                                                     double* __restrict__ v0, double* __restrict__ v1,
                                                     double* __restrict__ v2, double* __restrict__ v3,
                                                     double* __restrict__ v4, double* __restrict__ v5,
                                                     double* __restrict__ v6, double* __restrict__ v7) {
   int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= nnz) return;
+  const int i = slot_row[k], col = colind[k];
   double acc[ELEM_FORMS] = {0, 0, 0, 0, 0, 0, 0, 0};
-  int q0 = srcptr[k], q1 = srcptr[k + 1];
-  for (int q = q0; q < q1; ++q) {
-    int s = src[q];
-    int e = s / 36, ab = s - e * 36;
-    const double* p = elem + (size_t)e * ELEM_STRIDE + ab;
+  const int q1 = nptr[i + 1];
+  for (int q = nptr[i]; q < q1; ++q) {
+    const int e = nadj[q];
+    int b = -1;
+#pragma unroll
+    for (int bb = 0; bb < 6; ++bb)
+      if (edof[(size_t)bb * ne + e] == col) b = bb;
+    if (b < 0) continue;
+    const double* p = elem + (size_t)e * ELEM_STRIDE + (int)nloc[q] * 6 + b;
 #pragma unroll
     for (int f = 0; f < ELEM_FORMS; ++f) acc[f] += p[f * 36];
   }
@@ -192,7 +200,8 @@ void launch_element_matrices(plfem_ctx* c, int ncore, double eps_core, double ep
 
 void launch_csr_gather(plfem_ctx* c) {
   int grid = (c->nnz + 255) / 256;
-  hipLaunchKernelGGL(k_csr_gather, dim3(grid), dim3(256), 0, c->stream, c->nnz, c->d_srcptr, c->d_src, c->d_elem,
+  hipLaunchKernelGGL(k_csr_gather, dim3(grid), dim3(256), 0, c->stream, c->nnz, c->ne, c->d_slot_row, c->d_colind,
+                     c->d_nptr, c->d_nadj, c->d_nloc, c->d_edof, c->d_elem,
                      c->d_vals[0], c->d_vals[1], c->d_vals[2], c->d_vals[3], c->d_vals[4], c->d_vals[5],
                      c->d_vals[6], c->d_vals[7]);
 }

@@ -657,7 +657,7 @@ void launch_factor(plfem_ctx* c, double sigma, int stop_level, int stop_step, in
 void launch_solve(plfem_ctx* c, const double* rhs, double* x) {
   hipStream_t st = c->stream;
   (void)hipMemsetAsync(x, 0, sizeof(double) * c->n2, st);
-  constexpr int TARGET_BLOCKS = 2048;   // ~8 blocks per CU
+  constexpr int TARGET_BLOCKS = 16384;  // one 64-row tile per block unless that would exceed ~64 blocks per CU
   constexpr int DOT_FORM_MAX_FRONTS = 32;   // levels with at most this many fronts use the dot-form kernels
   auto split = [&](const LevelInfo& li, int rows) {
     int want = (TARGET_BLOCKS + li.count - 1) / li.count;

@@ -19,8 +19,8 @@ inline double secs(clk::time_point a, clk::time_point b) {
 
 // run f(begin, end, tid) over [0, n) on nthreads threads (static chunks)
 template <class F>
-void parallel_for(int64_t n, int nthreads, F f) {
-  if (nthreads <= 1 || n < 4096) {
+void parallel_for(int64_t n, int nthreads, F f, int64_t min_parallel = 4096) {
+  if (nthreads <= 1 || n < min_parallel) {
     f((int64_t)0, n, 0);
     return;
   }
@@ -133,8 +133,11 @@ std::string p2_numbering(int nv, int ne, const double* p, const int32_t* t, Symb
 }
 
 // node -> adjacent elements (CSR), elements ascending within each node
-void node_to_elem(const Symbolic& S, std::vector<int32_t>& ptr, std::vector<int32_t>& adj, std::vector<uint8_t>& loc) {
+void node_to_elem(Symbolic& S) {
   const int N = S.N, ne = S.ne;
+  std::vector<int32_t>& ptr = S.nptr;
+  std::vector<int32_t>& adj = S.nadj;
+  std::vector<uint8_t>& loc = S.nloc;
   ptr.assign((size_t)N + 1, 0);
   for (int a = 0; a < 6; ++a)
     for (int e = 0; e < ne; ++e) ptr[S.edof[(size_t)a * ne + e] + 1]++;
@@ -152,17 +155,17 @@ void node_to_elem(const Symbolic& S, std::vector<int32_t>& ptr, std::vector<int3
 }
 
 // ------------------------------------------------------------------------------------------------
-// scalar CSR pattern + contribution lists
+// scalar CSR pattern: row i = sorted union of the DOFs of the elements adjacent to node i
 // ------------------------------------------------------------------------------------------------
-void csr_pattern(Symbolic& S, const std::vector<int32_t>& nptr, const std::vector<int32_t>& nadj,
-                 const std::vector<uint8_t>& nloc, int nthreads) {
+void csr_pattern(Symbolic& S, int nthreads) {
   const int N = S.N, ne = S.ne;
-  // phase A: unique columns of every row into a scratch area of 6*deg per row
+  const std::vector<int32_t>& nptr = S.nptr;
+  const std::vector<int32_t>& nadj = S.nadj;
   std::vector<int64_t> soff((size_t)N + 1);
   soff[0] = 0;
   for (int i = 0; i < N; ++i) soff[i + 1] = soff[i] + 6 * (int64_t)(nptr[i + 1] - nptr[i]);
   std::vector<int32_t> scratch((size_t)soff[N]);
-  std::vector<int32_t> rowlen(N);
+  S.rowptr.assign((size_t)N + 1, 0);
   parallel_for(N, nthreads, [&](int64_t b, int64_t e_, int) {
     for (int64_t i = b; i < e_; ++i) {
       int32_t* s = scratch.data() + soff[i];
@@ -172,50 +175,19 @@ void csr_pattern(Symbolic& S, const std::vector<int32_t>& nptr, const std::vecto
         for (int a = 0; a < 6; ++a) s[n++] = S.edof[(size_t)a * ne + e];
       }
       std::sort(s, s + n);
-      rowlen[i] = (int32_t)(std::unique(s, s + n) - s);
+      S.rowptr[i + 1] = (int32_t)(std::unique(s, s + n) - s);
     }
   });
-  S.rowptr.resize((size_t)N + 1);
-  S.rowptr[0] = 0;
-  for (int i = 0; i < N; ++i) S.rowptr[i + 1] = S.rowptr[i] + rowlen[i];
+  for (int i = 0; i < N; ++i) S.rowptr[i + 1] += S.rowptr[i];
   const int64_t nnz = S.rowptr[N];
   S.colind.resize(nnz);
-  S.srcptr.assign((size_t)nnz + 1, 0);
-  // phase B: colind + per-slot contribution counts
+  S.slot_row.resize(nnz);
   parallel_for(N, nthreads, [&](int64_t b, int64_t e_, int) {
     for (int64_t i = b; i < e_; ++i) {
       const int32_t* s = scratch.data() + soff[i];
-      int32_t* c = S.colind.data() + S.rowptr[i];
-      std::copy(s, s + rowlen[i], c);
-      for (int32_t q = nptr[i]; q < nptr[i + 1]; ++q) {
-        int32_t e = nadj[q];
-        for (int bb = 0; bb < 6; ++bb) {
-          int32_t col = S.edof[(size_t)bb * ne + e];
-          int32_t pos = (int32_t)(std::lower_bound(c, c + rowlen[i], col) - c);
-          S.srcptr[(size_t)S.rowptr[i] + pos + 1]++;
-        }
-      }
-    }
-  });
-  for (int64_t k = 0; k < nnz; ++k) S.srcptr[k + 1] += S.srcptr[k];
-  S.src.resize((size_t)36 * ne);
-  // phase C: fill (elements ascending within a row => deterministic summation order)
-  parallel_for(N, nthreads, [&](int64_t b, int64_t e_, int) {
-    std::vector<int32_t> fill;
-    for (int64_t i = b; i < e_; ++i) {
-      const int32_t* c = S.colind.data() + S.rowptr[i];
-      int len = rowlen[i];
-      fill.assign(len, 0);
-      for (int32_t q = nptr[i]; q < nptr[i + 1]; ++q) {
-        int32_t e = nadj[q];
-        int a = nloc[q];
-        for (int bb = 0; bb < 6; ++bb) {
-          int32_t col = S.edof[(size_t)bb * ne + e];
-          int32_t pos = (int32_t)(std::lower_bound(c, c + len, col) - c);
-          int64_t slot = (int64_t)S.rowptr[i] + pos;
-          S.src[(size_t)S.srcptr[slot] + fill[pos]++] = e * 36 + a * 6 + bb;
-        }
-      }
+      const int32_t r0 = S.rowptr[i], len = S.rowptr[i + 1] - r0;
+      std::copy(s, s + len, S.colind.data() + r0);
+      std::fill(S.slot_row.data() + r0, S.slot_row.data() + r0 + len, (int32_t)i);
     }
   });
 }
@@ -346,60 +318,78 @@ inline int bitlen(uint32_t x) {
   return n;
 }
 
-std::string build_fronts(Symbolic& S, const std::vector<int32_t>& nptr, const std::vector<int32_t>& nadj) {
+std::string build_fronts(Symbolic& S, int nthreads) {
+  const std::vector<int32_t>& nptr = S.nptr;
+  const std::vector<int32_t>& nadj = S.nadj;
   const int N = S.N, ne = S.ne, L = S.L, nf = S.nfronts;
   // owner front of every non-Dirichlet node = deepest tree node containing all its elements
   S.owner.assign(N, -1);
-  for (int i = 0; i < N; ++i) {
-    if (S.bmask[i]) continue;
-    uint32_t lo = 0xffffffffu, hi = 0;
-    for (int32_t q = nptr[i]; q < nptr[i + 1]; ++q) {
-      uint32_t lf = (uint32_t)S.leaf_of_elem[nadj[q]];
-      lo = std::min(lo, lf);
-      hi = std::max(hi, lf);
+  bool orphan = false;
+  parallel_for(N, nthreads, [&](int64_t b, int64_t e_, int) {
+    for (int64_t i = b; i < e_; ++i) {
+      if (nptr[i] == nptr[i + 1]) { orphan = true; continue; }
+      if (S.bmask[i]) continue;
+      uint32_t lo = 0xffffffffu, hi = 0;
+      for (int32_t q = nptr[i]; q < nptr[i + 1]; ++q) {
+        uint32_t lf = (uint32_t)S.leaf_of_elem[nadj[q]];
+        lo = std::min(lo, lf);
+        hi = std::max(hi, lf);
+      }
+      int level = L - bitlen(lo ^ hi);
+      S.owner[i] = (1 << level) - 1 + (int)(lo >> (L - level));
     }
-    if (nptr[i] == nptr[i + 1]) return "mesh has a vertex that belongs to no element";
-    int level = L - bitlen(lo ^ hi);
-    S.owner[i] = (1 << level) - 1 + (int)(lo >> (L - level));
-  }
-  // per-front node lists, bottom-up.  lists[f] = own (ascending ids) ++ boundary (ascending ids)
+  }, 8192);
+  if (orphan) return "mesh has a vertex that belongs to no element";
+  // per-front node lists, bottom-up, level by level (fronts of one level are independent).
+  // lists[f] = own (ascending ids) ++ boundary (ascending ids)
   std::vector<std::vector<int32_t>> own(nf), bnd(nf);
   std::vector<std::vector<int32_t>> inv0(nf), inv1(nf);   // parent local (unpadded own++bnd) -> child bnd index
   const int leaf0 = (1 << L) - 1;
-  std::vector<int32_t> tmp;
-  for (int lf = 0; lf < (1 << L); ++lf) {
-    int f = leaf0 + lf;
-    tmp.clear();
-    for (int32_t q = S.leaf_elem_ptr[lf]; q < S.leaf_elem_ptr[lf + 1]; ++q) {
-      int32_t e = S.leaf_elems[q];
-      for (int a = 0; a < 6; ++a) {
-        int32_t i = S.edof[(size_t)a * ne + e];
-        if (!S.bmask[i]) tmp.push_back(i);
+  parallel_for((int64_t)1 << L, nthreads, [&](int64_t b, int64_t e_, int) {
+    std::vector<int32_t> tmp;
+    for (int64_t lf = b; lf < e_; ++lf) {
+      int f = leaf0 + (int)lf;
+      tmp.clear();
+      for (int32_t q = S.leaf_elem_ptr[lf]; q < S.leaf_elem_ptr[lf + 1]; ++q) {
+        int32_t e = S.leaf_elems[q];
+        for (int a = 0; a < 6; ++a) {
+          int32_t i = S.edof[(size_t)a * ne + e];
+          if (!S.bmask[i]) tmp.push_back(i);
+        }
       }
+      std::sort(tmp.begin(), tmp.end());
+      tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
+      own[f].reserve(tmp.size());
+      bnd[f].reserve(tmp.size());
+      for (int32_t i : tmp) (S.owner[i] == f ? own[f] : bnd[f]).push_back(i);
     }
-    std::sort(tmp.begin(), tmp.end());
-    tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
-    for (int32_t i : tmp) (S.owner[i] == f ? own[f] : bnd[f]).push_back(i);
-  }
-  for (int f = leaf0 - 1; f >= 0; --f) {
-    const auto& b0 = bnd[2 * f + 1];
-    const auto& b1 = bnd[2 * f + 2];
-    // merge the two ascending boundary lists
-    size_t i0 = 0, i1 = 0;
-    std::vector<int32_t> o_i0, o_i1, b_i0, b_i1;
-    while (i0 < b0.size() || i1 < b1.size()) {
-      int32_t v;
-      int32_t p0 = -1, p1 = -1;
-      if (i1 >= b1.size() || (i0 < b0.size() && b0[i0] < b1[i1])) { v = b0[i0]; p0 = (int32_t)i0++; }
-      else if (i0 >= b0.size() || b1[i1] < b0[i0]) { v = b1[i1]; p1 = (int32_t)i1++; }
-      else { v = b0[i0]; p0 = (int32_t)i0++; p1 = (int32_t)i1++; }
-      if (S.owner[v] == f) { own[f].push_back(v); o_i0.push_back(p0); o_i1.push_back(p1); }
-      else { bnd[f].push_back(v); b_i0.push_back(p0); b_i1.push_back(p1); }
-    }
-    inv0[f] = std::move(o_i0);
-    inv0[f].insert(inv0[f].end(), b_i0.begin(), b_i0.end());
-    inv1[f] = std::move(o_i1);
-    inv1[f].insert(inv1[f].end(), b_i1.begin(), b_i1.end());
+  }, 64);
+  for (int lev = L - 1; lev >= 0; --lev) {
+    const int first = (1 << lev) - 1;
+    parallel_for((int64_t)1 << lev, nthreads, [&](int64_t b, int64_t e_, int) {
+      for (int64_t q = b; q < e_; ++q) {
+        const int f = first + (int)q;
+        const auto& b0 = bnd[2 * f + 1];
+        const auto& b1 = bnd[2 * f + 2];
+        const size_t cap = b0.size() + b1.size();
+        std::vector<int32_t> bn, o0, o1, c0, c1;
+        bn.reserve(cap); c0.reserve(cap); c1.reserve(cap);
+        size_t i0 = 0, i1 = 0;
+        while (i0 < b0.size() || i1 < b1.size()) {     // merge the two ascending boundary lists
+          int32_t v, p0 = -1, p1 = -1;
+          if (i1 >= b1.size() || (i0 < b0.size() && b0[i0] < b1[i1])) { v = b0[i0]; p0 = (int32_t)i0++; }
+          else if (i0 >= b0.size() || b1[i1] < b0[i0]) { v = b1[i1]; p1 = (int32_t)i1++; }
+          else { v = b0[i0]; p0 = (int32_t)i0++; p1 = (int32_t)i1++; }
+          if (S.owner[v] == f) { own[f].push_back(v); o0.push_back(p0); o1.push_back(p1); }
+          else { bn.push_back(v); c0.push_back(p0); c1.push_back(p1); }
+        }
+        bnd[f] = std::move(bn);
+        o0.insert(o0.end(), c0.begin(), c0.end());
+        o1.insert(o1.end(), c1.begin(), c1.end());
+        inv0[f] = std::move(o0);
+        inv1[f] = std::move(o1);
+      }
+    }, 2);
   }
   if (!bnd[0].empty()) return "internal error: root front has boundary nodes";
   {
@@ -421,7 +411,7 @@ std::string build_fronts(Symbolic& S, const std::vector<int32_t>& nptr, const st
     S.fnode_ptr[f + 1] = S.fnode_ptr[f] + mn;
     int64_t m = 2 * mn, s2 = 2 * (int64_t)S.fs[f];
     S.foff[f + 1] = S.foff[f] + m * m;
-    S.factor_flops += 2.0 * (double)s2 * (double)m * (double)m;
+    S.factor_flops += (double)s2 * (double)m * (double)m;     // ~ block LDL^T + triangular inverse
     S.solve_entries += s2 * (m + (m - s2));
     S.max_m = std::max<int>(S.max_m, (int)m);
   }
@@ -429,34 +419,35 @@ std::string build_fronts(Symbolic& S, const std::vector<int32_t>& nptr, const st
   S.fnodes.assign(tot, -1);
   S.cinv0.assign(tot, -1);
   S.cinv1.assign(tot, -1);
-  for (int f = 0; f < nf; ++f) {
-    int32_t* fn = S.fnodes.data() + S.fnode_ptr[f];
-    std::copy(own[f].begin(), own[f].end(), fn);
-    std::copy(bnd[f].begin(), bnd[f].end(), fn + S.fs[f]);
-    if (f < leaf0) {
-      int32_t* c0 = S.cinv0.data() + S.fnode_ptr[f];
-      int32_t* c1 = S.cinv1.data() + S.fnode_ptr[f];
-      int so = S.fs_true[f];
-      for (int q = 0; q < so; ++q) { c0[q] = inv0[f][q]; c1[q] = inv1[f][q]; }
-      for (int q = 0; q < S.fb_true[f]; ++q) { c0[S.fs[f] + q] = inv0[f][so + q]; c1[S.fs[f] + q] = inv1[f][so + q]; }
-    }
-  }
-  // element node positions inside their leaf front
   S.epos.assign((size_t)6 * ne, -1);
-  std::vector<int32_t> mark(N, -1);
-  for (int lf = 0; lf < (1 << L); ++lf) {
-    int f = leaf0 + lf;
-    const int32_t* fn = S.fnodes.data() + S.fnode_ptr[f];
-    int mn = S.fs[f] + S.fb[f];
-    for (int q = 0; q < mn; ++q) if (fn[q] >= 0) mark[fn[q]] = q;
-    for (int32_t q = S.leaf_elem_ptr[lf]; q < S.leaf_elem_ptr[lf + 1]; ++q) {
-      int32_t e = S.leaf_elems[q];
-      for (int a = 0; a < 6; ++a) {
-        int32_t i = S.edof[(size_t)a * ne + e];
-        S.epos[(size_t)a * ne + e] = S.bmask[i] ? -1 : mark[i];
+  parallel_for(nf, nthreads, [&](int64_t b, int64_t e_, int) {
+    for (int64_t f = b; f < e_; ++f) {
+      int32_t* fn = S.fnodes.data() + S.fnode_ptr[f];
+      std::copy(own[f].begin(), own[f].end(), fn);
+      std::copy(bnd[f].begin(), bnd[f].end(), fn + S.fs[f]);
+      if (f < leaf0) {
+        int32_t* c0 = S.cinv0.data() + S.fnode_ptr[f];
+        int32_t* c1 = S.cinv1.data() + S.fnode_ptr[f];
+        const int so = S.fs_true[f];
+        for (int q = 0; q < so; ++q) { c0[q] = inv0[f][q]; c1[q] = inv1[f][q]; }
+        for (int q = 0; q < S.fb_true[f]; ++q) { c0[S.fs[f] + q] = inv0[f][so + q]; c1[S.fs[f] + q] = inv1[f][so + q]; }
+      } else {
+        // element node positions inside their leaf front (binary search in the two ascending lists)
+        const int lf = (int)f - leaf0;
+        for (int32_t q = S.leaf_elem_ptr[lf]; q < S.leaf_elem_ptr[lf + 1]; ++q) {
+          int32_t e = S.leaf_elems[q];
+          for (int a = 0; a < 6; ++a) {
+            int32_t i = S.edof[(size_t)a * ne + e];
+            if (S.bmask[i]) continue;
+            int32_t pos;
+            if (S.owner[i] == (int)f) pos = (int32_t)(std::lower_bound(own[f].begin(), own[f].end(), i) - own[f].begin());
+            else pos = S.fs[f] + (int32_t)(std::lower_bound(bnd[f].begin(), bnd[f].end(), i) - bnd[f].begin());
+            S.epos[(size_t)a * ne + e] = pos;
+          }
+        }
       }
     }
-  }
+  }, 64);
   return "";
 }
 
@@ -472,14 +463,12 @@ std::string build_symbolic(int nv, int ne, const double* p, const int32_t* t, in
   if (!err.empty()) return err;
   if (S.nsolve < 1) return "mesh has no interior DOF";
   auto t1 = clk::now();
-  std::vector<int32_t> nptr, nadj;
-  std::vector<uint8_t> nloc;
-  node_to_elem(S, nptr, nadj, nloc);
-  csr_pattern(S, nptr, nadj, nloc, nthreads);
+  node_to_elem(S);
+  csr_pattern(S, nthreads);
   auto t2 = clk::now();
   nd_tree(S, leaf_elems, nthreads);
   auto t3 = clk::now();
-  err = build_fronts(S, nptr, nadj);
+  err = build_fronts(S, nthreads);
   auto t4 = clk::now();
   S.t_numbering = secs(t0, t1);
   S.t_pattern = secs(t1, t2);

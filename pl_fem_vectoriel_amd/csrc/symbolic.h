@@ -28,8 +28,11 @@ struct Symbolic {
   // ---- scalar CSR pattern (full N x N, shared by every block of A and B) ----------------------
   std::vector<int32_t> rowptr;     // [N+1]
   std::vector<int32_t> colind;     // [nnz]
-  std::vector<int32_t> srcptr;     // [nnz+1]  contribution lists: slot -> element-matrix entries
-  std::vector<int32_t> src;        // [36 ne]  e*36 + a*6 + b   (a = local row/test, b = local col/trial)
+  std::vector<int32_t> slot_row;   // [nnz] row of every CSR slot
+  // node -> adjacent elements (ascending element ids): the contributions to row i come from these
+  std::vector<int32_t> nptr;       // [N+1]
+  std::vector<int32_t> nadj;       // [6 ne] element id
+  std::vector<uint8_t> nloc;       // [6 ne] local index of the node in that element
   // ---- nested-dissection front tree ----------------------------------------------------------
   int L = 0;                       // leaves at level L; fronts in heap order, nfronts = 2^(L+1)-1
   int nfronts = 0;

@@ -72,19 +72,16 @@ def test_numbering_and_pattern_match_oracle(built_library, c1_geometry, which):
     P.sort_indices()
     np.testing.assert_array_equal(sym.array("rowptr"), P.indptr)
     np.testing.assert_array_equal(sym.array("colind"), P.indices)
-    # contribution lists: every (e, a, b) exactly once, landing in slot (edof[a,e], edof[b,e]), counts = multiplicity
-    srcptr, src = sym.array("srcptr"), sym.array("src")
-    assert np.array_equal(np.sort(src), np.arange(36 * ed.shape[1]))
-    np.testing.assert_array_equal(np.diff(srcptr), P.data.astype(np.int64))
-    slot_of = np.repeat(np.arange(len(P.indices)), np.diff(srcptr))
-    e, a, bb = src // 36, (src % 36) // 6, src % 6
-    row_of_slot = np.repeat(np.arange(b.N), np.diff(P.indptr))
-    np.testing.assert_array_equal(row_of_slot[slot_of], ed[a, e])
-    np.testing.assert_array_equal(P.indices[slot_of], ed[bb, e])
-    # contributions to one slot are summed in ascending element order (deterministic assembly)
-    for k in np.random.default_rng(0).integers(0, len(P.indices), 200):
-        seg = src[srcptr[k]:srcptr[k + 1]] // 36
-        assert (np.diff(seg) >= 0).all()
+    np.testing.assert_array_equal(sym.array("slot_row"), np.repeat(np.arange(b.N), np.diff(P.indptr)))
+    # node -> element adjacency the device gather walks: every (element, local node) exactly once, filed
+    # under its node, elements ascending (=> deterministic summation order)
+    nptr, nadj, nloc = sym.array("nptr"), sym.array("nadj"), sym.array("nloc")
+    assert nptr[0] == 0 and nptr[-1] == 6 * ed.shape[1] == len(nadj) == len(nloc)
+    node_of = np.repeat(np.arange(b.N), np.diff(nptr))
+    np.testing.assert_array_equal(ed[nloc, nadj], node_of)
+    assert len(set(zip(nadj.tolist(), nloc.tolist()))) == 6 * ed.shape[1]
+    for i in np.random.default_rng(0).integers(0, b.N, 200):
+        assert (np.diff(nadj[nptr[i]:nptr[i + 1]]) > 0).all()
 
 
 def test_front_tree_invariants(built_library, c1_geometry):
