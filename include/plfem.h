@@ -79,9 +79,14 @@ int plfem_symbolic_get(const plfem_symbolic* sym, const char* name, void* out_ho
  * allocates every workspace (nothing is allocated later, so calls are graph-capturable).
  * hip_stream: a hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL = the default (null) stream.
  * max_ncv: largest Lanczos basis the context must hold.
+ * workspace_dev / workspace_bytes: optional caller-owned device memory (256-byte aligned, at least
+ * plfem_workspace_bytes(sym, max_ncv) bytes, e.g. a torch tensor so that torch's caching allocator
+ * recycles it between contexts) out of which EVERY device buffer of the context is carved; NULL / 0 =
+ * the library hipMalloc's one slab itself and frees it in plfem_destroy.
  * ------------------------------------------------------------------------------------------- */
+int plfem_workspace_bytes(const plfem_symbolic* sym, int32_t max_ncv, int64_t* bytes);
 int plfem_create(const plfem_symbolic* sym, int32_t device, void* hip_stream, int32_t max_ncv,
-                 plfem_ctx** out, char* err, int32_t errlen);
+                 void* workspace_dev, int64_t workspace_bytes, plfem_ctx** out, char* err, int32_t errlen);
 void plfem_destroy(plfem_ctx* ctx);
 const char* plfem_last_error(const plfem_ctx* ctx);
 int plfem_synchronize(plfem_ctx* ctx);

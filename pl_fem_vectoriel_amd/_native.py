@@ -26,7 +26,7 @@ POST_NAMES = ("norm", "div_energy", "core_x", "core_y", "all_x", "all_y")
 # every symbol include/plfem.h declares (tests check the library exports all of them)
 EXPORTS = (
     "plfem_symbolic_create", "plfem_symbolic_destroy", "plfem_symbolic_info", "plfem_symbolic_array_bytes",
-    "plfem_symbolic_get", "plfem_create", "plfem_destroy", "plfem_last_error", "plfem_synchronize",
+    "plfem_symbolic_get", "plfem_workspace_bytes", "plfem_create", "plfem_destroy", "plfem_last_error", "plfem_synchronize",
     "plfem_assemble_hfield", "plfem_block_values_dev", "plfem_block_values_host", "plfem_spmv", "plfem_factor",
     "plfem_solve", "plfem_lanczos_shift_invert", "plfem_postprocess", "plfem_timings",
     "plfem_debug_factor_until", "plfem_debug_copy",
@@ -73,8 +73,9 @@ def load_library() -> ctypes.CDLL:
     lib.plfem_symbolic_array_bytes.argtypes = [ctypes.c_void_p, ctypes.c_char_p]
     lib.plfem_symbolic_array_bytes.restype = ctypes.c_int64
     lib.plfem_symbolic_get.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_void_p, ctypes.c_int64]
-    lib.plfem_create.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32, c_void_pp,
-                                 ctypes.c_char_p, ctypes.c_int32]
+    lib.plfem_workspace_bytes.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.POINTER(ctypes.c_int64)]
+    lib.plfem_create.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p,
+                                 ctypes.c_int64, c_void_pp, ctypes.c_char_p, ctypes.c_int32]
     lib.plfem_destroy.argtypes = [ctypes.c_void_p]
     lib.plfem_destroy.restype = None
     lib.plfem_last_error.argtypes = [ctypes.c_void_p]
@@ -170,7 +171,17 @@ class Context:
         stream = torch.cuda.current_stream(self.tdev).cuda_stream if use_torch_stream else 0
         h = ctypes.c_void_p()
         err = ctypes.create_string_buffer(512)
-        rc = lib.plfem_create(sym._h, self.device, ctypes.c_void_p(stream), int(max_ncv), ctypes.byref(h), err, 512)
+        # every device buffer of the context lives in ONE torch tensor: torch's caching allocator
+        # recycles it when contexts come and go (cold solves in a loop pay no hipMalloc / hipFree)
+        need = ctypes.c_int64(0)
+        rc = lib.plfem_workspace_bytes(sym._h, int(max_ncv), ctypes.byref(need))
+        if rc != PLFEM_OK:
+            raise ValueError(f"plfem_workspace_bytes failed ({rc})")
+        self.workspace = torch.empty(int(need.value) + 256, dtype=torch.uint8, device=self.tdev)
+        base = self.workspace.data_ptr()
+        aligned = (base + 255) & ~255
+        rc = lib.plfem_create(sym._h, self.device, ctypes.c_void_p(stream), int(max_ncv), ctypes.c_void_p(aligned),
+                              ctypes.c_int64(int(need.value)), ctypes.byref(h), err, 512)
         if rc != PLFEM_OK:
             raise RuntimeError(f"plfem_create failed ({rc}): {err.value.decode()}")
         self._h = h
@@ -265,8 +276,9 @@ class Context:
 
     def close(self):
         if getattr(self, "_h", None):
-            self._lib.plfem_destroy(self._h)
+            self._lib.plfem_destroy(self._h)      # synchronises the stream before the workspace goes back to torch
             self._h = None
+            self.workspace = None
 
     def __del__(self):
         try:

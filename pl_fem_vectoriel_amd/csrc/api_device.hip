@@ -22,17 +22,28 @@ using plfem::Symbolic;
 
 namespace {
 
+// Every device buffer of a context is carved out of ONE slab (caller-provided, e.g. a torch tensor
+// recycled by its caching allocator, or hipMalloc'ed once here).  Pass 0 (c->slab == nullptr) only
+// measures; pass 1 places the buffers and uploads.
+inline size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
+
 template <class T>
-int upload(plfem_ctx* c, T** dst, const std::vector<T>& src) {
-  size_t bytes = std::max<size_t>(src.size(), 1) * sizeof(T);
-  HIP_TRY(c, hipMalloc((void**)dst, bytes));
-  if (!src.empty()) HIP_TRY(c, hipMemcpyAsync(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice, c->stream));
+int dalloc(plfem_ctx* c, T** dst, size_t count) {
+  size_t bytes = align_up(std::max<size_t>(count, 1) * sizeof(T));
+  if (c->slab) {
+    if (c->slab_off + bytes > c->slab_bytes) { c->err = "workspace too small"; return PLFEM_EINVAL; }
+    *dst = reinterpret_cast<T*>(c->slab + c->slab_off);
+  }
+  c->slab_off += bytes;
   return PLFEM_OK;
 }
 
 template <class T>
-int dalloc(plfem_ctx* c, T** dst, size_t count) {
-  HIP_TRY(c, hipMalloc((void**)dst, std::max<size_t>(count, 1) * sizeof(T)));
+int upload(plfem_ctx* c, T** dst, const std::vector<T>& src) {
+  int rc = dalloc(c, dst, src.size());
+  if (rc != PLFEM_OK) return rc;
+  if (c->slab && !src.empty())
+    HIP_TRY(c, hipMemcpyAsync(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice, c->stream));
   return PLFEM_OK;
 }
 
@@ -95,31 +106,25 @@ void jacobi_eigh(int n, std::vector<double>& A, std::vector<double>& V, std::vec
 }
 
 void free_all(plfem_ctx* c) {
-  auto F = [](void* p) { if (p) (void)hipFree(p); };
-  F(c->d_tsorted); F(c->d_edof); F(c->d_rowptr); F(c->d_colind); F(c->d_slot_row); F(c->d_nptr); F(c->d_nadj); F(c->d_nloc); F(c->d_interior);
-  F(c->d_bmask); F(c->d_doflocs); F(c->d_fs2); F(c->d_fm); F(c->d_fnode_ptr); F(c->d_foff); F(c->d_fnodes);
-  F(c->d_cinv0); F(c->d_cinv1); F(c->d_epos); F(c->d_leaf_elem_ptr); F(c->d_leaf_elems); F(c->d_cores);
-  F(c->d_elem);
-  for (auto& p : c->d_vals) F(p);
-  F(c->d_front); F(c->d_fvec); F(c->d_wbuf); F(c->d_rbuf); F(c->d_dinv); F(c->d_delta); F(c->d_tbuf); F(c->d_fvec2); F(c->d_counters);
-  F(c->d_V); F(c->d_BV); F(c->d_V2); F(c->d_BV2); F(c->d_w); F(c->d_bw); F(c->d_t1); F(c->d_t2);
-  F(c->d_h); F(c->d_hacc); F(c->d_partial); F(c->d_scal); F(c->d_S); F(c->d_Hcols); F(c->d_coremask); F(c->d_post);
+  if (c->own_slab && c->slab) (void)hipFree(c->slab);
   if (c->h_pinned) (void)hipHostFree(c->h_pinned);
   for (auto& pr : c->ev)
     for (auto& e : pr)
       if (e) (void)hipEventDestroy(e);
-  if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
 }
 
-int create_impl(plfem_ctx* c, const plfem_symbolic* sym, int device, void* stream, int max_ncv) {
+int create_impl(plfem_ctx* c, const plfem_symbolic* sym, int device, void* stream, int max_ncv, void* workspace,
+                int64_t workspace_bytes, bool size_only) {
   const Symbolic& S = sym->S;
   c->S = &S;
   c->device = device;
-  HIP_TRY(c, hipSetDevice(device));
   c->stream = (hipStream_t)stream;   // NULL = the device's default (null) stream
-  for (int q = 0; q < 5; ++q)
-    for (int r = 0; r < 2; ++r) HIP_TRY(c, hipEventCreate(&c->ev[q][r]));
-  HIP_TRY(c, hipEventRecord(c->ev[4][0], c->stream));
+  if (!size_only) {
+    HIP_TRY(c, hipSetDevice(device));
+    for (int q = 0; q < 5; ++q)
+      for (int r = 0; r < 2; ++r) HIP_TRY(c, hipEventCreate(&c->ev[q][r]));
+    HIP_TRY(c, hipEventRecord(c->ev[4][0], c->stream));
+  }
   c->nv = S.nv; c->ne = S.ne; c->N = S.N; c->nnz = (int)S.colind.size(); c->nsolve = S.nsolve;
   c->L = S.L; c->nfronts = S.nfronts; c->n2 = 2 * (int64_t)S.N; c->max_ncv = max_ncv;
   // per-front DOF counts + level table
@@ -137,6 +142,8 @@ int create_impl(plfem_ctx* c, const plfem_symbolic* sym, int device, void* strea
     }
     if (li.count > 65535) { c->err = "front tree level exceeds the launch grid limit"; return PLFEM_EINVAL; }
   }
+  auto place = [&]() -> int {
+  c->slab_off = 0;
   TRY(upload(c, &c->d_tsorted, S.tsorted));
   TRY(upload(c, &c->d_edof, S.edof));
   TRY(upload(c, &c->d_rowptr, S.rowptr));
@@ -171,7 +178,6 @@ int create_impl(plfem_ctx* c, const plfem_symbolic* sym, int device, void* strea
   TRY(dalloc(c, &c->d_tbuf, (size_t)2 * fnodes_total * plfem::NB));
   TRY(dalloc(c, &c->d_fvec2, (size_t)2 * fnodes_total));
   TRY(dalloc(c, &c->d_counters, 4));
-  HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, 4 * sizeof(int32_t), c->stream));
   const size_t n2 = (size_t)c->n2, nc1 = (size_t)max_ncv + 1;
   TRY(dalloc(c, &c->d_V, n2 * nc1));
   TRY(dalloc(c, &c->d_BV, n2 * nc1));
@@ -191,7 +197,27 @@ int create_impl(plfem_ctx* c, const plfem_symbolic* sym, int device, void* strea
   TRY(dalloc(c, &c->d_coremask, (size_t)S.N));
   const size_t post_blocks = (size_t)(S.N + 255) / 256;
   TRY(dalloc(c, &c->d_post, nc1 * post_blocks * 5 + nc1 * 5 + 16));
-  HIP_TRY(c, hipHostMalloc((void**)&c->h_pinned, sizeof(double) * (8192 + (nc1 + 1) * (nc1 + 1)), hipHostMallocDefault));
+  return PLFEM_OK;
+  };
+  TRY(place());                      // pass 0: measure
+  const size_t need = c->slab_off;
+  c->workspace_need = (int64_t)need;
+  if (size_only) return PLFEM_OK;
+  if (workspace) {
+    if (workspace_bytes < (int64_t)need) { c->err = "plfem_create: workspace smaller than plfem_workspace_bytes"; return PLFEM_EINVAL; }
+    if ((uintptr_t)workspace & 255) { c->err = "plfem_create: workspace must be 256-byte aligned"; return PLFEM_EINVAL; }
+    c->slab = reinterpret_cast<char*>(workspace);
+  } else {
+    HIP_TRY(c, hipMalloc((void**)&c->slab, need));
+    c->own_slab = true;
+  }
+  c->slab_bytes = need;
+  TRY(place());                      // pass 1: place + upload
+  HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, 4 * sizeof(int32_t), c->stream));
+  {
+    const size_t nc1p = (size_t)max_ncv + 2;
+    HIP_TRY(c, hipHostMalloc((void**)&c->h_pinned, sizeof(double) * (8192 + nc1p * nc1p), hipHostMallocDefault));
+  }
   HIP_TRY(c, hipEventRecord(c->ev[4][1], c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   c->ev_used[4] = true;
@@ -213,7 +239,8 @@ int upload_cores(plfem_ctx* c, const double* cores_host, int ncore) {
 }  // namespace
 
 extern "C" int plfem_create(const plfem_symbolic* sym, int32_t device, void* hip_stream, int32_t max_ncv,
-                            plfem_ctx** out, char* err, int32_t errlen) {
+                            void* workspace_dev, int64_t workspace_bytes, plfem_ctx** out, char* err,
+                            int32_t errlen) {
   if (!out) return PLFEM_EINVAL;
   *out = nullptr;
   auto fail = [&](const std::string& m, int code) {
@@ -227,7 +254,7 @@ extern "C" int plfem_create(const plfem_symbolic* sym, int32_t device, void* hip
     return fail("plfem_create: no HIP device available (this library has no CPU fallback)", PLFEM_EHIP);
   if (device < 0 || device >= ndev) return fail("plfem_create: device index out of range", PLFEM_EINVAL);
   plfem_ctx* c = new plfem_ctx();
-  int rc = create_impl(c, sym, device, hip_stream, max_ncv);
+  int rc = create_impl(c, sym, device, hip_stream, max_ncv, workspace_dev, workspace_bytes, false);
   if (rc != PLFEM_OK) {
     std::string m = c->err;
     free_all(c);
@@ -236,6 +263,14 @@ extern "C" int plfem_create(const plfem_symbolic* sym, int32_t device, void* hip
   }
   *out = c;
   return PLFEM_OK;
+}
+
+extern "C" int plfem_workspace_bytes(const plfem_symbolic* sym, int32_t max_ncv, int64_t* bytes) {
+  if (!sym || !bytes || max_ncv < 3 || max_ncv > 160) return PLFEM_EINVAL;
+  plfem_ctx tmp;
+  int rc = create_impl(&tmp, sym, 0, nullptr, max_ncv, nullptr, 0, true);
+  *bytes = tmp.workspace_need;
+  return rc;
 }
 
 extern "C" void plfem_destroy(plfem_ctx* ctx) {

@@ -66,6 +66,10 @@ struct plfem_ctx {
   double* d_post = nullptr;       // post-processing partial sums
   int npartial = 0;
   double* h_pinned = nullptr;     // pinned staging
+  char* slab = nullptr;           // the one device allocation every buffer above is carved from
+  size_t slab_off = 0, slab_bytes = 0;
+  bool own_slab = false;
+  int64_t workspace_need = 0;
   // state
   bool assembled = false, factored = false;
   double sigma = 0.0, k0 = 0.0;

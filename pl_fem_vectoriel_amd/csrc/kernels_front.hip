@@ -9,7 +9,7 @@
 // and, interleaved with it, the explicit inverse of the unit lower triangular L11 (a triangular
 // inverse is benign numerically, unlike F11^-1: the stiffness scale of near-degenerate elements
 // stays in the diagonal D).  What is left in F for the solves:
-//     lower(F11) = L11^-1, upper(F11) = L11^-T, F21 = L21, F12 = L21^T, delta = D
+//     lower(F11) = L11^-1, upper(F11) = L11^-T, F21 = Z = L21 L11^-1, F12 = Z^T, delta = D
 // so both solve sweeps are batched dense column-times-vector products over contiguous columns
 // (no triangular dependency chain inside a front).  A block Gauss-Jordan sweep (explicit F11^-1)
 // was tried first and is unstable on meshes with sliver elements ("numerics").
@@ -364,21 +364,88 @@ __device__ __forceinline__ double gather_rhs(int f, int i, int s2, int N, int le
   return v;
 }
 
-// 64-row tile of a dense matrix-vector product in "axpy form": lane = row (contiguous, coalesced),
-// the four waves of the block split the columns, partial sums meet in LDS in a fixed order.
-// element (r, c) = base[r + c*ld]; tri = 0: all columns in [c0, c1); tri = 1: only c <= r; tri = 2: only c >= r.
-template <int TRI>
-__device__ __forceinline__ double tile_gemv(const double* __restrict__ base, int64_t ld, int r, bool rvalid, int c0,
-                                            int c1, const double* __restrict__ v, double (*red)[64]) {
+// ---- Z = L21 L11^-1 (formed once per front after its LDL^T): with Z in place of L21 the forward
+// sweep of a front is ONE product [L11^-1; Z] r and the backward sweep ONE product [L11^-1; -Z]^T [D^-1 y; x_b].
+// Z^T (s2 x b2) is written into the F12 mirror region (F21 = L21 and the upper mirror of L11^-1 are
+// only read), 32x32 tile per wave on v_mfma_f64_16x16x4_f64; k_mirror_z then copies it back into F21.
+__global__ __launch_bounds__(256) void k_form_z(int first_front, const int32_t* __restrict__ fs2,
+                                                const int32_t* __restrict__ fm, const int64_t* __restrict__ foff,
+                                                double* __restrict__ front) {
+  const int f = first_front + blockIdx.z;
+  const int m = fm[f], s2 = fs2[f];
+  const int b2 = m - s2;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int b0 = (blockIdx.x * 2 + (wave & 1)) * 32;     // rows of Z (boundary DOFs)
+  const int c0 = (blockIdx.y * 2 + (wave >> 1)) * 32;     // columns of Z (owned DOFs)
+  if (b0 >= b2 || c0 >= s2) return;
+  double* F = front + foff[f];
+  const int lr = lane & 15, lk = lane >> 4;
+  const bool bv1 = b0 + 16 < b2, cv1 = c0 + 16 < s2;
+  v4d acc[2][2];
+  for (int tb = 0; tb < 2; ++tb)
+    for (int tc = 0; tc < 2; ++tc) acc[tb][tc] = (v4d){0.0, 0.0, 0.0, 0.0};
+  // Z[b, c] = sum_{j >= c} L21[b, j] Linv[j, c];  A <- L21 rows (contiguous in b), B <- Linv via the upper mirror
+  for (int j0 = c0; j0 < s2; j0 += 4) {
+    const int j = j0 + lk;
+    const double a0 = F[(int64_t)j * m + s2 + b0 + lr];
+    const double a1 = bv1 ? F[(int64_t)j * m + s2 + b0 + 16 + lr] : 0.0;
+    const int cA = c0 + lr, cB = c0 + 16 + lr;
+    const double x0 = (j >= cA) ? F[(int64_t)j * m + cA] : 0.0;
+    const double x1 = (cv1 && j >= cB) ? F[(int64_t)j * m + cB] : 0.0;
+    acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, x0, acc[0][0], 0, 0, 0);
+    acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, x1, acc[0][1], 0, 0, 0);
+    acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, x0, acc[1][0], 0, 0, 0);
+    acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, x1, acc[1][1], 0, 0, 0);
+  }
+  // D[row = b (lk + 4r)][col = c (lr)] -> Z^T[c, b] at F[c + (s2 + b) m]: lanes lr contiguous
+  for (int tb = 0; tb < 2; ++tb) {
+    if (tb == 1 && !bv1) continue;
+    for (int tc = 0; tc < 2; ++tc) {
+      if (tc == 1 && !cv1) continue;
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        F[(int64_t)(s2 + b0 + 16 * tb + lk + 4 * r) * m + (c0 + 16 * tc + lr)] = acc[tb][tc][r];
+    }
+  }
+}
+
+// F21[b, c] = F12[c, b] through a 32x32 LDS tile
+__global__ __launch_bounds__(256) void k_mirror_z(int first_front, const int32_t* __restrict__ fs2,
+                                                  const int32_t* __restrict__ fm, const int64_t* __restrict__ foff,
+                                                  double* __restrict__ front) {
+  const int f = first_front + blockIdx.z;
+  const int m = fm[f], s2 = fs2[f];
+  const int b2 = m - s2;
+  const int b0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+  if (b0 >= b2 || c0 >= s2) return;
+  __shared__ double tile[32][33];
+  double* F = front + foff[f];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+  for (int yy = ty; yy < 32; yy += 8) {
+    int c = c0 + tx, b = b0 + yy;
+    tile[yy][tx] = (c < s2 && b < b2) ? F[(int64_t)(s2 + b) * m + c] : 0.0;       // Z^T[c, b]
+  }
+  __syncthreads();
+  for (int yy = ty; yy < 32; yy += 8) {
+    int b = b0 + tx, c = c0 + yy;
+    if (b < b2 && c < s2) F[(int64_t)c * m + s2 + b] = tile[tx][yy];               // Z[b, c]
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// solve sweeps: one kernel per level and direction.
+//   forward : [ys; u] = [D^-1 L11^-1 r ;  w_b - Z r],     r = rhs_own + children's updates
+//   backward: x_own   = L11^-T ys - Z^T x_b
+// "tile" form (levels with many small fronts): lane = output row, the block's four waves split the
+// columns, partial sums meet in LDS in a fixed order.  "dot" form (few large fronts): one wave per
+// output, reduction across the lanes.  Both read contiguous runs of F thanks to the mirrored storage.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double tile_sum(const double* __restrict__ p, int64_t ld, bool valid, int cb, int ce,
+                                           const double* __restrict__ v, double (*red)[64]) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   double acc = 0.0;
-  if (rvalid) {
-    int cb = c0, ce = c1;
-    if (TRI == 1) ce = min(c1, r + 1);
-    if (TRI == 2) cb = max(c0, r);
-    // this wave's columns: c == wave (mod 4); 8 independent loads in flight per lane
-    int c = cb + ((wave - cb) & 3);
-    const double* p = base + r;
+  if (valid) {
+    int c = cb + ((wave - cb) & 3);       // this wave's columns: c == wave (mod 4); 8 loads in flight per lane
     for (; c + 28 < ce; c += 32) {
       double a[8];
 #pragma unroll
@@ -388,222 +455,128 @@ __device__ __forceinline__ double tile_gemv(const double* __restrict__ base, int
     }
     for (; c < ce; c += 4) acc += p[(int64_t)c * ld] * v[c];
   }
-  __syncthreads();            // previous tile's readers are done with red
   red[wave][lane] = acc;
   __syncthreads();
   return red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
 }
 
-// forward, step 1: y = L11^-1 r_own  (row i of L11^-1: lower triangle, contiguous down the rows)
-__global__ __launch_bounds__(256) void k_fwd_own(int first_front, int N, int leaf_level,
-                                                 const int32_t* __restrict__ fs2, const int32_t* __restrict__ fm,
-                                                 const int64_t* __restrict__ foff, const int64_t* __restrict__ fnode_ptr,
-                                                 const int32_t* __restrict__ fnodes, const int32_t* __restrict__ cinv0,
-                                                 const int32_t* __restrict__ cinv1, const double* __restrict__ front,
-                                                 const double* __restrict__ rhs, const double* __restrict__ fvec,
-                                                 double* __restrict__ fvec2) {
+__global__ __launch_bounds__(256) void k_fwd(int first_front, int N, int leaf_level, const int32_t* __restrict__ fs2,
+                                             const int32_t* __restrict__ fm, const int64_t* __restrict__ foff,
+                                             const int64_t* __restrict__ fnode_ptr, const int32_t* __restrict__ fnodes,
+                                             const int32_t* __restrict__ cinv0, const int32_t* __restrict__ cinv1,
+                                             const double* __restrict__ front, const double* __restrict__ delta,
+                                             const double* __restrict__ rhs, double* __restrict__ fvec,
+                                             double* __restrict__ fvec2) {
   extern __shared__ double sv[];
   __shared__ double red[4][64];
   const int f = first_front + blockIdx.y;
   const int m = fm[f], s2 = fs2[f];
-  if (blockIdx.x * 64 >= s2) return;
+  const int r0 = blockIdx.x * 64;
+  if (r0 >= m) return;
   const int64_t np = fnode_ptr[f];
   for (int i = threadIdx.x; i < s2; i += 256)
     sv[i] = gather_rhs(f, i, s2, N, leaf_level, np, fs2, fnode_ptr, fnodes, cinv0, cinv1, rhs, fvec);
   __syncthreads();
-  const int lane = threadIdx.x & 63;
-  const double* F = front + foff[f];
-  for (int r0 = blockIdx.x * 64; r0 < s2; r0 += gridDim.x * 64) {
-    const int r = r0 + lane;
-    double y = tile_gemv<1>(F, m, r, r < s2, 0, min(s2, r0 + 64), sv, red);
-    if (threadIdx.x < 64 && r < s2) fvec2[2 * np + r] = y;
+  const int r = r0 + (threadIdx.x & 63);
+  const bool valid = r < m;
+  const int ce = (r < s2) ? r + 1 : s2;               // rows of L11^-1 are lower triangular
+  const double acc = tile_sum(front + foff[f] + r, m, valid, 0, ce, sv, red);
+  if (threadIdx.x < 64 && valid) {
+    if (r < s2) fvec2[2 * np + r] = acc / delta[2 * np + r];
+    else fvec[2 * np + r] = gather_rhs(f, r, s2, N, leaf_level, np, fs2, fnode_ptr, fnodes, cinv0, cinv1, nullptr, fvec) - acc;
   }
 }
 
-// forward, step 2: u = w_b - L21 y   (row b of L21: block F21, contiguous down the rows)
-__global__ __launch_bounds__(256) void k_fwd_bnd(int first_front, int N, int leaf_level,
+__global__ __launch_bounds__(256) void k_fwd_dot(int first_front, int N, int leaf_level,
                                                  const int32_t* __restrict__ fs2, const int32_t* __restrict__ fm,
                                                  const int64_t* __restrict__ foff, const int64_t* __restrict__ fnode_ptr,
                                                  const int32_t* __restrict__ fnodes, const int32_t* __restrict__ cinv0,
                                                  const int32_t* __restrict__ cinv1, const double* __restrict__ front,
-                                                 double* __restrict__ fvec, const double* __restrict__ fvec2) {
-  extern __shared__ double sv[];
-  __shared__ double red[4][64];
-  const int f = first_front + blockIdx.y;
-  const int m = fm[f], s2 = fs2[f];
-  const int b2 = m - s2;
-  if (blockIdx.x * 64 >= b2) return;
-  const int64_t np = fnode_ptr[f];
-  for (int i = threadIdx.x; i < s2; i += 256) sv[i] = fvec2[2 * np + i];
-  __syncthreads();
-  const int lane = threadIdx.x & 63;
-  const double* F = front + foff[f] + s2;
-  for (int r0 = blockIdx.x * 64; r0 < b2; r0 += gridDim.x * 64) {
-    const int r = r0 + lane;
-    double acc = tile_gemv<0>(F, m, r, r < b2, 0, s2, sv, red);
-    if (threadIdx.x < 64 && r < b2)
-      fvec[2 * np + s2 + r] =
-          gather_rhs(f, s2 + r, s2, N, leaf_level, np, fs2, fnode_ptr, fnodes, cinv0, cinv1, nullptr, fvec) - acc;
-  }
-}
-
-// backward, step 1: t = D^-1 y - L21^T x_b   (row j of L21^T: block F12, contiguous down the rows)
-__global__ __launch_bounds__(256) void k_bwd_t(int first_front, int N, const int32_t* __restrict__ fs2,
-                                               const int32_t* __restrict__ fm, const int64_t* __restrict__ foff,
-                                               const int64_t* __restrict__ fnode_ptr, const int32_t* __restrict__ fnodes,
-                                               const double* __restrict__ front, const double* __restrict__ delta,
-                                               double* __restrict__ fvec, const double* __restrict__ fvec2,
-                                               const double* __restrict__ x) {
-  extern __shared__ double sv[];
-  __shared__ double red[4][64];
-  const int f = first_front + blockIdx.y;
-  const int m = fm[f], s2 = fs2[f];
-  if (blockIdx.x * 64 >= s2) return;
-  const int b2 = m - s2;
-  const int64_t np = fnode_ptr[f];
-  for (int i = threadIdx.x; i < b2; i += 256) {
-    int node = fnodes[np + ((s2 + i) >> 1)];
-    sv[i] = node >= 0 ? x[(int64_t)(i & 1) * N + node] : 0.0;     // s2 is even: parity of s2+i = parity of i
-  }
-  __syncthreads();
-  const int lane = threadIdx.x & 63;
-  const double* F = front + foff[f] + (int64_t)s2 * m;             // F12: element (j, b) at F[j + b*m]
-  for (int r0 = blockIdx.x * 64; r0 < s2; r0 += gridDim.x * 64) {
-    const int r = r0 + lane;
-    double acc = tile_gemv<0>(F, m, r, r < s2, 0, b2, sv, red);
-    if (threadIdx.x < 64 && r < s2) fvec[2 * np + r] = fvec2[2 * np + r] / delta[2 * np + r] - acc;
-  }
-}
-
-// backward, step 2: x_own = L11^-T t   (row j of L11^-T: upper mirror, contiguous down the rows)
-__global__ __launch_bounds__(256) void k_bwd_x(int first_front, int N, const int32_t* __restrict__ fs2,
-                                               const int32_t* __restrict__ fm, const int64_t* __restrict__ foff,
-                                               const int64_t* __restrict__ fnode_ptr, const int32_t* __restrict__ fnodes,
-                                               const double* __restrict__ front, const double* __restrict__ fvec,
-                                               double* __restrict__ x) {
-  extern __shared__ double sv[];
-  __shared__ double red[4][64];
-  const int f = first_front + blockIdx.y;
-  const int m = fm[f], s2 = fs2[f];
-  if (blockIdx.x * 64 >= s2) return;
-  const int64_t np = fnode_ptr[f];
-  for (int i = threadIdx.x; i < s2; i += 256) sv[i] = fvec[2 * np + i];
-  __syncthreads();
-  const int lane = threadIdx.x & 63;
-  const double* F = front + foff[f];
-  for (int r0 = blockIdx.x * 64; r0 < s2; r0 += gridDim.x * 64) {
-    const int r = r0 + lane;
-    double acc = tile_gemv<2>(F, m, r, r < s2, r0, s2, sv, red);
-    if (threadIdx.x < 64 && r < s2) {
-      const int node = fnodes[np + (r >> 1)];
-      if (node >= 0) x[(int64_t)(r & 1) * N + node] = acc;
-    }
-  }
-}
-
-// ---- the same four products in "dot form" (one wave per output, reduction across the lanes) for the
-// top levels of the tree: few fronts, long columns -> parallelism has to come from the outputs.
-__global__ __launch_bounds__(256) void k_fwd_own_dot(int first_front, int N, int leaf_level,
-                                                     const int32_t* __restrict__ fs2, const int32_t* __restrict__ fm,
-                                                     const int64_t* __restrict__ foff, const int64_t* __restrict__ fnode_ptr,
-                                                     const int32_t* __restrict__ fnodes, const int32_t* __restrict__ cinv0,
-                                                     const int32_t* __restrict__ cinv1, const double* __restrict__ front,
-                                                     const double* __restrict__ rhs, const double* __restrict__ fvec,
-                                                     double* __restrict__ fvec2) {
+                                                 const double* __restrict__ delta, const double* __restrict__ rhs,
+                                                 double* __restrict__ fvec, double* __restrict__ fvec2) {
   extern __shared__ double sv[];
   const int f = first_front + blockIdx.y;
   const int m = fm[f], s2 = fs2[f];
-  if (blockIdx.x * 4 >= s2) return;
+  if (blockIdx.x * 4 >= m) return;
   const int64_t np = fnode_ptr[f];
-  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
-  // only rows <= i of the right-hand side are needed by this block's four outputs
-  const int need = min(s2, blockIdx.x * 4 + 4);
+  const int need = min(s2, blockIdx.x * 4 + 4);       // rows < s2 only read r[0 .. row]
   for (int q = threadIdx.x; q < need; q += 256)
     sv[q] = gather_rhs(f, q, s2, N, leaf_level, np, fs2, fnode_ptr, fnodes, cinv0, cinv1, rhs, fvec);
   __syncthreads();
-  if (i >= s2) return;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= m) return;
   const int lane = threadIdx.x & 63;
-  const double* col = front + foff[f] + (int64_t)i * m;     // upper mirror: column i = row i of L11^-1
+  const double* col = front + foff[f] + (int64_t)r * m;  // column r of the upper part = row r of [L11^-1; Z]
+  const int ce = (r < s2) ? r + 1 : s2;
   double acc = 0.0;
-  for (int j = lane; j <= i; j += 64) acc += col[j] * sv[j];
+  for (int c = lane; c < ce; c += 64) acc += col[c] * sv[c];
   acc = wave_sum(acc);
-  if (lane == 0) fvec2[2 * np + i] = acc;
-}
-
-__global__ __launch_bounds__(256) void k_fwd_bnd_dot(int first_front, int N, int leaf_level,
-                                                     const int32_t* __restrict__ fs2, const int32_t* __restrict__ fm,
-                                                     const int64_t* __restrict__ foff, const int64_t* __restrict__ fnode_ptr,
-                                                     const int32_t* __restrict__ fnodes, const int32_t* __restrict__ cinv0,
-                                                     const int32_t* __restrict__ cinv1, const double* __restrict__ front,
-                                                     double* __restrict__ fvec, const double* __restrict__ fvec2) {
-  extern __shared__ double sv[];
-  const int f = first_front + blockIdx.y;
-  const int m = fm[f], s2 = fs2[f];
-  const int b2 = m - s2;
-  if (blockIdx.x * 4 >= b2) return;
-  const int64_t np = fnode_ptr[f];
-  for (int q = threadIdx.x; q < s2; q += 256) sv[q] = fvec2[2 * np + q];
-  __syncthreads();
-  const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (j >= b2) return;
-  const int lane = threadIdx.x & 63;
-  const double* col = front + foff[f] + (int64_t)(s2 + j) * m;   // F12 column = row j of L21
-  double acc = 0.0;
-  for (int i = lane; i < s2; i += 64) acc += col[i] * sv[i];
-  acc = wave_sum(acc);
-  if (lane == 0)
-    fvec[2 * np + s2 + j] =
-        gather_rhs(f, s2 + j, s2, N, leaf_level, np, fs2, fnode_ptr, fnodes, cinv0, cinv1, nullptr, fvec) - acc;
-}
-
-__global__ __launch_bounds__(256) void k_bwd_t_dot(int first_front, int N, const int32_t* __restrict__ fs2,
-                                                   const int32_t* __restrict__ fm, const int64_t* __restrict__ foff,
-                                                   const int64_t* __restrict__ fnode_ptr,
-                                                   const int32_t* __restrict__ fnodes, const double* __restrict__ front,
-                                                   const double* __restrict__ delta, double* __restrict__ fvec,
-                                                   const double* __restrict__ fvec2, const double* __restrict__ x) {
-  extern __shared__ double sv[];
-  const int f = first_front + blockIdx.y;
-  const int m = fm[f], s2 = fs2[f];
-  if (blockIdx.x * 4 >= s2) return;
-  const int b2 = m - s2;
-  const int64_t np = fnode_ptr[f];
-  for (int q = threadIdx.x; q < b2; q += 256) {
-    int node = fnodes[np + ((s2 + q) >> 1)];
-    sv[q] = node >= 0 ? x[(int64_t)(q & 1) * N + node] : 0.0;
+  if (lane == 0) {
+    if (r < s2) fvec2[2 * np + r] = acc / delta[2 * np + r];
+    else fvec[2 * np + r] = gather_rhs(f, r, s2, N, leaf_level, np, fs2, fnode_ptr, fnodes, cinv0, cinv1, nullptr, fvec) - acc;
   }
-  __syncthreads();
-  const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (j >= s2) return;
-  const int lane = threadIdx.x & 63;
-  const double* col = front + foff[f] + (int64_t)j * m + s2;     // F21 column j = column j of L21
-  double acc = 0.0;
-  for (int i = lane; i < b2; i += 64) acc += col[i] * sv[i];
-  acc = wave_sum(acc);
-  if (lane == 0) fvec[2 * np + j] = fvec2[2 * np + j] / delta[2 * np + j] - acc;
 }
 
-__global__ __launch_bounds__(256) void k_bwd_x_dot(int first_front, int N, const int32_t* __restrict__ fs2,
-                                                   const int32_t* __restrict__ fm, const int64_t* __restrict__ foff,
-                                                   const int64_t* __restrict__ fnode_ptr,
-                                                   const int32_t* __restrict__ fnodes, const double* __restrict__ front,
-                                                   const double* __restrict__ fvec, double* __restrict__ x) {
+// stage v = [ys ; -x_b] of front f in LDS (entries >= lo only)
+__device__ __forceinline__ void stage_bwd(double* sv, int lo, int m, int s2, int N, int64_t np,
+                                          const int32_t* __restrict__ fnodes, const double* __restrict__ fvec2,
+                                          const double* __restrict__ x) {
+  for (int i = lo + threadIdx.x; i < m; i += 256) {
+    double v;
+    if (i < s2) v = fvec2[2 * np + i];
+    else {
+      int node = fnodes[np + (i >> 1)];
+      v = node >= 0 ? -x[(int64_t)(i & 1) * N + node] : 0.0;
+    }
+    sv[i] = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_bwd(int first_front, int N, const int32_t* __restrict__ fs2,
+                                             const int32_t* __restrict__ fm, const int64_t* __restrict__ foff,
+                                             const int64_t* __restrict__ fnode_ptr, const int32_t* __restrict__ fnodes,
+                                             const double* __restrict__ front, const double* __restrict__ fvec2,
+                                             double* __restrict__ x) {
+  extern __shared__ double sv[];
+  __shared__ double red[4][64];
+  const int f = first_front + blockIdx.y;
+  const int m = fm[f], s2 = fs2[f];
+  const int r0 = blockIdx.x * 64;
+  if (r0 >= s2) return;
+  const int64_t np = fnode_ptr[f];
+  stage_bwd(sv, r0, m, s2, N, np, fnodes, fvec2, x);
+  __syncthreads();
+  const int r = r0 + (threadIdx.x & 63);
+  const bool valid = r < s2;
+  // element (j = r, i) of [L11^-T | Z^T] at F[r + i m], i in [r, m)
+  const double acc = tile_sum(front + foff[f] + r, m, valid, r, m, sv, red);
+  if (threadIdx.x < 64 && valid) {
+    const int node = fnodes[np + (r >> 1)];
+    if (node >= 0) x[(int64_t)(r & 1) * N + node] = acc;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_bwd_dot(int first_front, int N, const int32_t* __restrict__ fs2,
+                                                 const int32_t* __restrict__ fm, const int64_t* __restrict__ foff,
+                                                 const int64_t* __restrict__ fnode_ptr,
+                                                 const int32_t* __restrict__ fnodes, const double* __restrict__ front,
+                                                 const double* __restrict__ fvec2, double* __restrict__ x) {
   extern __shared__ double sv[];
   const int f = first_front + blockIdx.y;
   const int m = fm[f], s2 = fs2[f];
-  if (blockIdx.x * 4 >= s2) return;
-  const int64_t np = fnode_ptr[f];
   const int jlo = blockIdx.x * 4;
-  for (int q = jlo + threadIdx.x; q < s2; q += 256) sv[q] = fvec[2 * np + q];
+  if (jlo >= s2) return;
+  const int64_t np = fnode_ptr[f];
+  stage_bwd(sv, jlo, m, s2, N, np, fnodes, fvec2, x);
   __syncthreads();
   const int j = jlo + (threadIdx.x >> 6);
   if (j >= s2) return;
   const int node_j = fnodes[np + (j >> 1)];
   if (node_j < 0) return;
   const int lane = threadIdx.x & 63;
-  const double* col = front + foff[f] + (int64_t)j * m;          // lower triangle: column j of L11^-1
+  const double* col = front + foff[f] + (int64_t)j * m;   // column j of the lower part = column j of [L11^-1; Z]
   double acc = 0.0;
-  for (int i = j + lane; i < s2; i += 64) acc += col[i] * sv[i];
+  for (int i = j + lane; i < m; i += 64) acc += col[i] * sv[i];
   acc = wave_sum(acc);
   if (lane == 0) x[(int64_t)(j & 1) * N + node_j] = acc;
 }
@@ -650,6 +623,12 @@ void launch_factor(plfem_ctx* c, double sigma, int stop_level, int stop_step, in
       }
       if (stop_here && stop_stage == 4) return;
     }
+    if (li.max_b2 > 0 && li.max_s2 > 0) {
+      dim3 zg((li.max_b2 + 63) / 64, (li.max_s2 + 63) / 64, li.count);
+      hipLaunchKernelGGL(k_form_z, zg, dim3(256), 0, st, li.first, c->d_fs2, c->d_fm, c->d_foff, c->d_front);
+      dim3 mg((li.max_b2 + 31) / 32, (li.max_s2 + 31) / 32, li.count);
+      hipLaunchKernelGGL(k_mirror_z, mg, dim3(256), 0, st, li.first, c->d_fs2, c->d_fm, c->d_foff, c->d_front);
+    }
     if (lev == stop_level && stop_stage == 5) return;
   }
 }
@@ -657,56 +636,30 @@ void launch_factor(plfem_ctx* c, double sigma, int stop_level, int stop_step, in
 void launch_solve(plfem_ctx* c, const double* rhs, double* x) {
   hipStream_t st = c->stream;
   (void)hipMemsetAsync(x, 0, sizeof(double) * c->n2, st);
-  constexpr int TARGET_BLOCKS = 16384;  // one 64-row tile per block unless that would exceed ~64 blocks per CU
   constexpr int DOT_FORM_MAX_FRONTS = 32;   // levels with at most this many fronts use the dot-form kernels
-  auto split = [&](const LevelInfo& li, int rows) {
-    int want = (TARGET_BLOCKS + li.count - 1) / li.count;
-    return std::max(1, std::min(want, (rows + 63) / 64));
-  };
   for (int lev = c->L; lev >= 0; --lev) {
     const LevelInfo& li = c->levels[lev];
     const int leaf = lev == c->L ? 1 : 0;
-    const bool dot = li.count <= DOT_FORM_MAX_FRONTS;
-    if (li.max_s2 > 0) {
-      if (dot)
-        hipLaunchKernelGGL(k_fwd_own_dot, dim3((li.max_s2 + 3) / 4, li.count), dim3(256), sizeof(double) * li.max_s2,
-                           st, li.first, c->N, leaf, c->d_fs2, c->d_fm, c->d_foff, c->d_fnode_ptr, c->d_fnodes,
-                           c->d_cinv0, c->d_cinv1, c->d_front, rhs, c->d_fvec, c->d_fvec2);
-      else
-        hipLaunchKernelGGL(k_fwd_own, dim3(split(li, li.max_s2), li.count), dim3(256), sizeof(double) * li.max_s2, st,
-                           li.first, c->N, leaf, c->d_fs2, c->d_fm, c->d_foff, c->d_fnode_ptr, c->d_fnodes, c->d_cinv0,
-                           c->d_cinv1, c->d_front, rhs, c->d_fvec, c->d_fvec2);
-    }
-    if (li.max_b2 > 0) {
-      if (dot)
-        hipLaunchKernelGGL(k_fwd_bnd_dot, dim3((li.max_b2 + 3) / 4, li.count), dim3(256), sizeof(double) * li.max_s2,
-                           st, li.first, c->N, leaf, c->d_fs2, c->d_fm, c->d_foff, c->d_fnode_ptr, c->d_fnodes,
-                           c->d_cinv0, c->d_cinv1, c->d_front, c->d_fvec, c->d_fvec2);
-      else
-        hipLaunchKernelGGL(k_fwd_bnd, dim3(split(li, li.max_b2), li.count), dim3(256), sizeof(double) * li.max_s2, st,
-                           li.first, c->N, leaf, c->d_fs2, c->d_fm, c->d_foff, c->d_fnode_ptr, c->d_fnodes, c->d_cinv0,
-                           c->d_cinv1, c->d_front, c->d_fvec, c->d_fvec2);
-    }
+    if (li.count <= DOT_FORM_MAX_FRONTS)
+      hipLaunchKernelGGL(k_fwd_dot, dim3((li.max_m + 3) / 4, li.count), dim3(256), sizeof(double) * (li.max_s2 + 1), st,
+                         li.first, c->N, leaf, c->d_fs2, c->d_fm, c->d_foff, c->d_fnode_ptr, c->d_fnodes, c->d_cinv0,
+                         c->d_cinv1, c->d_front, c->d_delta, rhs, c->d_fvec, c->d_fvec2);
+    else
+      hipLaunchKernelGGL(k_fwd, dim3((li.max_m + 63) / 64, li.count), dim3(256), sizeof(double) * (li.max_s2 + 1), st,
+                         li.first, c->N, leaf, c->d_fs2, c->d_fm, c->d_foff, c->d_fnode_ptr, c->d_fnodes, c->d_cinv0,
+                         c->d_cinv1, c->d_front, c->d_delta, rhs, c->d_fvec, c->d_fvec2);
   }
   for (int lev = 0; lev <= c->L; ++lev) {
     const LevelInfo& li = c->levels[lev];
     if (li.max_s2 <= 0) continue;
-    const bool dot = li.count <= DOT_FORM_MAX_FRONTS;
-    if (dot) {
-      hipLaunchKernelGGL(k_bwd_t_dot, dim3((li.max_s2 + 3) / 4, li.count), dim3(256), sizeof(double) * (li.max_b2 + 1),
-                         st, li.first, c->N, c->d_fs2, c->d_fm, c->d_foff, c->d_fnode_ptr, c->d_fnodes, c->d_front,
-                         c->d_delta, c->d_fvec, c->d_fvec2, x);
-      hipLaunchKernelGGL(k_bwd_x_dot, dim3((li.max_s2 + 3) / 4, li.count), dim3(256), sizeof(double) * li.max_s2, st,
+    if (li.count <= DOT_FORM_MAX_FRONTS)
+      hipLaunchKernelGGL(k_bwd_dot, dim3((li.max_s2 + 3) / 4, li.count), dim3(256), sizeof(double) * (li.max_m + 1), st,
                          li.first, c->N, c->d_fs2, c->d_fm, c->d_foff, c->d_fnode_ptr, c->d_fnodes, c->d_front,
-                         c->d_fvec, x);
-    } else {
-      hipLaunchKernelGGL(k_bwd_t, dim3(split(li, li.max_s2), li.count), dim3(256), sizeof(double) * (li.max_b2 + 1),
-                         st, li.first, c->N, c->d_fs2, c->d_fm, c->d_foff, c->d_fnode_ptr, c->d_fnodes, c->d_front,
-                         c->d_delta, c->d_fvec, c->d_fvec2, x);
-      hipLaunchKernelGGL(k_bwd_x, dim3(split(li, li.max_s2), li.count), dim3(256), sizeof(double) * li.max_s2, st,
+                         c->d_fvec2, x);
+    else
+      hipLaunchKernelGGL(k_bwd, dim3((li.max_s2 + 63) / 64, li.count), dim3(256), sizeof(double) * (li.max_m + 1), st,
                          li.first, c->N, c->d_fs2, c->d_fm, c->d_foff, c->d_fnode_ptr, c->d_fnodes, c->d_front,
-                         c->d_fvec, x);
-    }
+                         c->d_fvec2, x);
   }
 }
 

@@ -83,7 +83,7 @@ def assemble_front(T: FrontTree, f, Ke, S):
 
 def ldl_partial(Fm, s2):
     """Unpivoted partial LDL^T of the first s2 pivots.  Returns the storage the HIP path leaves in F:
-    lower(F11) = L11^-1, upper(F11) = L11^-T, F21 = L21, F12 = L21^T, F22 = S; and D."""
+    lower(F11) = L11^-1, upper(F11) = L11^-T, F21 = Z = L21 L11^-1, F12 = Z^T, F22 = S; and D."""
     F = Fm.copy()
     m = F.shape[0]
     d = np.zeros(s2)
@@ -96,7 +96,9 @@ def ldl_partial(Fm, s2):
     X = sla.solve_triangular(L11, np.eye(s2), lower=True, unit_diagonal=True) if s2 else np.zeros((0, 0))
     out = F.copy()
     out[:s2, :s2] = np.tril(X) + np.tril(X, -1).T
-    out[:s2, s2:] = F[s2:, :s2].T
+    Z = F[s2:, :s2] @ np.tril(X)
+    out[s2:, :s2] = Z
+    out[:s2, s2:] = Z.T
     return out, d
 
 
@@ -132,9 +134,10 @@ def solve(T: FrontTree, Fs, Ds, rhs):
                 ok = inv >= 0
                 w[ok] += W[ch][T.s2(ch) + 2 * inv[ok] + comp[ok]]
         F = Fs[f]
-        y = np.array([F[:i + 1, i] @ w[:i + 1] for i in range(s2)])
-        w[s2:] -= F[:s2, s2:].T @ y
-        W[f], Y[f] = w, y
+        r = w[:s2].copy()
+        ys = np.array([F[:i + 1, i] @ r[:i + 1] for i in range(s2)]) / Ds[f] if s2 else np.zeros(0)
+        w[s2:] -= F[s2:, :s2] @ r                                  # u = w_b - Z r
+        W[f], Y[f] = w, ys
     x = np.zeros(2 * N)
     for f in range(T.nf):
         mn = int(T.fs[f] + T.fb[f])
@@ -144,8 +147,8 @@ def solve(T: FrontTree, Fs, Ds, rhs):
         comp = np.tile([0, 1], mn)
         xb = np.where(node[s2:] >= 0, x[comp[s2:] * N + np.maximum(node[s2:], 0)], 0.0)
         F = Fs[f]
-        t = Y[f] / Ds[f] - F[s2:, :s2].T @ xb
-        xo = np.array([F[j:s2, j] @ t[j:] for j in range(s2)])
+        v = np.concatenate([Y[f], -xb])                            # [ys ; -x_b]
+        xo = np.array([F[j:, j] @ v[j:] for j in range(s2)])      # L11^-T ys - Z^T x_b
         ok = node[:s2] >= 0
         x[comp[:s2][ok] * N + node[:s2][ok]] = xo[ok]
     return x

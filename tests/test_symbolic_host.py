@@ -40,7 +40,7 @@ def test_no_device_means_loud_failure(built_library, c1_geometry):
     # the C entry point itself also refuses (no silent CPU path)
     h = ctypes.c_void_p()
     err = ctypes.create_string_buffer(256)
-    rc = built_library.plfem_create(sym._h, 0, None, 45, ctypes.byref(h), err, 256)
+    rc = built_library.plfem_create(sym._h, 0, None, 45, None, 0, ctypes.byref(h), err, 256)
     assert rc == _native.PLFEM_EHIP and b"no HIP device" in err.value
 
 
