@@ -169,6 +169,17 @@ int plfem_postprocess(plfem_ctx* ctx, int32_t k, double* evecs_dev, const double
 int plfem_timings(plfem_ctx* ctx, double* out_host /* [8] */);
 
 /* ---------------------------------------------------------------------------------------------
+ * Live timing of the dominant kernel (bench.py "roofline"; no reference counterpart): between
+ * begin and end every launch of the tile-form backward-sweep kernel (k_bwd, the largest single
+ * consumer of GPU time in a solve) is bracketed by HIP events on the context's stream.
+ * out_host[3] = { launches timed, total microseconds, total algorithmic bytes of those launches }
+ * with algorithmic bytes of one launch = 8 B x sum over the level's fronts of
+ * (s2 m - s2^2/2 + m + s2): the entries of [L11^-T | Z^T] read once + staged vector + result.
+ * ------------------------------------------------------------------------------------------- */
+int plfem_profile_begin(plfem_ctx* ctx, int32_t max_launches);
+int plfem_profile_end(plfem_ctx* ctx, double* out_host /* [3] */);
+
+/* ---------------------------------------------------------------------------------------------
  * Debugging aids for the test-suite (no reference counterpart): run the factorisation only up to
  * a given (tree level, sweep step, stage: 0 assembled, 1 diag, 2 panel, 3 update, 4 level done),
  * and copy a slice of a named device workspace ("front","fvec","wbuf","rbuf","dinv","elem").

@@ -29,7 +29,7 @@ EXPORTS = (
     "plfem_symbolic_get", "plfem_workspace_bytes", "plfem_create", "plfem_destroy", "plfem_last_error", "plfem_synchronize",
     "plfem_assemble_hfield", "plfem_block_values_dev", "plfem_block_values_host", "plfem_spmv", "plfem_factor",
     "plfem_solve", "plfem_lanczos_shift_invert", "plfem_postprocess", "plfem_timings",
-    "plfem_debug_factor_until", "plfem_debug_copy",
+    "plfem_debug_factor_until", "plfem_debug_copy", "plfem_profile_begin", "plfem_profile_end",
 )
 
 _ARRAY_DTYPES = {
@@ -97,6 +97,8 @@ def load_library() -> ctypes.CDLL:
     lib.plfem_debug_factor_until.argtypes = [ctypes.c_void_p, ctypes.c_double, ctypes.c_int32, ctypes.c_int32,
                                              ctypes.c_int32]
     lib.plfem_debug_copy.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p]
+    lib.plfem_profile_begin.argtypes = [ctypes.c_void_p, ctypes.c_int32]
+    lib.plfem_profile_end.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
     _lib = lib
     return lib
 
@@ -270,6 +272,14 @@ class Context:
         self._check(self._lib.plfem_debug_copy(self._h, name.encode(), ctypes.c_int64(int(offset)),
                                                ctypes.c_int64(int(count)), _ptr(out)), "plfem_debug_copy")
         return out
+
+    def profile_begin(self, max_launches: int = 4096):
+        self._check(self._lib.plfem_profile_begin(self._h, int(max_launches)), "plfem_profile_begin")
+
+    def profile_end(self):
+        out = np.zeros(3, dtype=np.float64)
+        self._check(self._lib.plfem_profile_end(self._h, _ptr(out)), "plfem_profile_end")
+        return {"launches": int(out[0]), "total_us": float(out[1]), "bytes": float(out[2])}
 
     def synchronize(self):
         self._check(self._lib.plfem_synchronize(self._h), "plfem_synchronize")

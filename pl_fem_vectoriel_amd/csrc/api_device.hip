@@ -111,6 +111,7 @@ void free_all(plfem_ctx* c) {
   for (auto& pr : c->ev)
     for (auto& e : pr)
       if (e) (void)hipEventDestroy(e);
+  for (auto& e : c->prof_ev) (void)hipEventDestroy(e);
 }
 
 int create_impl(plfem_ctx* c, const plfem_symbolic* sym, int device, void* stream, int max_ncv, void* workspace,
@@ -139,6 +140,9 @@ int create_impl(plfem_ctx* c, const plfem_symbolic* sym, int device, void* strea
       li.max_m = std::max(li.max_m, fm[f]);
       li.max_s2 = std::max(li.max_s2, fs2[f]);
       li.max_b2 = std::max(li.max_b2, fm[f] - fs2[f]);
+      // backward sweep of one front: columns i in [j, m) for every owned row j of [L11^-T | Z^T], the staged
+      // vector (m) and the owned part of the solution (s2)
+      li.bwd_bytes += 8.0 * ((double)fs2[f] * fm[f] - 0.5 * (double)fs2[f] * fs2[f] + fm[f] + fs2[f]);
     }
     if (li.count > 65535) { c->err = "front tree level exceeds the launch grid limit"; return PLFEM_EINVAL; }
   }
@@ -552,5 +556,36 @@ extern "C" int plfem_debug_copy(plfem_ctx* c, const char* name, int64_t offset, 
   else return PLFEM_EINVAL;
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   HIP_TRY(c, hipMemcpy(out_host, src + offset, sizeof(double) * count, hipMemcpyDeviceToHost));
+  return PLFEM_OK;
+}
+
+// ---- live kernel timing for bench.py's roofline object -------------------------------------------
+extern "C" int plfem_profile_begin(plfem_ctx* c, int32_t max_launches) {
+  if (!c || max_launches < 1) return PLFEM_EINVAL;
+  HIP_TRY(c, hipSetDevice(c->device));
+  while ((int)c->prof_ev.size() < 2 * max_launches) {
+    hipEvent_t e;
+    HIP_TRY(c, hipEventCreate(&e));
+    c->prof_ev.push_back(e);
+  }
+  c->prof_n = 0;
+  c->prof_bytes = 0;
+  c->prof_on = true;
+  return PLFEM_OK;
+}
+
+extern "C" int plfem_profile_end(plfem_ctx* c, double* out_host) {
+  if (!c || !out_host) return PLFEM_EINVAL;
+  c->prof_on = false;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  double total_us = 0;
+  for (int q = 0; q < c->prof_n; ++q) {
+    float ms = 0;
+    HIP_TRY(c, hipEventElapsedTime(&ms, c->prof_ev[2 * q], c->prof_ev[2 * q + 1]));
+    total_us += ms * 1e3;
+  }
+  out_host[0] = c->prof_n;
+  out_host[1] = total_us;
+  out_host[2] = c->prof_bytes;
   return PLFEM_OK;
 }

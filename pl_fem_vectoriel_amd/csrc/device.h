@@ -21,6 +21,7 @@ struct LevelInfo {
   int max_m = 0;    // DOFs
   int max_s2 = 0;
   int max_b2 = 0;
+  double bwd_bytes = 0;   // algorithmic bytes one k_bwd / k_bwd_dot launch of this level moves
 };
 
 }  // namespace plfem
@@ -72,6 +73,11 @@ struct plfem_ctx {
   int64_t workspace_need = 0;
   // state
   bool assembled = false, factored = false;
+  // live kernel timing (plfem_profile_*): event pairs around every tile-form backward-sweep launch
+  bool prof_on = false;
+  int prof_n = 0;
+  double prof_bytes = 0;
+  std::vector<hipEvent_t> prof_ev;
   double sigma = 0.0, k0 = 0.0;
   hipEvent_t ev[5][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
   bool ev_used[5] = {false, false, false, false, false};

@@ -656,10 +656,19 @@ void launch_solve(plfem_ctx* c, const double* rhs, double* x) {
       hipLaunchKernelGGL(k_bwd_dot, dim3((li.max_s2 + 3) / 4, li.count), dim3(256), sizeof(double) * (li.max_m + 1), st,
                          li.first, c->N, c->d_fs2, c->d_fm, c->d_foff, c->d_fnode_ptr, c->d_fnodes, c->d_front,
                          c->d_fvec2, x);
-    else
+    else {
+      // optional live timing of this kernel (bench.py roofline): HIP events on the launch stream
+      const bool timed = c->prof_on && c->prof_n < (int)c->prof_ev.size() / 2;
+      if (timed) (void)hipEventRecord(c->prof_ev[2 * c->prof_n], st);
       hipLaunchKernelGGL(k_bwd, dim3((li.max_s2 + 63) / 64, li.count), dim3(256), sizeof(double) * (li.max_m + 1), st,
                          li.first, c->N, c->d_fs2, c->d_fm, c->d_foff, c->d_fnode_ptr, c->d_fnodes, c->d_front,
                          c->d_fvec2, x);
+      if (timed) {
+        (void)hipEventRecord(c->prof_ev[2 * c->prof_n + 1], st);
+        c->prof_bytes += li.bwd_bytes;
+        ++c->prof_n;
+      }
+    }
   }
 }
 

@@ -111,7 +111,7 @@ class TrueVectorialMaxwellSolver:
 
     def __init__(self, geometry, use_pml: bool = False, n_modes: Optional[int] = None, device: Optional[int] = None,
                  eig_tol: float = 1e-10, leaf_elems: int = 0, reuse_symbolic: bool = True, mesh_refinement: float = 1.0,
-                 mesh_levels: int = 1, refine_steps: int = 0):
+                 mesh_levels: int = 1, refine_steps: int = 0, profile_kernel: bool = False):
         _native.load_library()           # fail loudly: the reference raises RuntimeError when its backend is missing
         self.geometry = geometry
         self.k0 = geometry.k0
@@ -124,6 +124,7 @@ class TrueVectorialMaxwellSolver:
         self.mesh_refinement = mesh_refinement
         self.mesh_levels = mesh_levels
         self.refine_steps = int(refine_steps)
+        self.profile_kernel = bool(profile_kernel)   # HIP-event timing of the dominant kernel (bench.py roofline)
         self._cache = {}
         self.last_stats: Dict = {}
         logger.info(f"Solveur H-field initialisé - k₀={self.k0:.4f} µm⁻¹")
@@ -199,7 +200,11 @@ class TrueVectorialMaxwellSolver:
         self._assemble_device(ctx)
         sigma = shift_estimate(g)
         ctx.factor(sigma)
+        if self.profile_kernel:
+            ctx.profile_begin(4096)
         evals, evecs, st = ctx.lanczos(n_req, ncv, self.eig_tol, self.MAXITER, sigma)
+        if self.profile_kernel:
+            st = dict(st, kernel_profile=ctx.profile_end())
         post, frac_core, modes_int = ctx.postprocess(evecs, cores, want_interior=True)
         t1 = time.perf_counter()
         vecs = modes_int.cpu().numpy()        # (k, 2 N_solve): the caller owns NumPy copies, as in the reference
