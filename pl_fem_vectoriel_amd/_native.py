@@ -239,7 +239,8 @@ class Context:
         stats = np.zeros(8, dtype=np.float64)
         rc = self._lib.plfem_lanczos_shift_invert(self._h, int(k), int(ncv), float(tol), int(maxiter), float(sigma),
                                                   _ptr(evals), ctypes.c_void_p(evecs.data_ptr()), _ptr(stats))
-        st = {"nconv": int(stats[0]), "n_opinv": int(stats[1]), "restarts": int(stats[2]), "max_rel_res": float(stats[3])}
+        st = {"nconv": int(stats[0]), "n_opinv": int(stats[1]), "restarts": int(stats[2]), "max_rel_res": float(stats[3]),
+              "n_block_solves": int(stats[4])}       # 0: single-vector recurrence was used
         if rc == PLFEM_ENOCONV:
             raise ArpackLikeNoConvergence(self._lib.plfem_last_error(self._h).decode(), evals, evecs)
         self._check(rc, "plfem_lanczos_shift_invert")

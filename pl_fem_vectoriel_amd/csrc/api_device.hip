@@ -3,6 +3,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 
@@ -143,6 +144,7 @@ int create_impl(plfem_ctx* c, const plfem_symbolic* sym, int device, void* strea
       // backward sweep of one front: columns i in [j, m) for every owned row j of [L11^-T | Z^T], the staged
       // vector (m) and the owned part of the solution (s2)
       li.bwd_bytes += 8.0 * ((double)fs2[f] * fm[f] - 0.5 * (double)fs2[f] * fs2[f] + fm[f] + fs2[f]);
+      li.bwd_vec_doubles += fm[f] + fs2[f];
     }
     if (li.count > 65535) { c->err = "front tree level exceeds the launch grid limit"; return PLFEM_EINVAL; }
   }
@@ -174,27 +176,30 @@ int create_impl(plfem_ctx* c, const plfem_symbolic* sym, int device, void* strea
   for (auto& p : c->d_vals) TRY(dalloc(c, &p, (size_t)c->nnz));
   const int64_t fnodes_total = S.fnode_ptr[S.nfronts];
   TRY(dalloc(c, &c->d_front, (size_t)S.foff[S.nfronts]));
-  TRY(dalloc(c, &c->d_fvec, (size_t)2 * fnodes_total));
+  TRY(dalloc(c, &c->d_fvec, (size_t)2 * fnodes_total * plfem::BLOCK_P));
   TRY(dalloc(c, &c->d_wbuf, (size_t)2 * fnodes_total * plfem::NB));
   TRY(dalloc(c, &c->d_rbuf, (size_t)2 * fnodes_total * plfem::NB));
   TRY(dalloc(c, &c->d_dinv, (size_t)S.nfronts * plfem::NB * plfem::NB));
   TRY(dalloc(c, &c->d_delta, (size_t)2 * fnodes_total));
   TRY(dalloc(c, &c->d_tbuf, (size_t)2 * fnodes_total * plfem::NB));
-  TRY(dalloc(c, &c->d_fvec2, (size_t)2 * fnodes_total));
+  TRY(dalloc(c, &c->d_fvec2, (size_t)2 * fnodes_total * plfem::BLOCK_P));
   TRY(dalloc(c, &c->d_counters, 4));
-  const size_t n2 = (size_t)c->n2, nc1 = (size_t)max_ncv + 1;
+  const size_t n2 = (size_t)c->n2, nc1 = (size_t)max_ncv + 1 + plfem::BLOCK_P;
   TRY(dalloc(c, &c->d_V, n2 * nc1));
   TRY(dalloc(c, &c->d_BV, n2 * nc1));
   TRY(dalloc(c, &c->d_V2, n2 * nc1));
   TRY(dalloc(c, &c->d_BV2, n2 * nc1));
-  TRY(dalloc(c, &c->d_w, n2));
-  TRY(dalloc(c, &c->d_bw, n2));
+  TRY(dalloc(c, &c->d_w, n2 * plfem::BLOCK_P));
+  TRY(dalloc(c, &c->d_bw, n2 * plfem::BLOCK_P));
+  TRY(dalloc(c, &c->d_hblk, (nc1 + 8) * plfem::BLOCK_P));
+  TRY(dalloc(c, &c->d_G, 64));
+  TRY(dalloc(c, &c->d_Rinv, 64));
   TRY(dalloc(c, &c->d_t1, n2));
   TRY(dalloc(c, &c->d_t2, n2));
   c->npartial = (int)((c->n2 + 2047) / 2048);
   TRY(dalloc(c, &c->d_h, nc1 + 8));
   TRY(dalloc(c, &c->d_hacc, nc1 + 8));
-  TRY(dalloc(c, &c->d_partial, (size_t)c->npartial * (nc1 + 8)));
+  TRY(dalloc(c, &c->d_partial, (size_t)c->npartial * (nc1 + 8) * plfem::BLOCK_P));
   TRY(dalloc(c, &c->d_scal, 16));
   TRY(dalloc(c, &c->d_S, nc1 * nc1));
   TRY(dalloc(c, &c->d_Hcols, (nc1 + 1) * (nc1 + 1)));
@@ -219,7 +224,7 @@ int create_impl(plfem_ctx* c, const plfem_symbolic* sym, int device, void* strea
   TRY(place());                      // pass 1: place + upload
   HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, 4 * sizeof(int32_t), c->stream));
   {
-    const size_t nc1p = (size_t)max_ncv + 2;
+    const size_t nc1p = (size_t)max_ncv + 2 + plfem::BLOCK_P;
     HIP_TRY(c, hipHostMalloc((void**)&c->h_pinned, sizeof(double) * (8192 + nc1p * nc1p), hipHostMallocDefault));
   }
   HIP_TRY(c, hipEventRecord(c->ev[4][1], c->stream));
@@ -363,6 +368,158 @@ extern "C" int plfem_solve(plfem_ctx* c, const double* rhs_dev, double* x_dev, i
 }
 
 // ------------------------------------------------------------------------------------------------
+// block thick-restart Lanczos (BLOCK_P vectors per step): every pass over the factors of the
+// shift-invert operator serves BLOCK_P right-hand sides.  Same projected-matrix / restart logic as
+// the single-vector driver below; the block residual R_m (P x P) couples the last block.
+// ------------------------------------------------------------------------------------------------
+static int lanczos_block(plfem_ctx* c, int k, int ncv, double tol, int maxiter, double sigma, double* evals_host,
+                         double* evecs_dev, double* stats_host) {
+  constexpr int P = plfem::BLOCK_P;
+  const int64_t n = c->n2;
+  hipStream_t st = c->stream;
+  HIP_TRY(c, hipEventRecord(c->ev[2][0], st));
+  const int m = std::min(c->max_ncv, ((ncv + P - 1) / P) * P);   // basis columns before the residual block
+  const int ld = m + P;                                            // leading dimension of the projected matrix
+  std::vector<double> T((size_t)ld * ld, 0.0);
+  double* hH = c->h_pinned + 8192;
+  int nop = 0, nblock = 0, restarts = 0;
+  {
+    std::vector<double> v0((size_t)n * P, 0.0);
+    uint64_t s = 0x9E3779B97F4A7C15ull;
+    const Symbolic& S = *c->S;
+    for (int q = 0; q < P; ++q)
+      for (int comp = 0; comp < 2; ++comp)
+        for (int i = 0; i < S.nsolve; ++i) {
+          s = s * 6364136223846793005ull + 1442695040888963407ull;
+          v0[(size_t)q * n + (size_t)comp * S.N + S.interior[i]] = ((double)(s >> 11) / 9007199254740992.0) * 2.0 - 1.0;
+        }
+    HIP_TRY(c, hipMemcpyAsync(c->d_V2, v0.data(), sizeof(double) * n * P, hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipStreamSynchronize(st));
+    for (int q = 0; q < P; ++q) plfem::launch_spmv(c, 1, c->d_V2 + (size_t)q * n, c->d_bw + (size_t)q * n);
+    plfem::launch_solve_block(c, c->d_bw, c->d_w, n);
+    nop += P; ++nblock;
+    for (int q = 0; q < P; ++q) plfem::launch_spmv(c, 1, c->d_w + (size_t)q * n, c->d_bw + (size_t)q * n);
+    plfem::launch_panel_dot_block(c, c->d_w, P, c->d_bw, n, c->d_G, P);
+    plfem::launch_chol_block(c, c->d_G, P, c->d_hblk, P, c->d_Rinv);      // R itself is not needed for the start block
+    plfem::launch_block_scale(c, c->d_w, c->d_bw, n, c->d_Rinv, c->d_V, c->d_BV, n);
+  }
+  HIP_TRY(c, hipMemsetAsync(c->d_Hcols, 0, sizeof(double) * ld * ld, st));
+  int c0 = 0, mm = 0, nconv = 0;
+  double max_rel_res = 0.0;
+  bool done = false;
+  std::vector<double> theta, Svec, Tm;
+  std::vector<int> order;
+  const int first_new_col = 0;
+  (void)first_new_col;
+  int cstart = 0;                 // first column computed in the current cycle
+  while (true) {
+    cstart = c0;
+    while (c0 + P <= m) {
+      const int nc = c0 + P;
+      plfem::launch_solve_block(c, c->d_BV + (size_t)c0 * n, c->d_w, n);       // W = OP V_j
+      nop += P; ++nblock;
+      double* Hblk = c->d_Hcols + (size_t)c0 * ld;                              // T[0:nc, c0:c0+P]
+      plfem::launch_panel_dot_block(c, c->d_BV, nc, c->d_w, n, Hblk, ld);
+      plfem::launch_panel_axpy_block(c, c->d_V, nc, Hblk, ld, c->d_w, n);
+      plfem::launch_panel_dot_block(c, c->d_BV, nc, c->d_w, n, c->d_hblk, ld);  // CGS2 second pass
+      plfem::launch_panel_axpy_block(c, c->d_V, nc, c->d_hblk, ld, c->d_w, n);
+      plfem::launch_mat_add(c, nc, Hblk, ld, c->d_hblk, ld);
+      for (int q = 0; q < P; ++q) plfem::launch_spmv(c, 1, c->d_w + (size_t)q * n, c->d_bw + (size_t)q * n);
+      plfem::launch_panel_dot_block(c, c->d_w, P, c->d_bw, n, c->d_G, P);       // Gram matrix W^T B W
+      plfem::launch_chol_block(c, c->d_G, P, Hblk + nc, ld, c->d_Rinv);         // R -> T[nc:nc+P, c0:c0+P]
+      plfem::launch_block_scale(c, c->d_w, c->d_bw, n, c->d_Rinv, c->d_V + (size_t)nc * n, c->d_BV + (size_t)nc * n, n);
+      c0 = nc;
+    }
+    mm = c0;
+    TRY(check_launch(c, "block lanczos step"));
+    HIP_TRY(c, hipMemcpyAsync(hH, c->d_Hcols, sizeof(double) * ld * ld, hipMemcpyDeviceToHost, st));
+    int32_t* hc = reinterpret_cast<int32_t*>(c->h_pinned + 4096);
+    HIP_TRY(c, hipMemcpyAsync(hc, c->d_counters, sizeof(int32_t) * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipStreamSynchronize(st));
+    if (hc[2] != 0) { c->err = "block Lanczos: rank-deficient block (Krylov space exhausted)"; return PLFEM_ESINGULAR; }
+    for (int j = cstart; j < mm; ++j)
+      for (int i = 0; i < ld; ++i) T[(size_t)j * ld + i] = hH[(size_t)j * ld + i];
+    // symmetric mm x mm projected matrix from the upper triangle
+    Tm.assign((size_t)mm * mm, 0.0);
+    for (int j = 0; j < mm; ++j)
+      for (int i = 0; i <= j; ++i) {
+        double v = T[(size_t)j * ld + i];
+        if (!std::isfinite(v)) { c->err = "block Lanczos breakdown: non-finite projected matrix"; return PLFEM_ESINGULAR; }
+        Tm[(size_t)j * mm + i] = v;
+        Tm[(size_t)i * mm + j] = v;
+      }
+    jacobi_eigh(mm, Tm, Svec, theta);
+    order.resize(mm);
+    std::iota(order.begin(), order.end(), 0);
+    std::sort(order.begin(), order.end(), [&](int a, int b) { return std::fabs(theta[a]) > std::fabs(theta[b]); });
+    // residual of Ritz pair i: || R_m S[mm-P:mm, i] ||, R_m = T[mm:mm+P, mm-P:mm] (upper triangular)
+    auto resid = [&](int id) {
+      double r2 = 0.0;
+      for (int a = 0; a < P; ++a) {
+        double v = 0.0;
+        for (int b = a; b < P; ++b) v += T[(size_t)(mm - P + b) * ld + (mm + a)] * Svec[(size_t)id * mm + (mm - P + b)];
+        r2 += v * v;
+      }
+      return std::sqrt(r2);
+    };
+    nconv = 0;
+    max_rel_res = 0.0;
+    for (int q = 0; q < k; ++q) {
+      int id = order[q];
+      double rel = resid(id) / std::max(std::fabs(theta[id]), 3.7e-11);
+      max_rel_res = std::max(max_rel_res, rel);
+      if (rel <= tol) ++nconv;
+    }
+    if (nconv >= k || restarts >= maxiter) { done = nconv >= k; break; }
+    int pk = k + std::min(nconv, (mm - k) / 2);
+    pk = std::max(pk, k + (mm - k) / 4);
+    pk = std::min(pk, mm - 2 * P);
+    std::vector<double> Ssel((size_t)mm * pk);
+    for (int q = 0; q < pk; ++q) std::memcpy(&Ssel[(size_t)q * mm], &Svec[(size_t)order[q] * mm], sizeof(double) * mm);
+    std::memcpy(hH, Ssel.data(), sizeof(double) * mm * pk);
+    HIP_TRY(c, hipMemcpyAsync(c->d_S, hH, sizeof(double) * mm * pk, hipMemcpyHostToDevice, st));
+    plfem::launch_rotate(c, c->d_V, mm, c->d_S, mm, pk, c->d_V2);
+    plfem::launch_rotate(c, c->d_BV, mm, c->d_S, mm, pk, c->d_BV2);
+    HIP_TRY(c, hipMemcpyAsync(c->d_V2 + (size_t)pk * n, c->d_V + (size_t)mm * n, sizeof(double) * n * P, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(c, hipMemcpyAsync(c->d_BV2 + (size_t)pk * n, c->d_BV + (size_t)mm * n, sizeof(double) * n * P, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(c, hipStreamSynchronize(st));
+    std::swap(c->d_V, c->d_V2);
+    std::swap(c->d_BV, c->d_BV2);
+    std::fill(T.begin(), T.end(), 0.0);
+    for (int q = 0; q < pk; ++q) T[(size_t)q * ld + q] = theta[order[q]];
+    HIP_TRY(c, hipMemsetAsync(c->d_Hcols, 0, sizeof(double) * ld * ld, st));
+    c0 = pk;
+    ++restarts;
+  }
+  std::vector<int> want(order.begin(), order.begin() + k);
+  std::vector<double> lam(mm);
+  for (int i = 0; i < mm; ++i) lam[i] = sigma + 1.0 / theta[i];
+  std::sort(want.begin(), want.end(), [&](int a, int b) { return lam[a] < lam[b]; });
+  for (int q = 0; q < k; ++q) {
+    evals_host[q] = lam[want[q]];
+    std::memcpy(hH + (size_t)q * mm, &Svec[(size_t)want[q] * mm], sizeof(double) * mm);
+  }
+  HIP_TRY(c, hipMemcpyAsync(c->d_S, hH, sizeof(double) * mm * k, hipMemcpyHostToDevice, st));
+  plfem::launch_rotate(c, c->d_V, mm, c->d_S, mm, k, evecs_dev);
+  HIP_TRY(c, hipEventRecord(c->ev[2][1], st));
+  c->ev_used[2] = true;
+  TRY(check_launch(c, "ritz rotation"));
+  HIP_TRY(c, hipStreamSynchronize(st));
+  if (stats_host) {
+    stats_host[0] = nconv;
+    stats_host[1] = nop;
+    stats_host[2] = restarts;
+    stats_host[3] = max_rel_res;
+    stats_host[4] = nblock;
+  }
+  if (!done) {
+    c->err = "Lanczos: no convergence within maxiter restarts";
+    return PLFEM_ENOCONV;
+  }
+  return PLFEM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // thick-restart Lanczos, shift-invert, B inner product
 // ------------------------------------------------------------------------------------------------
 extern "C" int plfem_lanczos_shift_invert(plfem_ctx* c, int32_t k, int32_t ncv, double tol, int32_t maxiter,
@@ -373,6 +530,17 @@ extern "C" int plfem_lanczos_shift_invert(plfem_ctx* c, int32_t k, int32_t ncv, 
   if (k < 1 || ncv <= k || ncv > c->max_ncv || ncv > 2 * c->nsolve) { c->err = "need 1 <= k < ncv <= max_ncv"; return PLFEM_EINVAL; }
   if (tol <= 0) tol = 2.2e-16;
   HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipMemsetAsync(c->d_counters + 2, 0, sizeof(int32_t), c->stream));
+  // large problems: block Lanczos (BLOCK_P right-hand sides per pass over the factors); tiny ones
+  // (Krylov space of dimension ~n) keep the single-vector recurrence
+  {
+    const char* env = std::getenv("PLFEM_LANCZOS_BLOCK");
+    const bool allow = !(env && env[0] == '0');
+    const int mblk = ((ncv + plfem::BLOCK_P - 1) / plfem::BLOCK_P) * plfem::BLOCK_P;
+    if (allow && k >= plfem::BLOCK_P && mblk <= c->max_ncv && mblk >= k + 3 * plfem::BLOCK_P &&
+        2 * (int64_t)c->nsolve >= 16 * (int64_t)(mblk + plfem::BLOCK_P))
+      return lanczos_block(c, k, ncv, tol, maxiter, sigma, evals_host, evecs_dev, stats_host);
+  }
   hipStream_t st = c->stream;
   HIP_TRY(c, hipEventRecord(c->ev[2][0], st));
   const int m = ncv;

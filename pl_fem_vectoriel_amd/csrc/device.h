@@ -11,7 +11,8 @@
 
 namespace plfem {
 
-constexpr int NB = 32;          // pivot-block width of the block Gauss-Jordan sweep
+constexpr int NB = 32;          // pivot-block width of the block LDL^T
+constexpr int BLOCK_P = 4;      // right-hand sides per block solve / block Lanczos step
 constexpr int ELEM_FORMS = 8;   // Axx Axy Ayx Ayy Minv Dxx Dxy Dyy
 constexpr int ELEM_STRIDE = ELEM_FORMS * 36;
 
@@ -21,7 +22,8 @@ struct LevelInfo {
   int max_m = 0;    // DOFs
   int max_s2 = 0;
   int max_b2 = 0;
-  double bwd_bytes = 0;   // algorithmic bytes one k_bwd / k_bwd_dot launch of this level moves
+  double bwd_bytes = 0;   // algorithmic bytes one k_bwd / k_bwd_dot launch of this level moves (1 rhs)
+  double bwd_vec_doubles = 0;   // vector doubles (staged + written) per rhs of that launch
 };
 
 }  // namespace plfem
@@ -60,7 +62,8 @@ struct plfem_ctx {
   int32_t* d_counters = nullptr;  // [0] pivot perturbations
   // ---- Lanczos workspace
   double *d_V = nullptr, *d_BV = nullptr, *d_V2 = nullptr, *d_BV2 = nullptr;   // n2 x (max_ncv+1), column major
-  double *d_w = nullptr, *d_bw = nullptr, *d_t1 = nullptr, *d_t2 = nullptr;    // n2
+  double *d_w = nullptr, *d_bw = nullptr, *d_t1 = nullptr, *d_t2 = nullptr;    // n2 (d_w, d_bw: n2 x BLOCK_P)
+  double *d_hblk = nullptr, *d_G = nullptr, *d_Rinv = nullptr;                 // block Lanczos small matrices
   double *d_h = nullptr, *d_hacc = nullptr, *d_partial = nullptr, *d_scal = nullptr, *d_S = nullptr;
   double* d_Hcols = nullptr;      // (max_ncv+1) x (max_ncv+1) projected matrix columns
   uint8_t* d_coremask = nullptr;  // [N]
@@ -93,6 +96,7 @@ void launch_spmv(plfem_ctx* c, int which, const double* x, double* y);
 // kernels_front.hip
 void launch_factor(plfem_ctx* c, double sigma, int stop_level = -1, int stop_step = 0, int stop_stage = 0);
 void launch_solve(plfem_ctx* c, const double* rhs, double* x);
+void launch_solve_block(plfem_ctx* c, const double* rhs, double* x, int64_t ldx);   // BLOCK_P right-hand sides
 // kernels_lanczos.hip
 void launch_panel_dot(plfem_ctx* c, const double* P, int ncols, const double* w, double* h);   // h = P^T w
 void launch_panel_axpy(plfem_ctx* c, const double* P, int ncols, const double* h, double* w);  // w -= P h
@@ -102,6 +106,13 @@ void launch_scale_store(plfem_ctx* c, const double* w, const double* bw, const d
                         double* beta_out);  // v = w/sqrt(beta2), bv = bw/sqrt(beta2)
 void launch_axpby(plfem_ctx* c, double a, const double* x, double b, const double* y, double* z);  // z = a x + b y
 void launch_rotate(plfem_ctx* c, const double* V, int m, const double* Smat, int ldS, int p, double* out);  // out = V[:, :m] S
+// block (BLOCK_P vectors) variants; H matrices are column major with leading dimension ldh
+void launch_panel_dot_block(plfem_ctx* c, const double* Pm, int ncols, const double* W, int64_t ldw, double* h, int ldh);
+void launch_panel_axpy_block(plfem_ctx* c, const double* Pm, int ncols, const double* H, int ldh, double* W, int64_t ldw);
+void launch_mat_add(plfem_ctx* c, int ncols, double* acc, int lda, const double* h, int ldh);
+void launch_chol_block(plfem_ctx* c, const double* G, int ldg, double* Tblk, int ldT, double* Rinv);
+void launch_block_scale(plfem_ctx* c, const double* W, const double* BW, int64_t ldw, const double* Rinv, double* Vn,
+                        double* BVn, int64_t ldv);
 void launch_post(plfem_ctx* c, int k, double* evecs, int ncore, double* out_host, double* frac_core, double* modes_int);
 
 }  // namespace plfem

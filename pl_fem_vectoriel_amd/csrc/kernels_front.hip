@@ -337,33 +337,6 @@ __global__ __launch_bounds__(256) void k_ldl_update(int first_front, int kb, con
   }
 }
 
-// ------------------------------------------------------------------------------------------------
-// solve sweeps.  Grid = (nsplit, fronts of the level); every block stages the vector it multiplies
-// with in LDS once, then its four waves walk the front's columns (one wave per column, dot product
-// down a contiguous column of F).  No block is launched without work.
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ double wave_sum(double v) {
-  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
-  return v;
-}
-
-// local right-hand side of local DOF i: global rhs (owned DOFs) + the children's updates
-__device__ __forceinline__ double gather_rhs(int f, int i, int s2, int N, int leaf_level, int64_t np,
-                                             const int32_t* __restrict__ fs2, const int64_t* __restrict__ fnode_ptr,
-                                             const int32_t* __restrict__ fnodes, const int32_t* __restrict__ cinv0,
-                                             const int32_t* __restrict__ cinv1, const double* __restrict__ rhs,
-                                             const double* __restrict__ fvec) {
-  const int q = i >> 1, c = i & 1;
-  const int node = fnodes[np + q];
-  double v = (i < s2 && node >= 0) ? rhs[(int64_t)c * N + node] : 0.0;
-  if (!leaf_level) {
-    int c0 = cinv0[np + q], c1 = cinv1[np + q];
-    if (c0 >= 0) { int ch = 2 * f + 1; v += fvec[2 * fnode_ptr[ch] + fs2[ch] + 2 * c0 + c]; }
-    if (c1 >= 0) { int ch = 2 * f + 2; v += fvec[2 * fnode_ptr[ch] + fs2[ch] + 2 * c1 + c]; }
-  }
-  return v;
-}
-
 // ---- Z = L21 L11^-1 (formed once per front after its LDL^T): with Z in place of L21 the forward
 // sweep of a front is ONE product [L11^-1; Z] r and the backward sweep ONE product [L11^-1; -Z]^T [D^-1 y; x_b].
 // Z^T (s2 x b2) is written into the F12 mirror region (F21 = L21 and the upper mirror of L11^-1 are
@@ -433,61 +406,130 @@ __global__ __launch_bounds__(256) void k_mirror_z(int first_front, const int32_t
 }
 
 // ------------------------------------------------------------------------------------------------
-// solve sweeps: one kernel per level and direction.
+// solve sweeps: one kernel per level and direction, P right-hand sides at a time (P = 1: plfem_solve
+// and single-vector Lanczos; P = 4: block Lanczos -- every entry of the factors is read once for P
+// vectors).
 //   forward : [ys; u] = [D^-1 L11^-1 r ;  w_b - Z r],     r = rhs_own + children's updates
 //   backward: x_own   = L11^-T ys - Z^T x_b
 // "tile" form (levels with many small fronts): lane = output row, the block's four waves split the
 // columns, partial sums meet in LDS in a fixed order.  "dot" form (few large fronts): one wave per
 // output, reduction across the lanes.  Both read contiguous runs of F thanks to the mirrored storage.
+// Global vectors: column q of rhs / x at offset q*ldx.  Per-front vectors: [dof][P] interleaved.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ double tile_sum(const double* __restrict__ p, int64_t ld, bool valid, int cb, int ce,
-                                           const double* __restrict__ v, double (*red)[64]) {
+__device__ __forceinline__ double wave_sum(double v) {
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+
+// local right-hand side of local DOF i: global rhs (owned DOFs) + the children's updates
+template <int P>
+__device__ __forceinline__ void gather_rhs(double (&v)[P], int f, int i, int s2, int N, int64_t ldx, int leaf_level,
+                                           int64_t np, const int32_t* __restrict__ fs2,
+                                           const int64_t* __restrict__ fnode_ptr, const int32_t* __restrict__ fnodes,
+                                           const int32_t* __restrict__ cinv0, const int32_t* __restrict__ cinv1,
+                                           const double* __restrict__ rhs, const double* __restrict__ fvec) {
+  const int q = i >> 1, c = i & 1;
+  const int node = fnodes[np + q];
+#pragma unroll
+  for (int u = 0; u < P; ++u) v[u] = 0.0;
+  if (i < s2 && node >= 0) {
+#pragma unroll
+    for (int u = 0; u < P; ++u) v[u] = rhs[(int64_t)u * ldx + (int64_t)c * N + node];
+  }
+  if (!leaf_level) {
+    int c0 = cinv0[np + q], c1 = cinv1[np + q];
+    if (c0 >= 0) {
+      int ch = 2 * f + 1;
+      const double* s = fvec + (2 * fnode_ptr[ch] + fs2[ch] + 2 * c0 + c) * P;
+#pragma unroll
+      for (int u = 0; u < P; ++u) v[u] += s[u];
+    }
+    if (c1 >= 0) {
+      int ch = 2 * f + 2;
+      const double* s = fvec + (2 * fnode_ptr[ch] + fs2[ch] + 2 * c1 + c) * P;
+#pragma unroll
+      for (int u = 0; u < P; ++u) v[u] += s[u];
+    }
+  }
+}
+
+template <int P>
+__device__ __forceinline__ void tile_sum(double (&out)[P], const double* __restrict__ p, int64_t ld, bool valid,
+                                         int cb, int ce, const double* __restrict__ v, double* __restrict__ red) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  double acc = 0.0;
+  double acc[P];
+#pragma unroll
+  for (int u = 0; u < P; ++u) acc[u] = 0.0;
   if (valid) {
     int c = cb + ((wave - cb) & 3);       // this wave's columns: c == wave (mod 4); 8 loads in flight per lane
     for (; c + 28 < ce; c += 32) {
       double a[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) a[u] = p[(int64_t)(c + 4 * u) * ld];
+      for (int t = 0; t < 8; ++t) a[t] = p[(int64_t)(c + 4 * t) * ld];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) acc += a[u] * v[c + 4 * u];
+      for (int t = 0; t < 8; ++t) {
+#pragma unroll
+        for (int u = 0; u < P; ++u) acc[u] += a[t] * v[(c + 4 * t) * P + u];
+      }
     }
-    for (; c < ce; c += 4) acc += p[(int64_t)c * ld] * v[c];
+    for (; c < ce; c += 4) {
+      const double a = p[(int64_t)c * ld];
+#pragma unroll
+      for (int u = 0; u < P; ++u) acc[u] += a * v[c * P + u];
+    }
   }
-  red[wave][lane] = acc;
+#pragma unroll
+  for (int u = 0; u < P; ++u) red[(wave * P + u) * 64 + lane] = acc[u];
   __syncthreads();
-  return red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+#pragma unroll
+  for (int u = 0; u < P; ++u)
+    out[u] = red[(0 * P + u) * 64 + lane] + red[(1 * P + u) * 64 + lane] + red[(2 * P + u) * 64 + lane] +
+             red[(3 * P + u) * 64 + lane];
 }
 
-__global__ __launch_bounds__(256) void k_fwd(int first_front, int N, int leaf_level, const int32_t* __restrict__ fs2,
-                                             const int32_t* __restrict__ fm, const int64_t* __restrict__ foff,
-                                             const int64_t* __restrict__ fnode_ptr, const int32_t* __restrict__ fnodes,
-                                             const int32_t* __restrict__ cinv0, const int32_t* __restrict__ cinv1,
-                                             const double* __restrict__ front, const double* __restrict__ delta,
-                                             const double* __restrict__ rhs, double* __restrict__ fvec,
-                                             double* __restrict__ fvec2) {
+template <int P>
+__global__ __launch_bounds__(256) void k_fwd(int first_front, int N, int64_t ldx, int leaf_level,
+                                             const int32_t* __restrict__ fs2, const int32_t* __restrict__ fm,
+                                             const int64_t* __restrict__ foff, const int64_t* __restrict__ fnode_ptr,
+                                             const int32_t* __restrict__ fnodes, const int32_t* __restrict__ cinv0,
+                                             const int32_t* __restrict__ cinv1, const double* __restrict__ front,
+                                             const double* __restrict__ delta, const double* __restrict__ rhs,
+                                             double* __restrict__ fvec, double* __restrict__ fvec2) {
   extern __shared__ double sv[];
-  __shared__ double red[4][64];
+  __shared__ double red[4 * P * 64];
   const int f = first_front + blockIdx.y;
   const int m = fm[f], s2 = fs2[f];
   const int r0 = blockIdx.x * 64;
   if (r0 >= m) return;
   const int64_t np = fnode_ptr[f];
-  for (int i = threadIdx.x; i < s2; i += 256)
-    sv[i] = gather_rhs(f, i, s2, N, leaf_level, np, fs2, fnode_ptr, fnodes, cinv0, cinv1, rhs, fvec);
+  for (int i = threadIdx.x; i < s2; i += 256) {
+    double v[P];
+    gather_rhs<P>(v, f, i, s2, N, ldx, leaf_level, np, fs2, fnode_ptr, fnodes, cinv0, cinv1, rhs, fvec);
+#pragma unroll
+    for (int u = 0; u < P; ++u) sv[i * P + u] = v[u];
+  }
   __syncthreads();
   const int r = r0 + (threadIdx.x & 63);
   const bool valid = r < m;
   const int ce = (r < s2) ? r + 1 : s2;               // rows of L11^-1 are lower triangular
-  const double acc = tile_sum(front + foff[f] + r, m, valid, 0, ce, sv, red);
+  double acc[P];
+  tile_sum<P>(acc, front + foff[f] + r, m, valid, 0, ce, sv, red);
   if (threadIdx.x < 64 && valid) {
-    if (r < s2) fvec2[2 * np + r] = acc / delta[2 * np + r];
-    else fvec[2 * np + r] = gather_rhs(f, r, s2, N, leaf_level, np, fs2, fnode_ptr, fnodes, cinv0, cinv1, nullptr, fvec) - acc;
+    if (r < s2) {
+      const double di = 1.0 / delta[2 * np + r];
+#pragma unroll
+      for (int u = 0; u < P; ++u) fvec2[(2 * np + r) * P + u] = acc[u] * di;
+    } else {
+      double w[P];
+      gather_rhs<P>(w, f, r, s2, N, ldx, leaf_level, np, fs2, fnode_ptr, fnodes, cinv0, cinv1, nullptr, fvec);
+#pragma unroll
+      for (int u = 0; u < P; ++u) fvec[(2 * np + r) * P + u] = w[u] - acc[u];
+    }
   }
 }
 
-__global__ __launch_bounds__(256) void k_fwd_dot(int first_front, int N, int leaf_level,
+template <int P>
+__global__ __launch_bounds__(256) void k_fwd_dot(int first_front, int N, int64_t ldx, int leaf_level,
                                                  const int32_t* __restrict__ fs2, const int32_t* __restrict__ fm,
                                                  const int64_t* __restrict__ foff, const int64_t* __restrict__ fnode_ptr,
                                                  const int32_t* __restrict__ fnodes, const int32_t* __restrict__ cinv0,
@@ -500,63 +542,91 @@ __global__ __launch_bounds__(256) void k_fwd_dot(int first_front, int N, int lea
   if (blockIdx.x * 4 >= m) return;
   const int64_t np = fnode_ptr[f];
   const int need = min(s2, blockIdx.x * 4 + 4);       // rows < s2 only read r[0 .. row]
-  for (int q = threadIdx.x; q < need; q += 256)
-    sv[q] = gather_rhs(f, q, s2, N, leaf_level, np, fs2, fnode_ptr, fnodes, cinv0, cinv1, rhs, fvec);
+  for (int i = threadIdx.x; i < need; i += 256) {
+    double v[P];
+    gather_rhs<P>(v, f, i, s2, N, ldx, leaf_level, np, fs2, fnode_ptr, fnodes, cinv0, cinv1, rhs, fvec);
+#pragma unroll
+    for (int u = 0; u < P; ++u) sv[i * P + u] = v[u];
+  }
   __syncthreads();
   const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= m) return;
   const int lane = threadIdx.x & 63;
   const double* col = front + foff[f] + (int64_t)r * m;  // column r of the upper part = row r of [L11^-1; Z]
   const int ce = (r < s2) ? r + 1 : s2;
-  double acc = 0.0;
-  for (int c = lane; c < ce; c += 64) acc += col[c] * sv[c];
-  acc = wave_sum(acc);
+  double acc[P];
+#pragma unroll
+  for (int u = 0; u < P; ++u) acc[u] = 0.0;
+  for (int c = lane; c < ce; c += 64) {
+    const double a = col[c];
+#pragma unroll
+    for (int u = 0; u < P; ++u) acc[u] += a * sv[c * P + u];
+  }
+#pragma unroll
+  for (int u = 0; u < P; ++u) acc[u] = wave_sum(acc[u]);
   if (lane == 0) {
-    if (r < s2) fvec2[2 * np + r] = acc / delta[2 * np + r];
-    else fvec[2 * np + r] = gather_rhs(f, r, s2, N, leaf_level, np, fs2, fnode_ptr, fnodes, cinv0, cinv1, nullptr, fvec) - acc;
+    if (r < s2) {
+      const double di = 1.0 / delta[2 * np + r];
+#pragma unroll
+      for (int u = 0; u < P; ++u) fvec2[(2 * np + r) * P + u] = acc[u] * di;
+    } else {
+      double w[P];
+      gather_rhs<P>(w, f, r, s2, N, ldx, leaf_level, np, fs2, fnode_ptr, fnodes, cinv0, cinv1, nullptr, fvec);
+#pragma unroll
+      for (int u = 0; u < P; ++u) fvec[(2 * np + r) * P + u] = w[u] - acc[u];
+    }
   }
 }
 
-// stage v = [ys ; -x_b] of front f in LDS (entries >= lo only)
-__device__ __forceinline__ void stage_bwd(double* sv, int lo, int m, int s2, int N, int64_t np,
+// stage v = [ys ; -x_b] of front f in LDS (entries >= lo only), [dof][P]
+template <int P>
+__device__ __forceinline__ void stage_bwd(double* sv, int lo, int m, int s2, int N, int64_t ldx, int64_t np,
                                           const int32_t* __restrict__ fnodes, const double* __restrict__ fvec2,
                                           const double* __restrict__ x) {
   for (int i = lo + threadIdx.x; i < m; i += 256) {
-    double v;
-    if (i < s2) v = fvec2[2 * np + i];
-    else {
-      int node = fnodes[np + (i >> 1)];
-      v = node >= 0 ? -x[(int64_t)(i & 1) * N + node] : 0.0;
+    if (i < s2) {
+#pragma unroll
+      for (int u = 0; u < P; ++u) sv[i * P + u] = fvec2[(2 * np + i) * P + u];
+    } else {
+      const int node = fnodes[np + (i >> 1)];
+#pragma unroll
+      for (int u = 0; u < P; ++u)
+        sv[i * P + u] = node >= 0 ? -x[(int64_t)u * ldx + (int64_t)(i & 1) * N + node] : 0.0;
     }
-    sv[i] = v;
   }
 }
 
-__global__ __launch_bounds__(256) void k_bwd(int first_front, int N, const int32_t* __restrict__ fs2,
+template <int P>
+__global__ __launch_bounds__(256) void k_bwd(int first_front, int N, int64_t ldx, const int32_t* __restrict__ fs2,
                                              const int32_t* __restrict__ fm, const int64_t* __restrict__ foff,
                                              const int64_t* __restrict__ fnode_ptr, const int32_t* __restrict__ fnodes,
                                              const double* __restrict__ front, const double* __restrict__ fvec2,
                                              double* __restrict__ x) {
   extern __shared__ double sv[];
-  __shared__ double red[4][64];
+  __shared__ double red[4 * P * 64];
   const int f = first_front + blockIdx.y;
   const int m = fm[f], s2 = fs2[f];
   const int r0 = blockIdx.x * 64;
   if (r0 >= s2) return;
   const int64_t np = fnode_ptr[f];
-  stage_bwd(sv, r0, m, s2, N, np, fnodes, fvec2, x);
+  stage_bwd<P>(sv, r0, m, s2, N, ldx, np, fnodes, fvec2, x);
   __syncthreads();
   const int r = r0 + (threadIdx.x & 63);
   const bool valid = r < s2;
   // element (j = r, i) of [L11^-T | Z^T] at F[r + i m], i in [r, m)
-  const double acc = tile_sum(front + foff[f] + r, m, valid, r, m, sv, red);
+  double acc[P];
+  tile_sum<P>(acc, front + foff[f] + r, m, valid, r, m, sv, red);
   if (threadIdx.x < 64 && valid) {
     const int node = fnodes[np + (r >> 1)];
-    if (node >= 0) x[(int64_t)(r & 1) * N + node] = acc;
+    if (node >= 0) {
+#pragma unroll
+      for (int u = 0; u < P; ++u) x[(int64_t)u * ldx + (int64_t)(r & 1) * N + node] = acc[u];
+    }
   }
 }
 
-__global__ __launch_bounds__(256) void k_bwd_dot(int first_front, int N, const int32_t* __restrict__ fs2,
+template <int P>
+__global__ __launch_bounds__(256) void k_bwd_dot(int first_front, int N, int64_t ldx, const int32_t* __restrict__ fs2,
                                                  const int32_t* __restrict__ fm, const int64_t* __restrict__ foff,
                                                  const int64_t* __restrict__ fnode_ptr,
                                                  const int32_t* __restrict__ fnodes, const double* __restrict__ front,
@@ -567,7 +637,7 @@ __global__ __launch_bounds__(256) void k_bwd_dot(int first_front, int N, const i
   const int jlo = blockIdx.x * 4;
   if (jlo >= s2) return;
   const int64_t np = fnode_ptr[f];
-  stage_bwd(sv, jlo, m, s2, N, np, fnodes, fvec2, x);
+  stage_bwd<P>(sv, jlo, m, s2, N, ldx, np, fnodes, fvec2, x);
   __syncthreads();
   const int j = jlo + (threadIdx.x >> 6);
   if (j >= s2) return;
@@ -575,10 +645,20 @@ __global__ __launch_bounds__(256) void k_bwd_dot(int first_front, int N, const i
   if (node_j < 0) return;
   const int lane = threadIdx.x & 63;
   const double* col = front + foff[f] + (int64_t)j * m;   // column j of the lower part = column j of [L11^-1; Z]
-  double acc = 0.0;
-  for (int i = j + lane; i < m; i += 64) acc += col[i] * sv[i];
-  acc = wave_sum(acc);
-  if (lane == 0) x[(int64_t)(j & 1) * N + node_j] = acc;
+  double acc[P];
+#pragma unroll
+  for (int u = 0; u < P; ++u) acc[u] = 0.0;
+  for (int i = j + lane; i < m; i += 64) {
+    const double a = col[i];
+#pragma unroll
+    for (int u = 0; u < P; ++u) acc[u] += a * sv[i * P + u];
+  }
+#pragma unroll
+  for (int u = 0; u < P; ++u) acc[u] = wave_sum(acc[u]);
+  if (lane == 0) {
+#pragma unroll
+    for (int u = 0; u < P; ++u) x[(int64_t)u * ldx + (int64_t)(j & 1) * N + node_j] = acc[u];
+  }
 }
 
 }  // namespace
@@ -633,43 +713,50 @@ void launch_factor(plfem_ctx* c, double sigma, int stop_level, int stop_step, in
   }
 }
 
-void launch_solve(plfem_ctx* c, const double* rhs, double* x) {
+template <int P>
+static void launch_solve_p(plfem_ctx* c, const double* rhs, double* x, int64_t ldx) {
   hipStream_t st = c->stream;
-  (void)hipMemsetAsync(x, 0, sizeof(double) * c->n2, st);
+  for (int u = 0; u < P; ++u) (void)hipMemsetAsync(x + (int64_t)u * ldx, 0, sizeof(double) * c->n2, st);
   constexpr int DOT_FORM_MAX_FRONTS = 32;   // levels with at most this many fronts use the dot-form kernels
   for (int lev = c->L; lev >= 0; --lev) {
     const LevelInfo& li = c->levels[lev];
     const int leaf = lev == c->L ? 1 : 0;
+    const size_t lds = sizeof(double) * P * (li.max_s2 + 1);
     if (li.count <= DOT_FORM_MAX_FRONTS)
-      hipLaunchKernelGGL(k_fwd_dot, dim3((li.max_m + 3) / 4, li.count), dim3(256), sizeof(double) * (li.max_s2 + 1), st,
-                         li.first, c->N, leaf, c->d_fs2, c->d_fm, c->d_foff, c->d_fnode_ptr, c->d_fnodes, c->d_cinv0,
-                         c->d_cinv1, c->d_front, c->d_delta, rhs, c->d_fvec, c->d_fvec2);
+      hipLaunchKernelGGL(k_fwd_dot<P>, dim3((li.max_m + 3) / 4, li.count), dim3(256), lds, st, li.first, c->N, ldx, leaf,
+                         c->d_fs2, c->d_fm, c->d_foff, c->d_fnode_ptr, c->d_fnodes, c->d_cinv0, c->d_cinv1, c->d_front,
+                         c->d_delta, rhs, c->d_fvec, c->d_fvec2);
     else
-      hipLaunchKernelGGL(k_fwd, dim3((li.max_m + 63) / 64, li.count), dim3(256), sizeof(double) * (li.max_s2 + 1), st,
-                         li.first, c->N, leaf, c->d_fs2, c->d_fm, c->d_foff, c->d_fnode_ptr, c->d_fnodes, c->d_cinv0,
-                         c->d_cinv1, c->d_front, c->d_delta, rhs, c->d_fvec, c->d_fvec2);
+      hipLaunchKernelGGL(k_fwd<P>, dim3((li.max_m + 63) / 64, li.count), dim3(256), lds, st, li.first, c->N, ldx, leaf,
+                         c->d_fs2, c->d_fm, c->d_foff, c->d_fnode_ptr, c->d_fnodes, c->d_cinv0, c->d_cinv1, c->d_front,
+                         c->d_delta, rhs, c->d_fvec, c->d_fvec2);
   }
   for (int lev = 0; lev <= c->L; ++lev) {
     const LevelInfo& li = c->levels[lev];
     if (li.max_s2 <= 0) continue;
+    const size_t lds = sizeof(double) * P * (li.max_m + 1);
     if (li.count <= DOT_FORM_MAX_FRONTS)
-      hipLaunchKernelGGL(k_bwd_dot, dim3((li.max_s2 + 3) / 4, li.count), dim3(256), sizeof(double) * (li.max_m + 1), st,
-                         li.first, c->N, c->d_fs2, c->d_fm, c->d_foff, c->d_fnode_ptr, c->d_fnodes, c->d_front,
-                         c->d_fvec2, x);
+      hipLaunchKernelGGL(k_bwd_dot<P>, dim3((li.max_s2 + 3) / 4, li.count), dim3(256), lds, st, li.first, c->N, ldx,
+                         c->d_fs2, c->d_fm, c->d_foff, c->d_fnode_ptr, c->d_fnodes, c->d_front, c->d_fvec2, x);
     else {
       // optional live timing of this kernel (bench.py roofline): HIP events on the launch stream
       const bool timed = c->prof_on && c->prof_n < (int)c->prof_ev.size() / 2;
       if (timed) (void)hipEventRecord(c->prof_ev[2 * c->prof_n], st);
-      hipLaunchKernelGGL(k_bwd, dim3((li.max_s2 + 63) / 64, li.count), dim3(256), sizeof(double) * (li.max_m + 1), st,
-                         li.first, c->N, c->d_fs2, c->d_fm, c->d_foff, c->d_fnode_ptr, c->d_fnodes, c->d_front,
-                         c->d_fvec2, x);
+      hipLaunchKernelGGL(k_bwd<P>, dim3((li.max_s2 + 63) / 64, li.count), dim3(256), lds, st, li.first, c->N, ldx,
+                         c->d_fs2, c->d_fm, c->d_foff, c->d_fnode_ptr, c->d_fnodes, c->d_front, c->d_fvec2, x);
       if (timed) {
         (void)hipEventRecord(c->prof_ev[2 * c->prof_n + 1], st);
-        c->prof_bytes += li.bwd_bytes;
+        c->prof_bytes += li.bwd_bytes + 8.0 * (P - 1) * li.bwd_vec_doubles;
         ++c->prof_n;
       }
     }
   }
+}
+
+void launch_solve(plfem_ctx* c, const double* rhs, double* x) { launch_solve_p<1>(c, rhs, x, c->n2); }
+
+void launch_solve_block(plfem_ctx* c, const double* rhs, double* x, int64_t ldx) {
+  launch_solve_p<BLOCK_P>(c, rhs, x, ldx);
 }
 
 }  // namespace plfem

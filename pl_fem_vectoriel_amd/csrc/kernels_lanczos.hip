@@ -78,6 +78,135 @@ __global__ __launch_bounds__(256) void k_axpby(int64_t n, double a, const double
   if (i < n) z[i] = a * x[i] + b * y[i];
 }
 
+// ---- block (P-vector) variants for block Lanczos --------------------------------------------------
+// partial[(c*P + q) * nchunks + chunk] = sum_{i in chunk} Pm[i, c] * W[i, q]: one wave per (chunk, column c)
+template <int P>
+__global__ __launch_bounds__(256) void k_panel_dot_p(int64_t n, int ncols, int nchunks, const double* __restrict__ Pm,
+                                                     const double* __restrict__ W, int64_t ldw,
+                                                     double* __restrict__ partial) {
+  const int c = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (c >= ncols) return;
+  const int lane = threadIdx.x & 63;
+  const int64_t i0 = (int64_t)blockIdx.x * CHUNK;
+  const int64_t i1 = min(n, i0 + CHUNK);
+  const double* col = Pm + (int64_t)c * n;
+  double acc[P];
+#pragma unroll
+  for (int q = 0; q < P; ++q) acc[q] = 0.0;
+  for (int64_t i = i0 + lane; i < i1; i += 64) {
+    const double a = col[i];
+#pragma unroll
+    for (int q = 0; q < P; ++q) acc[q] += a * W[(int64_t)q * ldw + i];
+  }
+#pragma unroll
+  for (int q = 0; q < P; ++q) {
+    double v = acc[q];
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+    if (lane == 0) partial[((int64_t)c * P + q) * nchunks + blockIdx.x] = v;
+  }
+}
+
+// h[c + q*ldh] = sum over chunks (one wave per (c, q), fixed order)
+__global__ __launch_bounds__(64) void k_panel_dot_finish_p(int P, int nchunks, const double* __restrict__ partial,
+                                                           double* __restrict__ h, int ldh) {
+  const int cq = blockIdx.x;          // c*P + q
+  const int c = cq / P, q = cq % P;
+  double acc = 0.0;
+  for (int t = threadIdx.x; t < nchunks; t += 64) acc += partial[(int64_t)cq * nchunks + t];
+  for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
+  if (threadIdx.x == 0) h[c + (int64_t)q * ldh] = acc;
+}
+
+// W[i, q] -= sum_c Pm[i, c] H[c + q*ldh]
+template <int P>
+__global__ __launch_bounds__(256) void k_panel_axpy_p(int64_t n, int ncols, const double* __restrict__ Pm,
+                                                      const double* __restrict__ H, int ldh, double* __restrict__ W,
+                                                      int64_t ldw) {
+  extern __shared__ double sh[];      // [c][P]
+  for (int k = threadIdx.x; k < ncols * P; k += 256) sh[k] = H[(k / P) + (int64_t)(k % P) * ldh];
+  __syncthreads();
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  double acc[P];
+#pragma unroll
+  for (int q = 0; q < P; ++q) acc[q] = 0.0;
+  for (int c = 0; c < ncols; ++c) {
+    const double a = Pm[(int64_t)c * n + i];
+#pragma unroll
+    for (int q = 0; q < P; ++q) acc[q] += a * sh[c * P + q];
+  }
+#pragma unroll
+  for (int q = 0; q < P; ++q) W[(int64_t)q * ldw + i] -= acc[q];
+}
+
+// acc[c + q*lda] += h[c + q*ldh]
+__global__ void k_mat_add(int ncols, int P, double* __restrict__ acc, int lda, const double* __restrict__ h, int ldh) {
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= ncols * P) return;
+  int c = t % ncols, q = t / ncols;
+  acc[c + (int64_t)q * lda] += h[c + (int64_t)q * ldh];
+}
+
+// Cholesky G = R^T R of the P x P Gram matrix of the new block (one lane), R into the projected matrix
+// (rows nc.., columns c0..), R^-1 for the block scaling.  A non-positive pivot (rank-deficient block:
+// the Krylov space is exhausted) raises counters[2].
+template <int P>
+__global__ void k_chol_small(const double* __restrict__ G, int ldg, double* __restrict__ Tblk, int ldT,
+                             double* __restrict__ Rinv, int32_t* __restrict__ counters) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double R[P][P], X[P][P];
+  for (int i = 0; i < P; ++i)
+    for (int j = 0; j < P; ++j) { R[i][j] = 0.0; X[i][j] = 0.0; }
+  for (int j = 0; j < P; ++j) {
+    for (int i = 0; i <= j; ++i) {
+      double v = 0.5 * (G[i + (int64_t)j * ldg] + G[j + (int64_t)i * ldg]);
+      for (int k = 0; k < i; ++k) v -= R[k][i] * R[k][j];
+      if (i == j) {
+        if (!(v > 0.0)) { atomicAdd(&counters[2], 1); v = 1.0; }
+        R[j][j] = sqrt(v);
+      } else {
+        R[i][j] = v / R[i][i];
+      }
+    }
+  }
+  for (int j = 0; j < P; ++j) {           // X = R^-1 (upper), column by column
+    X[j][j] = 1.0 / R[j][j];
+    for (int i = j - 1; i >= 0; --i) {
+      double v = 0.0;
+      for (int k = i + 1; k <= j; ++k) v -= R[i][k] * X[k][j];
+      X[i][j] = v / R[i][i];
+    }
+  }
+  for (int i = 0; i < P; ++i)
+    for (int j = 0; j < P; ++j) {
+      Tblk[i + (int64_t)j * ldT] = R[i][j];
+      Rinv[i + j * P] = X[i][j];
+    }
+}
+
+// Vn = W R^-1, BVn = BW R^-1 (R^-1 upper triangular)
+template <int P>
+__global__ __launch_bounds__(256) void k_block_scale(int64_t n, const double* __restrict__ W, const double* __restrict__ BW,
+                                                     int64_t ldw, const double* __restrict__ Rinv,
+                                                     double* __restrict__ Vn, double* __restrict__ BVn, int64_t ldv) {
+  __shared__ double X[P * P];
+  if (threadIdx.x < P * P) X[threadIdx.x] = Rinv[threadIdx.x];
+  __syncthreads();
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  double w[P], bw[P];
+#pragma unroll
+  for (int q = 0; q < P; ++q) { w[q] = W[(int64_t)q * ldw + i]; bw[q] = BW[(int64_t)q * ldw + i]; }
+#pragma unroll
+  for (int q = 0; q < P; ++q) {
+    double a = 0.0, b = 0.0;
+#pragma unroll
+    for (int k = 0; k <= q; ++k) { a += w[k] * X[k + q * P]; b += bw[k] * X[k + q * P]; }
+    Vn[(int64_t)q * ldv + i] = a;
+    BVn[(int64_t)q * ldv + i] = b;
+  }
+}
+
 // Ritz rotation out[:, 0:p] = V[:, 0:m] S[0:m, 0:p] on the matrix cores: one wave per 16 rows,
 // v_mfma_f64_16x16x4_f64 tiles (A <- V rows, B <- S), S staged in LDS.  m, p <= 144.
 __global__ __launch_bounds__(256) void k_rotate(int64_t n, int m, int p, const double* __restrict__ V,
@@ -236,6 +365,35 @@ void launch_scale_store(plfem_ctx* c, const double* w, const double* bw, const d
 
 void launch_axpby(plfem_ctx* c, double a, const double* x, double b, const double* y, double* z) {
   hipLaunchKernelGGL(k_axpby, dim3((unsigned)((c->n2 + 255) / 256)), dim3(256), 0, c->stream, c->n2, a, x, b, y, z);
+}
+
+void launch_panel_dot_block(plfem_ctx* c, const double* Pm, int ncols, const double* W, int64_t ldw, double* h, int ldh) {
+  constexpr int P = BLOCK_P;
+  const int nchunks = c->npartial;
+  hipLaunchKernelGGL(k_panel_dot_p<P>, dim3(nchunks, (ncols + 3) / 4), dim3(256), 0, c->stream, c->n2, ncols, nchunks,
+                     Pm, W, ldw, c->d_partial);
+  hipLaunchKernelGGL(k_panel_dot_finish_p, dim3(ncols * P), dim3(64), 0, c->stream, P, nchunks, c->d_partial, h, ldh);
+}
+
+void launch_panel_axpy_block(plfem_ctx* c, const double* Pm, int ncols, const double* H, int ldh, double* W, int64_t ldw) {
+  constexpr int P = BLOCK_P;
+  hipLaunchKernelGGL(k_panel_axpy_p<P>, dim3((unsigned)((c->n2 + 255) / 256)), dim3(256), sizeof(double) * ncols * P,
+                     c->stream, c->n2, ncols, Pm, H, ldh, W, ldw);
+}
+
+void launch_mat_add(plfem_ctx* c, int ncols, double* acc, int lda, const double* h, int ldh) {
+  const int n = ncols * BLOCK_P;
+  hipLaunchKernelGGL(k_mat_add, dim3((n + 255) / 256), dim3(256), 0, c->stream, ncols, BLOCK_P, acc, lda, h, ldh);
+}
+
+void launch_chol_block(plfem_ctx* c, const double* G, int ldg, double* Tblk, int ldT, double* Rinv) {
+  hipLaunchKernelGGL(k_chol_small<BLOCK_P>, dim3(1), dim3(64), 0, c->stream, G, ldg, Tblk, ldT, Rinv, c->d_counters);
+}
+
+void launch_block_scale(plfem_ctx* c, const double* W, const double* BW, int64_t ldw, const double* Rinv, double* Vn,
+                        double* BVn, int64_t ldv) {
+  hipLaunchKernelGGL(k_block_scale<BLOCK_P>, dim3((unsigned)((c->n2 + 255) / 256)), dim3(256), 0, c->stream, c->n2, W,
+                     BW, ldw, Rinv, Vn, BVn, ldv);
 }
 
 void launch_rotate(plfem_ctx* c, const double* V, int m, const double* Smat, int ldS, int p, double* out) {
