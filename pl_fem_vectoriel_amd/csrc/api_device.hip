@@ -395,10 +395,10 @@ static int lanczos_block(plfem_ctx* c, int k, int ncv, double tol, int maxiter, 
         }
     HIP_TRY(c, hipMemcpyAsync(c->d_V2, v0.data(), sizeof(double) * n * P, hipMemcpyHostToDevice, st));
     HIP_TRY(c, hipStreamSynchronize(st));
-    for (int q = 0; q < P; ++q) plfem::launch_spmv(c, 1, c->d_V2 + (size_t)q * n, c->d_bw + (size_t)q * n);
+    plfem::launch_spmv_b_block(c, c->d_V2, c->d_bw, n);
     plfem::launch_solve_block(c, c->d_bw, c->d_w, n);
     nop += P; ++nblock;
-    for (int q = 0; q < P; ++q) plfem::launch_spmv(c, 1, c->d_w + (size_t)q * n, c->d_bw + (size_t)q * n);
+    plfem::launch_spmv_b_block(c, c->d_w, c->d_bw, n);
     plfem::launch_panel_dot_block(c, c->d_w, P, c->d_bw, n, c->d_G, P);
     plfem::launch_chol_block(c, c->d_G, P, c->d_hblk, P, c->d_Rinv);      // R itself is not needed for the start block
     plfem::launch_block_scale(c, c->d_w, c->d_bw, n, c->d_Rinv, c->d_V, c->d_BV, n);
@@ -424,7 +424,7 @@ static int lanczos_block(plfem_ctx* c, int k, int ncv, double tol, int maxiter, 
       plfem::launch_panel_dot_block(c, c->d_BV, nc, c->d_w, n, c->d_hblk, ld);  // CGS2 second pass
       plfem::launch_panel_axpy_block(c, c->d_V, nc, c->d_hblk, ld, c->d_w, n);
       plfem::launch_mat_add(c, nc, Hblk, ld, c->d_hblk, ld);
-      for (int q = 0; q < P; ++q) plfem::launch_spmv(c, 1, c->d_w + (size_t)q * n, c->d_bw + (size_t)q * n);
+      plfem::launch_spmv_b_block(c, c->d_w, c->d_bw, n);
       plfem::launch_panel_dot_block(c, c->d_w, P, c->d_bw, n, c->d_G, P);       // Gram matrix W^T B W
       plfem::launch_chol_block(c, c->d_G, P, Hblk + nc, ld, c->d_Rinv);         // R -> T[nc:nc+P, c0:c0+P]
       plfem::launch_block_scale(c, c->d_w, c->d_bw, n, c->d_Rinv, c->d_V + (size_t)nc * n, c->d_BV + (size_t)nc * n, n);

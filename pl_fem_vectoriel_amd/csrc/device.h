@@ -93,6 +93,7 @@ namespace plfem {
 void launch_element_matrices(plfem_ctx* c, int ncore, double eps_core, double eps_clad, double k0, double alpha_p);
 void launch_csr_gather(plfem_ctx* c);
 void launch_spmv(plfem_ctx* c, int which, const double* x, double* y);
+void launch_spmv_b_block(plfem_ctx* c, const double* x, double* y, int64_t ld);   // y_q = B x_q, BLOCK_P vectors
 // kernels_front.hip
 void launch_factor(plfem_ctx* c, double sigma, int stop_level = -1, int stop_step = 0, int stop_stage = 0);
 void launch_solve(plfem_ctx* c, const double* rhs, double* x);

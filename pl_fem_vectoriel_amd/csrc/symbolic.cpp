@@ -6,7 +6,9 @@
 #include <cmath>
 #include <cstring>
 #include <functional>
+#include <memory>
 #include <numeric>
+#include <atomic>
 #include <thread>
 
 namespace plfem {
@@ -17,21 +19,57 @@ inline double secs(clk::time_point a, clk::time_point b) {
   return std::chrono::duration<double>(b - a).count();
 }
 
-// run f(begin, end, tid) over [0, n) on nthreads threads (static chunks)
+// Small spin-waiting worker pool, alive for the duration of one build_symbolic() call: the parallel
+// regions of the analysis are ~0.1-3 ms each, far too short to pay a thread creation per region.
+struct Pool {
+  int nt;
+  std::vector<std::thread> th;
+  std::atomic<int> gen{0}, done{0};
+  std::atomic<bool> stop{false};
+  std::function<void(int)> job;
+  explicit Pool(int n) : nt(n) {
+    for (int t = 1; t < nt; ++t)
+      th.emplace_back([this, t] {
+        int seen = 0;
+        while (true) {
+          while (gen.load(std::memory_order_acquire) == seen) {
+            if (stop.load(std::memory_order_acquire)) return;
+            std::this_thread::yield();
+          }
+          seen = gen.load(std::memory_order_acquire);
+          job(t);
+          done.fetch_add(1, std::memory_order_release);
+        }
+      });
+  }
+  void run(const std::function<void(int)>& f) {
+    job = f;
+    done.store(0, std::memory_order_release);
+    gen.fetch_add(1, std::memory_order_release);
+    f(0);
+    while (done.load(std::memory_order_acquire) < nt - 1) std::this_thread::yield();
+  }
+  ~Pool() {
+    stop.store(true, std::memory_order_release);
+    for (auto& x : th) x.join();
+  }
+};
+thread_local Pool* g_pool = nullptr;
+
+// run f(begin, end, tid) over [0, n) in static chunks on the pool of the current build (if any)
 template <class F>
 void parallel_for(int64_t n, int nthreads, F f, int64_t min_parallel = 4096) {
-  if (nthreads <= 1 || n < min_parallel) {
+  Pool* pool = g_pool;
+  if (nthreads <= 1 || n < min_parallel || !pool) {
     f((int64_t)0, n, 0);
     return;
   }
-  std::vector<std::thread> th;
-  int64_t chunk = (n + nthreads - 1) / nthreads;
-  for (int tdx = 0; tdx < nthreads; ++tdx) {
+  const int nt = pool->nt;
+  const int64_t chunk = (n + nt - 1) / nt;
+  pool->run([&](int tdx) {
     int64_t b = tdx * chunk, e = std::min(n, b + chunk);
-    if (b >= e) break;
-    th.emplace_back([=] { f(b, e, tdx); });
-  }
-  for (auto& x : th) x.join();
+    if (b < e) f(b, e, tdx);
+  });
 }
 
 inline int pad8(int x) { return (x + 7) & ~7; }
@@ -458,6 +496,10 @@ std::string build_symbolic(int nv, int ne, const double* p, const int32_t* t, in
   if (nv < 3 || ne < 1) return "empty mesh";
   if (leaf_elems < 1) leaf_elems = 16;
   if (nthreads < 1) nthreads = 1;
+  std::unique_ptr<Pool> pool;
+  if (nthreads > 1) pool.reset(new Pool(nthreads));
+  g_pool = pool.get();
+  struct Reset { ~Reset() { g_pool = nullptr; } } reset_guard;
   auto t0 = clk::now();
   std::string err = p2_numbering(nv, ne, p, t, S);
   if (!err.empty()) return err;
