@@ -416,6 +416,13 @@ __global__ __launch_bounds__(256) void k_mirror_z(int first_front, const int32_t
 // output, reduction across the lanes.  Both read contiguous runs of F thanks to the mirrored storage.
 // Global vectors: column q of rhs / x at offset q*ldx.  Per-front vectors: [dof][P] interleaved.
 // ------------------------------------------------------------------------------------------------
+// global vector element (dof index i, right-hand side u): ldx > 0 -> separate columns (u*ldx + i),
+// ldx == 0 -> interleaved [i][P] (the block solve: P values of a DOF in one 32-B run)
+template <int P>
+__device__ __forceinline__ int64_t vidx(int64_t i, int u, int64_t ldx) {
+  return ldx ? (int64_t)u * ldx + i : i * P + u;
+}
+
 __device__ __forceinline__ double wave_sum(double v) {
   for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
   return v;
@@ -434,7 +441,7 @@ __device__ __forceinline__ void gather_rhs(double (&v)[P], int f, int i, int s2,
   for (int u = 0; u < P; ++u) v[u] = 0.0;
   if (i < s2 && node >= 0) {
 #pragma unroll
-    for (int u = 0; u < P; ++u) v[u] = rhs[(int64_t)u * ldx + (int64_t)c * N + node];
+    for (int u = 0; u < P; ++u) v[u] = rhs[vidx<P>((int64_t)c * N + node, u, ldx)];
   }
   if (!leaf_level) {
     int c0 = cinv0[np + q], c1 = cinv1[np + q];
@@ -453,7 +460,7 @@ __device__ __forceinline__ void gather_rhs(double (&v)[P], int f, int i, int s2,
   }
 }
 
-template <int P>
+template <int P, int NW>
 __device__ __forceinline__ void tile_sum(double (&out)[P], const double* __restrict__ p, int64_t ld, bool valid,
                                          int cb, int ce, const double* __restrict__ v, double* __restrict__ red) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -461,18 +468,18 @@ __device__ __forceinline__ void tile_sum(double (&out)[P], const double* __restr
 #pragma unroll
   for (int u = 0; u < P; ++u) acc[u] = 0.0;
   if (valid) {
-    int c = cb + ((wave - cb) & 3);       // this wave's columns: c == wave (mod 4); 8 loads in flight per lane
-    for (; c + 28 < ce; c += 32) {
+    int c = cb + ((wave - cb) & (NW - 1));   // this wave's columns: c == wave (mod NW); 8 loads in flight per lane
+    for (; c + 7 * NW < ce; c += 8 * NW) {
       double a[8];
 #pragma unroll
-      for (int t = 0; t < 8; ++t) a[t] = p[(int64_t)(c + 4 * t) * ld];
+      for (int t = 0; t < 8; ++t) a[t] = p[(int64_t)(c + NW * t) * ld];
 #pragma unroll
       for (int t = 0; t < 8; ++t) {
 #pragma unroll
-        for (int u = 0; u < P; ++u) acc[u] += a[t] * v[(c + 4 * t) * P + u];
+        for (int u = 0; u < P; ++u) acc[u] += a[t] * v[(c + NW * t) * P + u];
       }
     }
-    for (; c < ce; c += 4) {
+    for (; c < ce; c += NW) {
       const double a = p[(int64_t)c * ld];
 #pragma unroll
       for (int u = 0; u < P; ++u) acc[u] += a * v[c * P + u];
@@ -482,13 +489,16 @@ __device__ __forceinline__ void tile_sum(double (&out)[P], const double* __restr
   for (int u = 0; u < P; ++u) red[(wave * P + u) * 64 + lane] = acc[u];
   __syncthreads();
 #pragma unroll
-  for (int u = 0; u < P; ++u)
-    out[u] = red[(0 * P + u) * 64 + lane] + red[(1 * P + u) * 64 + lane] + red[(2 * P + u) * 64 + lane] +
-             red[(3 * P + u) * 64 + lane];
+  for (int u = 0; u < P; ++u) {
+    double t = 0.0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) t += red[(w * P + u) * 64 + lane];
+    out[u] = t;
+  }
 }
 
-template <int P>
-__global__ __launch_bounds__(256) void k_fwd(int first_front, int N, int64_t ldx, int leaf_level,
+template <int P, int NW>
+__global__ __launch_bounds__(NW * 64) void k_fwd(int first_front, int N, int64_t ldx, int leaf_level,
                                              const int32_t* __restrict__ fs2, const int32_t* __restrict__ fm,
                                              const int64_t* __restrict__ foff, const int64_t* __restrict__ fnode_ptr,
                                              const int32_t* __restrict__ fnodes, const int32_t* __restrict__ cinv0,
@@ -496,13 +506,13 @@ __global__ __launch_bounds__(256) void k_fwd(int first_front, int N, int64_t ldx
                                              const double* __restrict__ delta, const double* __restrict__ rhs,
                                              double* __restrict__ fvec, double* __restrict__ fvec2) {
   extern __shared__ double sv[];
-  __shared__ double red[4 * P * 64];
+  __shared__ double red[NW * P * 64];
   const int f = first_front + blockIdx.y;
   const int m = fm[f], s2 = fs2[f];
   const int r0 = blockIdx.x * 64;
   if (r0 >= m) return;
   const int64_t np = fnode_ptr[f];
-  for (int i = threadIdx.x; i < s2; i += 256) {
+  for (int i = threadIdx.x; i < s2; i += NW * 64) {
     double v[P];
     gather_rhs<P>(v, f, i, s2, N, ldx, leaf_level, np, fs2, fnode_ptr, fnodes, cinv0, cinv1, rhs, fvec);
 #pragma unroll
@@ -513,7 +523,7 @@ __global__ __launch_bounds__(256) void k_fwd(int first_front, int N, int64_t ldx
   const bool valid = r < m;
   const int ce = (r < s2) ? r + 1 : s2;               // rows of L11^-1 are lower triangular
   double acc[P];
-  tile_sum<P>(acc, front + foff[f] + r, m, valid, 0, ce, sv, red);
+  tile_sum<P, NW>(acc, front + foff[f] + r, m, valid, 0, ce, sv, red);
   if (threadIdx.x < 64 && valid) {
     if (r < s2) {
       const double di = 1.0 / delta[2 * np + r];
@@ -583,7 +593,7 @@ template <int P>
 __device__ __forceinline__ void stage_bwd(double* sv, int lo, int m, int s2, int N, int64_t ldx, int64_t np,
                                           const int32_t* __restrict__ fnodes, const double* __restrict__ fvec2,
                                           const double* __restrict__ x) {
-  for (int i = lo + threadIdx.x; i < m; i += 256) {
+  for (int i = lo + threadIdx.x; i < m; i += blockDim.x) {
     if (i < s2) {
 #pragma unroll
       for (int u = 0; u < P; ++u) sv[i * P + u] = fvec2[(2 * np + i) * P + u];
@@ -591,19 +601,19 @@ __device__ __forceinline__ void stage_bwd(double* sv, int lo, int m, int s2, int
       const int node = fnodes[np + (i >> 1)];
 #pragma unroll
       for (int u = 0; u < P; ++u)
-        sv[i * P + u] = node >= 0 ? -x[(int64_t)u * ldx + (int64_t)(i & 1) * N + node] : 0.0;
+        sv[i * P + u] = node >= 0 ? -x[vidx<P>((int64_t)(i & 1) * N + node, u, ldx)] : 0.0;
     }
   }
 }
 
-template <int P>
-__global__ __launch_bounds__(256) void k_bwd(int first_front, int N, int64_t ldx, const int32_t* __restrict__ fs2,
+template <int P, int NW>
+__global__ __launch_bounds__(NW * 64) void k_bwd(int first_front, int N, int64_t ldx, const int32_t* __restrict__ fs2,
                                              const int32_t* __restrict__ fm, const int64_t* __restrict__ foff,
                                              const int64_t* __restrict__ fnode_ptr, const int32_t* __restrict__ fnodes,
                                              const double* __restrict__ front, const double* __restrict__ fvec2,
                                              double* __restrict__ x) {
   extern __shared__ double sv[];
-  __shared__ double red[4 * P * 64];
+  __shared__ double red[NW * P * 64];
   const int f = first_front + blockIdx.y;
   const int m = fm[f], s2 = fs2[f];
   const int r0 = blockIdx.x * 64;
@@ -615,12 +625,12 @@ __global__ __launch_bounds__(256) void k_bwd(int first_front, int N, int64_t ldx
   const bool valid = r < s2;
   // element (j = r, i) of [L11^-T | Z^T] at F[r + i m], i in [r, m)
   double acc[P];
-  tile_sum<P>(acc, front + foff[f] + r, m, valid, r, m, sv, red);
+  tile_sum<P, NW>(acc, front + foff[f] + r, m, valid, r, m, sv, red);
   if (threadIdx.x < 64 && valid) {
     const int node = fnodes[np + (r >> 1)];
     if (node >= 0) {
 #pragma unroll
-      for (int u = 0; u < P; ++u) x[(int64_t)u * ldx + (int64_t)(r & 1) * N + node] = acc[u];
+      for (int u = 0; u < P; ++u) x[vidx<P>((int64_t)(r & 1) * N + node, u, ldx)] = acc[u];
     }
   }
 }
@@ -657,8 +667,27 @@ __global__ __launch_bounds__(256) void k_bwd_dot(int first_front, int N, int64_t
   for (int u = 0; u < P; ++u) acc[u] = wave_sum(acc[u]);
   if (lane == 0) {
 #pragma unroll
-    for (int u = 0; u < P; ++u) x[(int64_t)u * ldx + (int64_t)(j & 1) * N + node_j] = acc[u];
+    for (int u = 0; u < P; ++u) x[vidx<P>((int64_t)(j & 1) * N + node_j, u, ldx)] = acc[u];
   }
+}
+
+// columns (ld) -> interleaved [i][P] and back
+template <int P>
+__global__ __launch_bounds__(256) void k_interleave(int64_t n, const double* __restrict__ cols, int64_t ld,
+                                                    double* __restrict__ il) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+#pragma unroll
+  for (int u = 0; u < P; ++u) il[i * P + u] = cols[(int64_t)u * ld + i];
+}
+
+template <int P>
+__global__ __launch_bounds__(256) void k_deinterleave(int64_t n, const double* __restrict__ il, double* __restrict__ cols,
+                                                      int64_t ld) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+#pragma unroll
+  for (int u = 0; u < P; ++u) cols[(int64_t)u * ld + i] = il[i * P + u];
 }
 
 }  // namespace
@@ -716,8 +745,11 @@ void launch_factor(plfem_ctx* c, double sigma, int stop_level, int stop_step, in
 template <int P>
 static void launch_solve_p(plfem_ctx* c, const double* rhs, double* x, int64_t ldx) {
   hipStream_t st = c->stream;
-  for (int u = 0; u < P; ++u) (void)hipMemsetAsync(x + (int64_t)u * ldx, 0, sizeof(double) * c->n2, st);
+  if (ldx == 0) (void)hipMemsetAsync(x, 0, sizeof(double) * c->n2 * P, st);
+  else
+    for (int u = 0; u < P; ++u) (void)hipMemsetAsync(x + (int64_t)u * ldx, 0, sizeof(double) * c->n2, st);
   constexpr int DOT_FORM_MAX_FRONTS = 32;   // levels with at most this many fronts use the dot-form kernels
+  constexpr int NW = (P == 1) ? 4 : 8;      // waves per tile-form block: the P-fold LDS vector serves more waves
   for (int lev = c->L; lev >= 0; --lev) {
     const LevelInfo& li = c->levels[lev];
     const int leaf = lev == c->L ? 1 : 0;
@@ -727,7 +759,7 @@ static void launch_solve_p(plfem_ctx* c, const double* rhs, double* x, int64_t l
                          c->d_fs2, c->d_fm, c->d_foff, c->d_fnode_ptr, c->d_fnodes, c->d_cinv0, c->d_cinv1, c->d_front,
                          c->d_delta, rhs, c->d_fvec, c->d_fvec2);
     else
-      hipLaunchKernelGGL(k_fwd<P>, dim3((li.max_m + 63) / 64, li.count), dim3(256), lds, st, li.first, c->N, ldx, leaf,
+      hipLaunchKernelGGL((k_fwd<P, NW>), dim3((li.max_m + 63) / 64, li.count), dim3(NW * 64), lds, st, li.first, c->N, ldx, leaf,
                          c->d_fs2, c->d_fm, c->d_foff, c->d_fnode_ptr, c->d_fnodes, c->d_cinv0, c->d_cinv1, c->d_front,
                          c->d_delta, rhs, c->d_fvec, c->d_fvec2);
   }
@@ -742,7 +774,7 @@ static void launch_solve_p(plfem_ctx* c, const double* rhs, double* x, int64_t l
       // optional live timing of this kernel (bench.py roofline): HIP events on the launch stream
       const bool timed = c->prof_on && c->prof_n < (int)c->prof_ev.size() / 2;
       if (timed) (void)hipEventRecord(c->prof_ev[2 * c->prof_n], st);
-      hipLaunchKernelGGL(k_bwd<P>, dim3((li.max_s2 + 63) / 64, li.count), dim3(256), lds, st, li.first, c->N, ldx,
+      hipLaunchKernelGGL((k_bwd<P, NW>), dim3((li.max_s2 + 63) / 64, li.count), dim3(NW * 64), lds, st, li.first, c->N, ldx,
                          c->d_fs2, c->d_fm, c->d_foff, c->d_fnode_ptr, c->d_fnodes, c->d_front, c->d_fvec2, x);
       if (timed) {
         (void)hipEventRecord(c->prof_ev[2 * c->prof_n + 1], st);
@@ -755,8 +787,13 @@ static void launch_solve_p(plfem_ctx* c, const double* rhs, double* x, int64_t l
 
 void launch_solve(plfem_ctx* c, const double* rhs, double* x) { launch_solve_p<1>(c, rhs, x, c->n2); }
 
+// BLOCK_P right-hand sides given as columns (ldx apart): interleaved inside the sweeps so that the P
+// values of a DOF are one 32-byte access (t1/t2 scratch: n2 x BLOCK_P each)
 void launch_solve_block(plfem_ctx* c, const double* rhs, double* x, int64_t ldx) {
-  launch_solve_p<BLOCK_P>(c, rhs, x, ldx);
+  const unsigned grid = (unsigned)((c->n2 + 255) / 256);
+  hipLaunchKernelGGL(k_interleave<BLOCK_P>, dim3(grid), dim3(256), 0, c->stream, c->n2, rhs, ldx, c->d_t1);
+  launch_solve_p<BLOCK_P>(c, c->d_t1, c->d_t2, 0);
+  hipLaunchKernelGGL(k_deinterleave<BLOCK_P>, dim3(grid), dim3(256), 0, c->stream, c->n2, c->d_t2, x, ldx);
 }
 
 }  // namespace plfem
