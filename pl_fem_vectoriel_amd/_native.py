@@ -119,7 +119,9 @@ class Symbolic:
         h = ctypes.c_void_p()
         err = ctypes.create_string_buffer(512)
         if nthreads <= 0:
-            nthreads = min(os.cpu_count() or 1, 8)
+            nthreads = int(os.environ.get("PLFEM_HOST_THREADS", min(os.cpu_count() or 1, 8)))
+        if leaf_elems <= 0:
+            leaf_elems = int(os.environ.get("PLFEM_LEAF_ELEMS", 0))
         rc = lib.plfem_symbolic_create(p.shape[1], t.shape[1], _ptr(p), _ptr(t), int(leaf_elems), int(nthreads),
                                        ctypes.byref(h), err, 512)
         if rc != PLFEM_OK:

@@ -63,47 +63,112 @@ int check_launch(plfem_ctx* c, const char* what) {
   return PLFEM_OK;
 }
 
-// cyclic Jacobi eigen-decomposition of a small dense symmetric matrix (n <= ~130).
-// A: n x n column major (destroyed), V: eigenvectors in columns, w: eigenvalues.
-void jacobi_eigh(int n, std::vector<double>& A, std::vector<double>& V, std::vector<double>& w) {
-  V.assign((size_t)n * n, 0.0);
-  for (int i = 0; i < n; ++i) V[(size_t)i * n + i] = 1.0;
-  auto a = [&](int i, int j) -> double& { return A[(size_t)j * n + i]; };
-  auto v = [&](int i, int j) -> double& { return V[(size_t)j * n + i]; };
-  for (int sweep = 0; sweep < 60; ++sweep) {
-    double off = 0.0, diag = 0.0;
-    for (int j = 0; j < n; ++j) {
-      diag += a(j, j) * a(j, j);
-      for (int i = 0; i < j; ++i) off += a(i, j) * a(i, j);
-    }
-    if (off <= 1e-34 * (diag + off) || off == 0.0) break;
-    for (int p = 0; p < n - 1; ++p)
-      for (int q = p + 1; q < n; ++q) {
-        double apq = a(p, q);
-        if (apq == 0.0) continue;
-        double app = a(p, p), aqq = a(q, q);
-        double tau = (aqq - app) / (2.0 * apq);
-        double t = (tau >= 0 ? 1.0 : -1.0) / (std::fabs(tau) + std::sqrt(1.0 + tau * tau));
-        double cs = 1.0 / std::sqrt(1.0 + t * t), sn = t * cs;
-        for (int k = 0; k < n; ++k) {
-          double akp = a(k, p), akq = a(k, q);
-          a(k, p) = cs * akp - sn * akq;
-          a(k, q) = sn * akp + cs * akq;
+// Dense symmetric eigen-decomposition: Householder tridiagonalisation + implicit-shift QL
+// (the classical EISPACK tred2 / tql2 pair).  A: n x n column major (destroyed), V: eigenvectors in
+// columns, w: eigenvalues (unordered).
+void tridiag_eigh(int n, std::vector<double>& A, std::vector<double>& V, std::vector<double>& w) {
+  std::vector<double> e(n, 0.0);
+  w.assign(n, 0.0);
+  V = A;   // work in V, row-major view z[i][j] = V[i*n + j] (A symmetric: layout irrelevant on entry)
+  auto z = [&](int i, int j) -> double& { return V[(size_t)i * n + j]; };
+  // ---- tred2: reduce to tridiagonal form, accumulate the transformation in z
+  for (int i = n - 1; i > 0; --i) {
+    int l = i - 1;
+    double h = 0.0, scale = 0.0;
+    if (l > 0) {
+      for (int k = 0; k <= l; ++k) scale += std::fabs(z(i, k));
+      if (scale == 0.0) {
+        e[i] = z(i, l);
+      } else {
+        for (int k = 0; k <= l; ++k) { z(i, k) /= scale; h += z(i, k) * z(i, k); }
+        double f = z(i, l);
+        double g = (f >= 0.0) ? -std::sqrt(h) : std::sqrt(h);
+        e[i] = scale * g;
+        h -= f * g;
+        z(i, l) = f - g;
+        f = 0.0;
+        for (int j = 0; j <= l; ++j) {
+          z(j, i) = z(i, j) / h;
+          g = 0.0;
+          for (int k = 0; k <= j; ++k) g += z(j, k) * z(i, k);
+          for (int k = j + 1; k <= l; ++k) g += z(k, j) * z(i, k);
+          e[j] = g / h;
+          f += e[j] * z(i, j);
         }
-        for (int k = 0; k < n; ++k) {
-          double apk = a(p, k), aqk = a(q, k);
-          a(p, k) = cs * apk - sn * aqk;
-          a(q, k) = sn * apk + cs * aqk;
-        }
-        for (int k = 0; k < n; ++k) {
-          double vkp = v(k, p), vkq = v(k, q);
-          v(k, p) = cs * vkp - sn * vkq;
-          v(k, q) = sn * vkp + cs * vkq;
+        double hh = f / (h + h);
+        for (int j = 0; j <= l; ++j) {
+          f = z(i, j);
+          e[j] = g = e[j] - hh * f;
+          for (int k = 0; k <= j; ++k) z(j, k) -= (f * e[k] + g * z(i, k));
         }
       }
+    } else {
+      e[i] = z(i, l);
+    }
+    w[i] = h;
   }
-  w.resize(n);
-  for (int i = 0; i < n; ++i) w[i] = a(i, i);
+  w[0] = 0.0;
+  e[0] = 0.0;
+  for (int i = 0; i < n; ++i) {
+    int l = i - 1;
+    if (w[i] != 0.0) {
+      for (int j = 0; j <= l; ++j) {
+        double g = 0.0;
+        for (int k = 0; k <= l; ++k) g += z(i, k) * z(k, j);
+        for (int k = 0; k <= l; ++k) z(k, j) -= g * z(k, i);
+      }
+    }
+    w[i] = z(i, i);
+    z(i, i) = 1.0;
+    for (int j = 0; j <= l; ++j) z(j, i) = z(i, j) = 0.0;
+  }
+  // ---- tql2: eigenvalues / vectors of the tridiagonal matrix (d = w, e), rotations applied to z
+  for (int i = 1; i < n; ++i) e[i - 1] = e[i];
+  e[n - 1] = 0.0;
+  for (int l = 0; l < n; ++l) {
+    int iter = 0, m;
+    do {
+      for (m = l; m < n - 1; ++m) {
+        double dd = std::fabs(w[m]) + std::fabs(w[m + 1]);
+        if (std::fabs(e[m]) <= 2.3e-16 * dd) break;
+      }
+      if (m != l) {
+        if (iter++ == 120) break;   // no convergence: leave the current approximation
+        double g = (w[l + 1] - w[l]) / (2.0 * e[l]);
+        double r = std::hypot(g, 1.0);
+        g = w[m] - w[l] + e[l] / (g + (g >= 0.0 ? std::fabs(r) : -std::fabs(r)));
+        double s = 1.0, c = 1.0, p = 0.0;
+        int i;
+        for (i = m - 1; i >= l; --i) {
+          double f = s * e[i], b = c * e[i];
+          e[i + 1] = (r = std::hypot(f, g));
+          if (r == 0.0) {
+            w[i + 1] -= p;
+            e[m] = 0.0;
+            break;
+          }
+          s = f / r;
+          c = g / r;
+          g = w[i + 1] - p;
+          r = (w[i] - g) * s + 2.0 * c * b;
+          w[i + 1] = g + (p = s * r);
+          g = c * r - b;
+          for (int k = 0; k < n; ++k) {
+            f = z(k, i + 1);
+            z(k, i + 1) = s * z(k, i) + c * f;
+            z(k, i) = c * z(k, i) - s * f;
+          }
+        }
+        if (r == 0.0 && i >= l) continue;
+        w[l] -= p;
+        e[l] = g;
+        e[m] = 0.0;
+      }
+    } while (m != l);
+  }
+  // z(k, i) = component k of eigenvector i  ->  column-major V: V[i*n + k]; currently V[k*n + i]: transpose
+  for (int i = 0; i < n; ++i)
+    for (int k = i + 1; k < n; ++k) std::swap(V[(size_t)i * n + k], V[(size_t)k * n + i]);
 }
 
 void free_all(plfem_ctx* c) {
@@ -448,7 +513,7 @@ static int lanczos_block(plfem_ctx* c, int k, int ncv, double tol, int maxiter, 
         Tm[(size_t)j * mm + i] = v;
         Tm[(size_t)i * mm + j] = v;
       }
-    jacobi_eigh(mm, Tm, Svec, theta);
+    tridiag_eigh(mm, Tm, Svec, theta);
     order.resize(mm);
     std::iota(order.begin(), order.end(), 0);
     std::sort(order.begin(), order.end(), [&](int a, int b) { return std::fabs(theta[a]) > std::fabs(theta[b]); });
@@ -607,7 +672,7 @@ extern "C" int plfem_lanczos_shift_invert(plfem_ctx* c, int32_t k, int32_t ncv, 
         Tm[(size_t)j * m + i] = v;
         Tm[(size_t)i * m + j] = v;
       }
-    jacobi_eigh(m, Tm, Svec, theta);
+    tridiag_eigh(m, Tm, Svec, theta);
     order.resize(m);
     std::iota(order.begin(), order.end(), 0);
     std::sort(order.begin(), order.end(), [&](int a, int b) { return std::fabs(theta[a]) > std::fabs(theta[b]); });
