@@ -443,7 +443,8 @@ static int lanczos_block(plfem_ctx* c, int k, int ncv, double tol, int maxiter, 
   const int64_t n = c->n2;
   hipStream_t st = c->stream;
   HIP_TRY(c, hipEventRecord(c->ev[2][0], st));
-  const int m = std::min(c->max_ncv, ((ncv + P - 1) / P) * P);   // basis columns before the residual block
+  int m = ((ncv + P - 1) / P) * P;                                 // basis columns before the residual block
+  if (m > c->max_ncv) m = (c->max_ncv / P) * P;
   const int ld = m + P;                                            // leading dimension of the projected matrix
   std::vector<double> T((size_t)ld * ld, 0.0);
   double* hH = c->h_pinned + 8192;
@@ -601,8 +602,9 @@ extern "C" int plfem_lanczos_shift_invert(plfem_ctx* c, int32_t k, int32_t ncv, 
   {
     const char* env = std::getenv("PLFEM_LANCZOS_BLOCK");
     const bool allow = !(env && env[0] == '0');
-    const int mblk = ((ncv + plfem::BLOCK_P - 1) / plfem::BLOCK_P) * plfem::BLOCK_P;
-    if (allow && k >= plfem::BLOCK_P && mblk <= c->max_ncv && mblk >= k + 3 * plfem::BLOCK_P &&
+    int mblk = ((ncv + plfem::BLOCK_P - 1) / plfem::BLOCK_P) * plfem::BLOCK_P;
+    if (mblk > c->max_ncv) mblk = (c->max_ncv / plfem::BLOCK_P) * plfem::BLOCK_P;   // round down instead
+    if (allow && k >= plfem::BLOCK_P && mblk >= k + 3 * plfem::BLOCK_P &&
         2 * (int64_t)c->nsolve >= 16 * (int64_t)(mblk + plfem::BLOCK_P))
       return lanczos_block(c, k, ncv, tol, maxiter, sigma, evals_host, evecs_dev, stats_host);
   }

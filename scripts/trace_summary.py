@@ -20,7 +20,7 @@ if starts:
     for i in range(s, e):
         print(f"{names[i]:14s} grid={grid[i]} dur={dur[i]/1e3:7.1f}us start={(int(rows[i]['Start_Timestamp'])-t0)/1e3:8.1f}us")
     print('solve: launches', e - s, 'sum kernel us', sum(dur[s:e]) / 1e3, 'span us', (int(rows[e - 1]['End_Timestamp']) - t0) / 1e3)
-FS = ('k_leaf_assemble', 'k_front_gather', 'k_ldl_diag', 'k_ldl_invrow', 'k_ldl_panel', 'k_ldl_update')
+FS = ('k_leaf_assemble', 'k_front_gather', 'k_ldl_diag', 'k_ldl_invrow', 'k_ldl_panel', 'k_ldl_update', 'k_form_z', 'k_mirror_z')
 f0s = [i for i, n in enumerate(names) if n == 'k_leaf_assemble']
 if f0s:
     f0 = f0s[-1]; f1 = f0

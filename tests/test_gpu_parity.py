@@ -309,3 +309,37 @@ def test_north_star_size_properties(c1_geometry, gpu_device, built_library):
     assert ((x - V[3] / (evals[3] - sigma)).norm() / x.norm()).item() < 1e-7
     # n_eff band of SURVEY appendix B at L = 1: 26.122 .. 26.180
     assert abs(evals[0] - 26.122) < 2e-3 and abs(evals[-1] - 26.180) < 2e-3
+
+
+def test_block_and_single_vector_lanczos_agree(medium, monkeypatch):
+    """The block recurrence (4 right-hand sides per pass over the factors) and the single-vector one
+    return the same 22 pairs; the dispatch is visible in the stats."""
+    P = medium
+    P.ctx.factor(P.sigma)
+    ev_b, V_b, st_b = P.ctx.lanczos(22, 45, 1e-10, 12000, P.sigma)
+    assert st_b["n_block_solves"] > 0 and st_b["n_opinv"] == 4 * st_b["n_block_solves"]
+    monkeypatch.setenv("PLFEM_LANCZOS_BLOCK", "0")
+    ev_s, V_s, st_s = P.ctx.lanczos(22, 45, 1e-10, 12000, P.sigma)
+    assert st_s["n_block_solves"] == 0 and st_s["nconv"] == 22
+    assert np.abs(ev_b - ev_s).max() < 1e-9
+    Vb = V_b.cpu().numpy()[:, P.idx].T
+    Vs = V_s.cpu().numpy()[:, P.idx].T
+    assert _match_fields(Vb, Vs, ev_s).max() < FIELD_TOL
+    # fewer passes over the factors than single-vector OP applications
+    assert st_b["n_block_solves"] < st_s["n_opinv"]
+
+
+def test_live_kernel_profile_hooks(small):
+    P = small
+    P.ctx.factor(P.sigma)
+    P.ctx.profile_begin(64)
+    b = P.embed(np.random.default_rng(2).standard_normal(len(P.idx)))
+    for _ in range(3):
+        P.ctx.solve(b, 0)
+    prof = P.ctx.profile_end()
+    T = fe.FrontTree(P.sym)
+    tile_levels = sum(1 for lev in range(T.L + 1) if (1 << lev) > 32)
+    assert prof["launches"] == 3 * tile_levels
+    assert prof["total_us"] > 0 and prof["bytes"] > 0
+    # algorithmic bytes of one backward sweep never exceed the bytes of the stored factors + vectors
+    assert prof["bytes"] / 3 <= 8.0 * (P.sym.info["solve_entries"] + 4 * P.sym.info["front_doubles"] ** 0.5 * T.nf)
