@@ -75,6 +75,18 @@ int64_t plfem_symbolic_array_bytes(const plfem_symbolic* sym, const char* name);
 int plfem_symbolic_get(const plfem_symbolic* sym, const char* name, void* out_host, int64_t nbytes);
 
 /* ---------------------------------------------------------------------------------------------
+ * Mesh producer helper (the step before the path).
+ * Replaces: MeshTri.refined() in MeshGenerator._generate_mesh   reference mesh.py:317-327
+ * Uniform red refinement: new vertex id = nv + edge id (the P2 edge numbering), children
+ * (t0,e0,e2), (t1,e0,e1), (t2,e2,e1), (e0,e1,e2), columns sorted.  p_out: [2][nv + nedges],
+ * t_out: [3][4 ne]; nedges from plfem_mesh_edge_count.
+ * ------------------------------------------------------------------------------------------- */
+int plfem_mesh_edge_count(int32_t nv, int32_t ne, const double* p_host, const int32_t* t_host,
+                          int32_t* nedges, char* err, int32_t errlen);
+int plfem_mesh_refine(int32_t nv, int32_t ne, const double* p_host, const int32_t* t_host,
+                      double* p_out, int32_t* t_out, char* err, int32_t errlen);
+
+/* ---------------------------------------------------------------------------------------------
  * Context: binds a symbolic analysis to a device and stream, uploads the index structures and
  * allocates every workspace (nothing is allocated later, so calls are graph-capturable).
  * hip_stream: a hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL = the default (null) stream.

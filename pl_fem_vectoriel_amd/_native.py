@@ -30,6 +30,7 @@ EXPORTS = (
     "plfem_assemble_hfield", "plfem_block_values_dev", "plfem_block_values_host", "plfem_spmv", "plfem_factor",
     "plfem_solve", "plfem_lanczos_shift_invert", "plfem_postprocess", "plfem_timings",
     "plfem_debug_factor_until", "plfem_debug_copy", "plfem_profile_begin", "plfem_profile_end",
+    "plfem_mesh_edge_count", "plfem_mesh_refine",
 )
 
 _ARRAY_DTYPES = {
@@ -97,6 +98,10 @@ def load_library() -> ctypes.CDLL:
     lib.plfem_debug_factor_until.argtypes = [ctypes.c_void_p, ctypes.c_double, ctypes.c_int32, ctypes.c_int32,
                                              ctypes.c_int32]
     lib.plfem_debug_copy.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p]
+    lib.plfem_mesh_edge_count.argtypes = [ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p,
+                                          ctypes.POINTER(ctypes.c_int32), ctypes.c_char_p, ctypes.c_int32]
+    lib.plfem_mesh_refine.argtypes = [ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p,
+                                      ctypes.c_void_p, ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int32]
     lib.plfem_profile_begin.argtypes = [ctypes.c_void_p, ctypes.c_int32]
     lib.plfem_profile_end.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
     _lib = lib
@@ -105,6 +110,27 @@ def load_library() -> ctypes.CDLL:
 
 def _ptr(a: np.ndarray):
     return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def mesh_refine(p, t):
+    """Uniform red refinement on the host side of the library (``plfem_mesh_refine``):
+    returns ``(p2 (2, nv + nedges) float64, t2 (3, 4 ne) int32)``."""
+    lib = load_library()
+    p = np.ascontiguousarray(np.asarray(p, dtype=np.float64))
+    t = np.ascontiguousarray(np.asarray(t, dtype=np.int32))
+    if p.ndim != 2 or p.shape[0] != 2 or t.ndim != 2 or t.shape[0] != 3:
+        raise ValueError("mesh.p must be (2, nv) and mesh.t (3, ne)")
+    err = ctypes.create_string_buffer(512)
+    nedges = ctypes.c_int32(0)
+    rc = lib.plfem_mesh_edge_count(p.shape[1], t.shape[1], _ptr(p), _ptr(t), ctypes.byref(nedges), err, 512)
+    if rc != PLFEM_OK:
+        raise ValueError(f"plfem_mesh_edge_count failed ({rc}): {err.value.decode()}")
+    p2 = np.empty((2, p.shape[1] + nedges.value), dtype=np.float64)
+    t2 = np.empty((3, 4 * t.shape[1]), dtype=np.int32)
+    rc = lib.plfem_mesh_refine(p.shape[1], t.shape[1], _ptr(p), _ptr(t), _ptr(p2), _ptr(t2), err, 512)
+    if rc != PLFEM_OK:
+        raise ValueError(f"plfem_mesh_refine failed ({rc}): {err.value.decode()}")
+    return p2, t2
 
 
 class Symbolic:

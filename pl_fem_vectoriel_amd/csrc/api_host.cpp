@@ -3,6 +3,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <utility>
 
 #include "../../include/plfem.h"
 #include "internal.h"
@@ -118,5 +119,47 @@ extern "C" int plfem_symbolic_get(const plfem_symbolic* sym, const char* name, v
   if (!lookup(sym->S, name, r)) return PLFEM_EINVAL;
   if (r.bytes != nbytes) return PLFEM_EINVAL;
   std::memcpy(out_host, r.ptr, (size_t)nbytes);
+  return PLFEM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Uniform red refinement (mesh producer).
+// ---------------------------------------------------------------------------------------------
+extern "C" int plfem_mesh_edge_count(int32_t nv, int32_t ne, const double* p_host, const int32_t* t_host,
+                                     int32_t* nedges, char* err, int32_t errlen) {
+  if (!p_host || !t_host || !nedges) return PLFEM_EINVAL;
+  plfem::Symbolic S;
+  std::string msg = plfem::numbering_only(nv, ne, p_host, t_host, S);
+  if (!msg.empty()) { set_err(err, errlen, msg); return PLFEM_EMESH; }
+  *nedges = S.nedges;
+  return PLFEM_OK;
+}
+
+extern "C" int plfem_mesh_refine(int32_t nv, int32_t ne, const double* p_host, const int32_t* t_host,
+                                 double* p_out, int32_t* t_out, char* err, int32_t errlen) {
+  if (!p_host || !t_host || !p_out || !t_out) return PLFEM_EINVAL;
+  plfem::Symbolic S;
+  std::string msg = plfem::numbering_only(nv, ne, p_host, t_host, S);
+  if (!msg.empty()) { set_err(err, errlen, msg); return PLFEM_EMESH; }
+  const int N = S.N;
+  std::memcpy(p_out, S.doflocs.data(), sizeof(double) * 2 * (size_t)N);   // vertices, then edge midpoints
+  const int32_t* d = S.edof.data();
+  const size_t n4 = (size_t)4 * ne;
+  for (int e = 0; e < ne; ++e) {
+    const int32_t v0 = d[e], v1 = d[(size_t)ne + e], v2 = d[(size_t)2 * ne + e];
+    const int32_t e0 = d[(size_t)3 * ne + e], e1 = d[(size_t)4 * ne + e], e2 = d[(size_t)5 * ne + e];
+    // children hstacked as (t0,e0,e2), (t1,e0,e1), (t2,e2,e1), (e0,e1,e2), every column sorted ascending
+    const int32_t ch[4][3] = {{v0, e0, e2}, {v1, e0, e1}, {v2, e2, e1}, {e0, e1, e2}};
+    for (int c = 0; c < 4; ++c) {
+      int32_t a = ch[c][0], b = ch[c][1], cc = ch[c][2];
+      if (a > b) std::swap(a, b);
+      if (b > cc) std::swap(b, cc);
+      if (a > b) std::swap(a, b);
+      const size_t col = (size_t)c * ne + e;
+      t_out[col] = a;
+      t_out[n4 + col] = b;
+      t_out[2 * n4 + col] = cc;
+    }
+  }
   return PLFEM_OK;
 }

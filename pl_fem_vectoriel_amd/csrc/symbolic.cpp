@@ -491,6 +491,11 @@ std::string build_fronts(Symbolic& S, int nthreads) {
 
 }  // namespace
 
+std::string numbering_only(int nv, int ne, const double* p, const int32_t* t, Symbolic& S) {
+  if (nv < 3 || ne < 1) return "empty mesh";
+  return p2_numbering(nv, ne, p, t, S);
+}
+
 std::string build_symbolic(int nv, int ne, const double* p, const int32_t* t, int leaf_elems,
                            int nthreads, Symbolic& S) {
   if (nv < 3 || ne < 1) return "empty mesh";

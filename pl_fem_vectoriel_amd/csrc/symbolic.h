@@ -59,4 +59,8 @@ struct Symbolic {
 std::string build_symbolic(int nv, int ne, const double* p, const int32_t* t, int leaf_elems,
                            int nthreads, Symbolic& S);
 
+// P2 numbering only (fills nv..int_index of S): what uniform red refinement needs, since the refined
+// mesh's vertices are exactly the P2 nodes of the coarse mesh (new vertex id = nv + edge id).
+std::string numbering_only(int nv, int ne, const double* p, const int32_t* t, Symbolic& S);
+
 }  // namespace plfem
