@@ -107,30 +107,48 @@ std::string p2_numbering(int nv, int ne, const double* p, const int32_t* t, Symb
     }
   }
   // sort + unique each bucket; edge id = running count => lexicographic (min, max) rank
+  // (two passes so that the per-vertex work runs on the worker pool: sort + count, prefix, write)
   std::vector<int32_t> eoff((size_t)nv + 1, 0);
-  std::vector<uint8_t> mult;
-  mult.reserve((size_t)3 * ne / 2 + 16);
-  S.edges.clear();
-  std::vector<int32_t> ea, eb;
-  ea.reserve((size_t)3 * ne / 2 + 16);
-  eb.reserve((size_t)3 * ne / 2 + 16);
-  for (int v = 0; v < nv; ++v) {
-    int32_t* b = nb.data() + cnt[v];
-    int32_t* e = nb.data() + cnt[v + 1];
-    std::sort(b, e);
-    eoff[v] = (int32_t)ea.size();
-    for (int32_t* q = b; q < e;) {
-      int32_t* r = q;
-      while (r < e && *r == *q) ++r;
-      if (r - q > 2) return "non-manifold mesh: an edge is shared by more than two triangles";
-      ea.push_back(v);
-      eb.push_back(*q);
-      mult.push_back((uint8_t)(r - q));
-      q = r;
+  std::atomic<int> bad{0};
+  const int nth = g_pool ? g_pool->nt : 1;
+  parallel_for(nv, nth, [&](int64_t vb, int64_t ve, int) {
+    for (int64_t v = vb; v < ve; ++v) {
+      int32_t* b = nb.data() + cnt[v];
+      int32_t* e = nb.data() + cnt[v + 1];
+      std::sort(b, e);
+      int32_t nu = 0;
+      for (int32_t* q = b; q < e;) {
+        int32_t* r = q;
+        while (r < e && *r == *q) ++r;
+        if (r - q > 2) bad.store(1);
+        ++nu;
+        q = r;
+      }
+      eoff[v + 1] = nu;
     }
-  }
-  eoff[nv] = (int32_t)ea.size();
-  S.nedges = (int)ea.size();
+  });
+  if (bad.load()) return "non-manifold mesh: an edge is shared by more than two triangles";
+  for (int v = 0; v < nv; ++v) eoff[v + 1] += eoff[v];
+  const int nedges_total = eoff[nv];
+  std::vector<uint8_t> mult((size_t)nedges_total);
+  std::vector<int32_t> ea((size_t)nedges_total), eb((size_t)nedges_total);
+  parallel_for(nv, nth, [&](int64_t vb, int64_t ve, int) {
+    for (int64_t v = vb; v < ve; ++v) {
+      const int32_t* b = nb.data() + cnt[v];
+      const int32_t* e = nb.data() + cnt[v + 1];
+      int32_t k = eoff[v];
+      for (const int32_t* q = b; q < e;) {
+        const int32_t* r = q;
+        while (r < e && *r == *q) ++r;
+        ea[k] = (int32_t)v;
+        eb[k] = *q;
+        mult[k] = (uint8_t)(r - q);
+        ++k;
+        q = r;
+      }
+    }
+  });
+  S.nedges = nedges_total;
   S.edges.resize((size_t)2 * S.nedges);
   std::copy(ea.begin(), ea.end(), S.edges.begin());
   std::copy(eb.begin(), eb.end(), S.edges.begin() + S.nedges);
@@ -143,21 +161,25 @@ std::string p2_numbering(int nv, int ne, const double* p, const int32_t* t, Symb
   };
   S.edof.resize((size_t)6 * ne);
   int32_t* d = S.edof.data();
-  for (int e = 0; e < ne; ++e) {
-    d[e] = t0[e];
-    d[(size_t)ne + e] = t1[e];
-    d[(size_t)2 * ne + e] = t2[e];
-    d[(size_t)3 * ne + e] = nv + edge_id(t0[e], t1[e]);
-    d[(size_t)4 * ne + e] = nv + edge_id(t1[e], t2[e]);
-    d[(size_t)5 * ne + e] = nv + edge_id(t0[e], t2[e]);
-  }
+  parallel_for(ne, nth, [&](int64_t e0, int64_t e1, int) {
+    for (int64_t e = e0; e < e1; ++e) {
+      d[e] = t0[e];
+      d[(size_t)ne + e] = t1[e];
+      d[(size_t)2 * ne + e] = t2[e];
+      d[(size_t)3 * ne + e] = nv + edge_id(t0[e], t1[e]);
+      d[(size_t)4 * ne + e] = nv + edge_id(t1[e], t2[e]);
+      d[(size_t)5 * ne + e] = nv + edge_id(t0[e], t2[e]);
+    }
+  });
   S.doflocs.resize((size_t)2 * N);
   std::memcpy(S.doflocs.data(), p, sizeof(double) * nv);
   std::memcpy(S.doflocs.data() + N, p + nv, sizeof(double) * nv);
-  for (int k = 0; k < S.nedges; ++k) {
-    S.doflocs[nv + k] = 0.5 * (p[ea[k]] + p[eb[k]]);
-    S.doflocs[(size_t)N + nv + k] = 0.5 * (p[nv + ea[k]] + p[nv + eb[k]]);
-  }
+  parallel_for(S.nedges, nth, [&](int64_t k0, int64_t k1, int) {
+    for (int64_t k = k0; k < k1; ++k) {
+      S.doflocs[nv + k] = 0.5 * (p[ea[k]] + p[eb[k]]);
+      S.doflocs[(size_t)N + nv + k] = 0.5 * (p[nv + ea[k]] + p[nv + eb[k]]);
+    }
+  });
   S.bmask.assign(N, 0);
   for (int k = 0; k < S.nedges; ++k)
     if (mult[k] == 1) { S.bmask[ea[k]] = 1; S.bmask[eb[k]] = 1; S.bmask[nv + k] = 1; }
