@@ -130,6 +130,13 @@ class TrueVectorialMaxwellSolver:
         logger.info(f"Solveur H-field initialisé - k₀={self.k0:.4f} µm⁻¹")
 
     # -- symbolic / context management -------------------------------------------------------------
+    def adopt_analysis(self, mesh, sym: "_native.Symbolic") -> None:
+        """Install a mesh-only analysis built elsewhere (e.g. on a background thread while the GPU
+        was busy with the previous cross-section of a sweep) for ``mesh``."""
+        self._cache.clear()
+        self._cache[(id(mesh), mesh.p.shape[1], mesh.t.shape[1])] = {
+            "sym": sym, "ctx": None, "basis": None, "t_symbolic": 0.0, "mesh": mesh}
+
     def _analysis(self, mesh, need_ctx: bool, max_ncv: int = 65):
         key = (id(mesh), mesh.p.shape[1], mesh.t.shape[1])
         ent = self._cache.get(key) if self.reuse_symbolic else None

@@ -84,9 +84,22 @@ def partition(items: Sequence[SweepItem], world_size: int) -> List[List[SweepIte
 
 
 def default_solve(device: Optional[int] = None) -> Callable[[SweepItem, dict], np.ndarray]:
-    """Solve one item on the GPU; ``cache`` keeps one solver (symbolic analysis + context) per mesh."""
+    """Solve one item on the GPU; ``cache`` keeps one solver (symbolic analysis + context) per mesh.
+
+    ``solve.prepare(item, cache)`` may be called from a background thread for the NEXT mesh: mesh
+    generation (SciPy Delaunay + native refinement) and the host-side symbolic analysis release the GIL,
+    so they overlap with the GPU solves of the current mesh."""
+    from . import _native
     from .mesh import generate_mesh
     from .solver_fem import TrueVectorialMaxwellSolver
+
+    def build(item: SweepItem) -> dict:
+        g = item.geometry()
+        mesh = generate_mesh(g, item.mesh_refinement, item.mesh_levels)
+        return {"key": item.mesh_key, "mesh": mesh, "sym": _native.Symbolic(mesh.p, mesh.t)}
+
+    def prepare(item: SweepItem, cache: dict) -> None:
+        cache.setdefault("prefetched", {})[item.mesh_key] = build(item)
 
     def solve(item: SweepItem, cache: dict) -> np.ndarray:
         g = item.geometry()
@@ -94,14 +107,16 @@ def default_solve(device: Optional[int] = None) -> Callable[[SweepItem, dict], n
         if ent is None or ent["key"] != item.mesh_key:
             if ent is not None:
                 ent["solver"].clear_cache()
-            ent = {"key": item.mesh_key, "mesh": generate_mesh(g, item.mesh_refinement, item.mesh_levels),
-                   "solver": TrueVectorialMaxwellSolver(g, device=device)}
+            ent = cache.get("prefetched", {}).pop(item.mesh_key, None) or build(item)
+            ent["solver"] = TrueVectorialMaxwellSolver(g, device=device)
+            ent["solver"].adopt_analysis(ent["mesh"], ent["sym"])
             cache["cur"] = ent
         s = ent["solver"]
         s.geometry, s.k0 = g, g.k0
         modes = s.solve_vectorial_modes(ent["mesh"], item.n_modes)
         return np.array([m["n_eff"] for m in modes], dtype=np.float64)
 
+    solve.prepare = prepare
     return solve
 
 
@@ -123,7 +138,20 @@ def run_sweep(items: Sequence[SweepItem], rank: int = 0, world_size: int = 1,
     per_rank = max(len(p) for p in partition(items, world_size))
     rec = np.full((per_rank, REC_WIDTH), np.nan)
     rec[:, 0] = -1
+    prefetch = None
     for q, it in enumerate(mine):
+        new_group = q == 0 or mine[q - 1].mesh_key != it.mesh_key
+        if new_group:
+            if prefetch is not None:
+                prefetch.join()             # the mesh prepared in the background is this item's
+                prefetch = None
+            if hasattr(solve, "prepare"):
+                # while the GPU works on this mesh, prepare the next DIFFERENT mesh on a host thread
+                nxt = next((x for x in mine[q + 1:] if x.mesh_key != it.mesh_key), None)
+                if nxt is not None:
+                    import threading
+                    prefetch = threading.Thread(target=solve.prepare, args=(nxt, cache), daemon=True)
+                    prefetch.start()
         ne = np.asarray(solve(it, cache), dtype=np.float64)[:K_MAX]
         rec[q, 0], rec[q, 1], rec[q, 2], rec[q, 3] = it.index, len(ne), rank, 0
         rec[q, 4:4 + len(ne)] = ne
