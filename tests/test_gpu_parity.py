@@ -343,3 +343,21 @@ def test_live_kernel_profile_hooks(small):
     assert prof["total_us"] > 0 and prof["bytes"] > 0
     # algorithmic bytes of one backward sweep never exceed the bytes of the stored factors + vectors
     assert prof["bytes"] / 3 <= 8.0 * (P.sym.info["solve_entries"] + 4 * P.sym.info["front_doubles"] ** 0.5 * T.nf)
+
+
+def test_sweep_driver_on_gpu_matches_direct_solves(gpu_device, built_library):
+    """Two meshes x two wavelengths through run_sweep (background preparation of the next mesh,
+    adopted analysis, context reuse across wavelengths) = the same n_eff as isolated solves."""
+    from pl_fem_vectoriel_amd.sweep import SweepItem, run_sweep
+    items = []
+    for arr in ("linear_2", "triangular_3"):
+        for lam in (1.55, 1.60):
+            items.append(SweepItem(len(items), arr, 8.0, lam, n_modes=4, mesh_refinement=0.35, mesh_levels=0))
+    table, n_local = run_sweep(items, 0, 1, device=gpu_device)
+    assert n_local == 4 and sorted(table) == [0, 1, 2, 3]
+    for it in items:
+        g = it.geometry()
+        mesh = generate_mesh(g, it.mesh_refinement, it.mesh_levels)
+        direct = TrueVectorialMaxwellSolver(g, device=gpu_device).solve_vectorial_modes(mesh, it.n_modes)
+        ref = np.array([m["n_eff"] for m in direct])
+        assert len(ref) == len(table[it.index]) and np.abs(ref - table[it.index]).max() < 1e-10
