@@ -37,6 +37,7 @@ def cpu_baseline(geom, mesh, gpu_modes):
     import numpy as np
     from oracle import hfield
     from oracle.p2 import MeshTriLite
+    from oracle.compare import mode_field_errors
 
     threads = int(os.environ.get("PLFEM_CPU_THREADS", "4"))         # the reference sets OMP/MKL_NUM_THREADS=4 (main.py:19-20)
     try:
@@ -51,11 +52,7 @@ def cpu_baseline(geom, mesh, gpu_modes):
     if limiter is not None:
         limiter.restore_original_limits()
     dn = max(abs(a["n_eff"] - b["n_eff"]) for a, b in zip(gpu_modes, ref)) if len(ref) == len(gpu_modes) else float("nan")
-    worst = 0.0
-    for a, b in zip(gpu_modes, ref):
-        va = np.concatenate([a["Ex_dofs"], a["Ey_dofs"]])
-        vb = np.concatenate([b["Ex_dofs"], b["Ey_dofs"]])
-        worst = max(worst, min(np.linalg.norm(va - vb), np.linalg.norm(va + vb)))
+    worst = float(np.max(mode_field_errors(gpu_modes, ref))) if len(ref) == len(gpu_modes) else float("nan")
     base = {"value": N_MODES / dt, "unit": "modes/s", "cores": threads, "kind": "port",
             "sample": f"1 full solve of the same C1 workload ({dt:.1f} s: assembly {tm['assembly']:.1f} s, "
                       f"eigsh {tm['eigsh']:.1f} s; assembly and SuperLU are single-threaded, BLAS limited to {threads} threads; "
