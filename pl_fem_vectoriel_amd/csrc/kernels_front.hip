@@ -102,14 +102,25 @@ __global__ __launch_bounds__(256) void k_front_gather(
 // ------------------------------------------------------------------------------------------------
 // block LDL^T, step kb of a level:  diag -> invrow -> panel -> update
 // ------------------------------------------------------------------------------------------------
-// Pivot block: unpivoted LDL^T of the NB x NB block in LDS (static perturbation of vanishing pivots),
-// X = L^-1 by forward substitution.  Writes X (dinv), D (delta), the block itself (lower X, upper
-// X^T) and saves the block row L[k, <k] of L11 for the triangular-inverse update (tbuf).
-__global__ __launch_bounds__(256) void k_ldl_diag(int first_front, int kb, const int32_t* __restrict__ fs2,
-                                                  const int32_t* __restrict__ fm, const int64_t* __restrict__ foff,
-                                                  const int64_t* __restrict__ fnode_ptr, double* __restrict__ front,
-                                                  double* __restrict__ dinv, double* __restrict__ delta,
-                                                  double* __restrict__ tbuf, int32_t* __restrict__ counters) {
+// Pivot block: unpivoted LDL^T of the NB x NB block (static perturbation of vanishing pivots) with
+// X = L^-1 formed by applying the row operations to the identity at the same time.  Writes X (dinv),
+// D (delta), the block itself (lower X, upper X^T).  Workgroups of ONE wave, so the 32 dependent
+// elimination steps need no workgroup barrier: lane (i, h) keeps columns 16h .. 16h+15 of row i in
+// registers -- entry c is a[i][c] while c > k and x[i][c] once c <= k -- the pivot is broadcast with
+// v_readlane and row k of x / column k of L travel through one LDS row.  blockIdx.y >= 1: the other
+// waves save the block row L[k, <k] of L11 for the triangular-inverse update (tbuf), 64 columns each.
+__device__ __forceinline__ double readlane_f64(double v, int src) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+  return __hiloint2double(hi, lo);
+}
+
+__global__ __launch_bounds__(64) void k_ldl_diag(int first_front, int kb, const int32_t* __restrict__ fs2,
+                                                 const int32_t* __restrict__ fm, const int64_t* __restrict__ foff,
+                                                 const int64_t* __restrict__ fnode_ptr, double* __restrict__ front,
+                                                 double* __restrict__ dinv, double* __restrict__ delta,
+                                                 double* __restrict__ tbuf, int32_t* __restrict__ counters) {
+  static_assert(NB == 32, "lane map of k_ldl_diag");
   const int f = first_front + blockIdx.x;
   const int s2 = fs2[f];
   const int k0 = kb * NB;
@@ -117,63 +128,88 @@ __global__ __launch_bounds__(256) void k_ldl_diag(int first_front, int kb, const
   const int nbk = min(NB, s2 - k0);
   const int m = fm[f];
   double* F = front + foff[f];
-  __shared__ double a[NB][NB + 1];
-  __shared__ double x[NB][NB + 1];
-  __shared__ double lk[NB];
-  __shared__ double dl[NB];
-  __shared__ double s_red[4];
-  const int tid = threadIdx.x;
-  // save the block row of L11 left of the pivot block: tbuf[q + j*NB] = L[k0+q, j], j < k0
-  double* T = tbuf + 2 * fnode_ptr[f] * NB;
-  for (int k = tid; k < NB * k0; k += 256) {
-    int q = k % NB, j = k / NB;
-    T[k] = (q < nbk) ? F[(int64_t)j * m + (k0 + q)] : 0.0;
+  const int lane = threadIdx.x;
+  if (blockIdx.y > 0) {
+    // tbuf[q + j*NB] = L[k0+q, j] for the 64 columns j of this block
+    const int jb = (blockIdx.y - 1) * 64;
+    if (jb >= k0) return;
+    double* T = tbuf + 2 * fnode_ptr[f] * NB;
+    const int q = lane & 31, jh = lane >> 5;
+#pragma unroll 8
+    for (int jj = 0; jj < 64; jj += 2) {
+      const int j = jb + jj + jh;
+      if (j < k0) T[(int64_t)j * NB + q] = (q < nbk) ? F[(int64_t)j * m + (k0 + q)] : 0.0;
+    }
+    return;
   }
+  __shared__ double srow[NB];
+  __shared__ double tile[NB][NB + 1];
+  const int i = lane & 31, h = lane >> 5;
+  double v[16];
   double amax = 0.0;
-  for (int k = tid; k < NB * NB; k += 256) {
-    int r = k % NB, c = k / NB;
-    double v = (r < nbk && c < nbk) ? F[(int64_t)(k0 + c) * m + (k0 + r)] : (r == c ? 1.0 : 0.0);
-    a[r][c] = v;
-    amax = fmax(amax, fabs(v));
+#pragma unroll
+  for (int cc = 0; cc < 16; ++cc) {
+    const int c = 16 * h + cc;
+    v[cc] = (i < nbk && c < nbk) ? F[(int64_t)(k0 + c) * m + (k0 + i)] : (i == c ? 1.0 : 0.0);
+    amax = fmax(amax, fabs(v[cc]));
   }
   for (int off = 32; off >= 1; off >>= 1) amax = fmax(amax, __shfl_xor(amax, off));
-  if ((tid & 63) == 0) s_red[tid >> 6] = amax;
-  __syncthreads();
-  amax = fmax(fmax(s_red[0], s_red[1]), fmax(s_red[2], s_red[3]));
   const double thr = fmax(1e-13 * amax, 1e-300);
-  const int i = tid >> 3, cg = tid & 7;   // trailing update: row i, columns cg*4 .. cg*4+3
-  for (int k = tid; k < NB * NB; k += 256) x[k % NB][k / NB] = (k % NB == k / NB) ? 1.0 : 0.0;
-  // The row operations of the elimination are applied to the identity at the same time, so that
-  // x = L^-1 when the loop ends (row k of x is final when step k starts).
+  double dmine = 1.0;
+#pragma unroll
   for (int k = 0; k < NB; ++k) {
-    double dk = a[k][k];
+    const int kh = k >> 4, kc = k & 15;
+    double dk = readlane_f64(v[kc], k + 32 * kh);              // a[k][k]
     if (!(fabs(dk) >= thr)) {
       dk = (dk < 0.0) ? -thr : thr;
-      if (tid == 0) atomicAdd(&counters[0], 1);
+      if (lane == 0) atomicAdd(&counters[0], 1);
     }
-    if (tid < NB) {
-      lk[tid] = (tid > k) ? a[tid][k] / dk : 0.0;
-      if (tid == k) dl[k] = dk;
+    if (i == k) dmine = dk;
+    double colk = 0.0;
+    if (h == kh) {                                            // column k leaves a and becomes a column of x
+      colk = v[kc];
+      v[kc] = (i == k) ? 1.0 : 0.0;
     }
-    __syncthreads();
-    if (i > k) {
-      const double li = lk[i];
+    // one LDS row: entries c <= k = row k of x (from lane row k), entries c > k = L[c][k] (from lane row c).
+    // The LDS queue of a wave is in order, so the second write wins where both touch.
+    if (i == k) {
 #pragma unroll
-      for (int cc = 0; cc < 4; ++cc) {
-        int c = cg * 4 + cc;
-        if (c > k) a[i][c] -= li * dk * lk[c];
-        else x[i][c] -= li * x[k][c];
-      }
+      for (int cc = 0; cc < 16; ++cc) srow[16 * h + cc] = v[cc];
     }
-    __syncthreads();
+    if (h == kh && i > k) srow[i] = colk / dk;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const double li = (i > k) ? srow[i] : 0.0;
+    const double t = li * dk;
+#pragma unroll
+    for (int cc = 0; cc < 16; ++cc) {
+      const int c = 16 * h + cc;
+      const double src = srow[c];
+      v[cc] -= ((c > k) ? t : li) * src;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   }
+  // x[i][c] = v for c <= i, 0 above the diagonal
   double* D = dinv + (int64_t)f * NB * NB;
-  for (int k = tid; k < NB * NB; k += 256) {
-    int r = k % NB, c = k / NB;
-    D[k] = x[r][c];
-    if (r < nbk && c < nbk) F[(int64_t)(k0 + c) * m + (k0 + r)] = (r >= c) ? x[r][c] : x[c][r];
+#pragma unroll
+  for (int cc = 0; cc < 16; ++cc) {
+    const int c = 16 * h + cc;
+    const double xv = (c <= i) ? v[cc] : 0.0;
+    D[(int64_t)c * NB + i] = xv;
+    tile[i][c] = xv;
   }
-  if (tid < nbk) delta[2 * fnode_ptr[f] + k0 + tid] = dl[tid];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+  for (int cc = 0; cc < 16; ++cc) {
+    const int c = 16 * h + cc;
+    if (i < nbk && c < nbk) F[(int64_t)(k0 + c) * m + (k0 + i)] = (i >= c) ? tile[i][c] : tile[c][i];
+  }
+  if (h == 0 && i < nbk) delta[2 * fnode_ptr[f] + k0 + i] = dmine;
 }
 
 // Triangular-inverse update: with X<k the inverse of the leading k0 x k0 block of L11,
@@ -201,14 +237,21 @@ __global__ __launch_bounds__(256) void k_ldl_invrow(int first_front, int kb, con
   const int lr = lane & 15, lk = lane >> 4;
   const int c = c0 + lr;
   v4d t0 = (v4d){0.0, 0.0, 0.0, 0.0}, t1 = (v4d){0.0, 0.0, 0.0, 0.0};
-#pragma unroll 4
-  for (int j0 = c0; j0 < k0; j0 += 4) {
-    const int j = j0 + lk;
-    const double a0 = T[(int64_t)j * NB + lr];
-    const double a1 = T[(int64_t)j * NB + 16 + lr];
-    const double b = (j >= c) ? F[(int64_t)j * m + c] : 0.0;    // X<k[j, c] (unit diagonal stored)
-    t0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b, t0, 0, 0, 0);
-    t1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b, t1, 0, 0, 0);
+  // k0 - c0 is a multiple of 16: four k-steps (12 loads) are requested before their MFMAs
+  for (int j0 = c0; j0 < k0; j0 += 16) {
+    double a0[4], a1[4], b[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int j = j0 + 4 * t + lk;
+      a0[t] = T[(int64_t)j * NB + lr];
+      a1[t] = T[(int64_t)j * NB + 16 + lr];
+      b[t] = (j >= c) ? F[(int64_t)j * m + c] : 0.0;            // X<k[j, c] (unit diagonal stored)
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      t0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[t], b[t], t0, 0, 0, 0);
+      t1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[t], b[t], t1, 0, 0, 0);
+    }
   }
   v4d x0 = (v4d){0.0, 0.0, 0.0, 0.0}, x1 = (v4d){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -310,29 +353,48 @@ __global__ __launch_bounds__(256) void k_ldl_update(int first_front, int kb, con
   const double* Y = rbuf + 2 * fnode_ptr[f] * NB;
   const int lr = lane & 15, lk = lane >> 4;
   const bool iv1 = i0 + 16 < m, jv1 = j0 + 16 < m;
-  v4d acc[2][2];
-  for (int tj = 0; tj < 2; ++tj)
-    for (int ti = 0; ti < 2; ++ti) acc[tj][ti] = (v4d){0.0, 0.0, 0.0, 0.0};
-  for (int kk = 0; kk < nbk; kk += 4) {
-    const int64_t col = (int64_t)(kk + lk) * m;
-    double a0 = Y[col + j0 + lr];
-    double a1 = jv1 ? Y[col + j0 + 16 + lr] : 0.0;
-    double b0 = W[col + i0 + lr];
-    double b1 = iv1 ? W[col + i0 + 16 + lr] : 0.0;
-    acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
-    acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
-    acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
-    acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+  // every operand of the tile is requested before the first MFMA: the panel kernel stores all NB columns
+  // of W and Y (zeros past nbk), so the trip count is fixed and the 32 + 16 loads are in flight together
+  double a0[NB / 4], a1[NB / 4], b0[NB / 4], b1[NB / 4];
+#pragma unroll
+  for (int it = 0; it < NB / 4; ++it) {
+    const int64_t col = (int64_t)(4 * it + lk) * m;
+    a0[it] = Y[col + j0 + lr];
+    a1[it] = jv1 ? Y[col + j0 + 16 + lr] : 0.0;
+    b0[it] = W[col + i0 + lr];
+    b1[it] = iv1 ? W[col + i0 + 16 + lr] : 0.0;
   }
+  double fv[2][2][4];
+#pragma unroll
+  for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const bool ok = (tj == 0 || jv1) && (ti == 0 || iv1);
+        fv[tj][ti][r] = ok ? F[(int64_t)(j0 + 16 * tj + lk + 4 * r) * m + (i0 + 16 * ti + lr)] : 0.0;
+      }
+  v4d acc[2][2];
+#pragma unroll
+  for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti) acc[tj][ti] = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int it = 0; it < NB / 4; ++it) {
+    acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[it], b0[it], acc[0][0], 0, 0, 0);
+    acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[it], b1[it], acc[0][1], 0, 0, 0);
+    acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[it], b0[it], acc[1][0], 0, 0, 0);
+    acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[it], b1[it], acc[1][1], 0, 0, 0);
+  }
+#pragma unroll
   for (int tj = 0; tj < 2; ++tj) {
     if (tj == 1 && !jv1) continue;
+#pragma unroll
     for (int ti = 0; ti < 2; ++ti) {
       if (ti == 1 && !iv1) continue;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        int64_t idx = (int64_t)(j0 + 16 * tj + lk + 4 * r) * m + (i0 + 16 * ti + lr);
-        F[idx] -= acc[tj][ti][r];
-      }
+      for (int r = 0; r < 4; ++r)
+        F[(int64_t)(j0 + 16 * tj + lk + 4 * r) * m + (i0 + 16 * ti + lr)] = fv[tj][ti][r] - acc[tj][ti][r];
     }
   }
 }
@@ -411,9 +473,12 @@ __global__ __launch_bounds__(256) void k_mirror_z(int first_front, const int32_t
 // vectors).
 //   forward : [ys; u] = [D^-1 L11^-1 r ;  w_b - Z r],     r = rhs_own + children's updates
 //   backward: x_own   = L11^-T ys - Z^T x_b
-// "tile" form (levels with many small fronts): lane = output row, the block's four waves split the
-// columns, partial sums meet in LDS in a fixed order.  "dot" form (few large fronts): one wave per
-// output, reduction across the lanes.  Both read contiguous runs of F thanks to the mirrored storage.
+// Forward: "tile" form (levels with many fronts): lane = output row, the block's waves split the columns,
+// partial sums meet in LDS in a fixed order; "dot" form (few large fronts): one wave per output row,
+// reduction across the lanes.  Backward: "row" form (k_bwd_rows: a wave owns R rows and runs along the
+// contiguous columns of the lower storage) except at the leaf level, where the fronts have about as many
+// owned rows as boundary columns and the tile form is faster.  All read contiguous runs of F thanks to the
+// mirrored storage.
 // Global vectors: column q of rhs / x at offset q*ldx.  Per-front vectors: [dof][P] interleaved.
 // ------------------------------------------------------------------------------------------------
 // global vector element (dof index i, right-hand side u): ldx > 0 -> separate columns (u*ldx + i),
@@ -524,6 +589,8 @@ __global__ __launch_bounds__(NW * 64) void k_fwd(int first_front, int N, int64_t
   const int ce = (r < s2) ? r + 1 : s2;               // rows of L11^-1 are lower triangular
   double acc[P];
   tile_sum<P, NW>(acc, front + foff[f] + r, m, valid, 0, ce, sv, red);
+  // (fetching the epilogue operands before the sum is slower: the dependent index -> value loads of
+  // gather_rhs would sit in front of the matrix loads in the in-order memory counter)
   if (threadIdx.x < 64 && valid) {
     if (r < s2) {
       const double di = 1.0 / delta[2 * np + r];
@@ -624,10 +691,10 @@ __global__ __launch_bounds__(NW * 64) void k_bwd(int first_front, int N, int64_t
   const int r = r0 + (threadIdx.x & 63);
   const bool valid = r < s2;
   // element (j = r, i) of [L11^-T | Z^T] at F[r + i m], i in [r, m)
+  const int node = (threadIdx.x < 64 && valid) ? fnodes[np + (r >> 1)] : -1;
   double acc[P];
   tile_sum<P, NW>(acc, front + foff[f] + r, m, valid, r, m, sv, red);
   if (threadIdx.x < 64 && valid) {
-    const int node = fnodes[np + (r >> 1)];
     if (node >= 0) {
 #pragma unroll
       for (int u = 0; u < P; ++u) x[vidx<P>((int64_t)(r & 1) * N + node, u, ldx)] = acc[u];
@@ -635,40 +702,89 @@ __global__ __launch_bounds__(NW * 64) void k_bwd(int first_front, int N, int64_t
   }
 }
 
-template <int P>
-__global__ __launch_bounds__(256) void k_bwd_dot(int first_front, int N, int64_t ldx, const int32_t* __restrict__ fs2,
-                                                 const int32_t* __restrict__ fm, const int64_t* __restrict__ foff,
-                                                 const int64_t* __restrict__ fnode_ptr,
-                                                 const int32_t* __restrict__ fnodes, const double* __restrict__ front,
-                                                 const double* __restrict__ fvec2, double* __restrict__ x) {
+// Sums V (a power of two <= 64) per-lane values over the 64 lanes with V - 1 + log2(64 / V) shuffles instead of
+// 6 V: each butterfly step halves the values a lane still carries.  On return a[0] of lane l is the complete sum
+// of value multi_reduce_index<V>(l); lanes 0 .. V-1 cover every value once.  Fixed order, so deterministic.
+template <int V>
+__device__ __forceinline__ int multi_reduce_index(int lane) {
+  int idx = 0;
+#pragma unroll
+  for (int h = V / 2, s = 0; h >= 1; h >>= 1, ++s) idx += ((lane >> s) & 1) ? h : 0;
+  return idx;
+}
+
+template <int V>
+__device__ __forceinline__ void multi_reduce(double (&a)[V], int lane) {
+#pragma unroll
+  for (int h = V / 2, bit = 1; h >= 1; h >>= 1, bit <<= 1) {
+    const bool up = (lane & bit) != 0;
+#pragma unroll
+    for (int k = 0; k < h; ++k) {
+      const double send = up ? a[k] : a[k + h];
+      const double keep = up ? a[k + h] : a[k];
+      a[k] = keep + __shfl_xor(send, bit);
+    }
+  }
+#pragma unroll
+  for (int off = V; off < 64; off <<= 1) a[0] += __shfl_xor(a[0], off);
+}
+
+// Backward sweep, row form: x_j = sum_{i >= j} [L11^-1 ; Z](i, j) v_i with v = [ys ; -x_b] staged in LDS.
+// Column j of the lower storage is contiguous in i, so a wave reads 512-byte runs; a wave owns R rows
+// (j0 + wave + NW q) and keeps R x 8/R loads in flight; a block (NW waves) shares one staged vector for NW R rows.
+template <int P, int NW, int R>
+__global__ __launch_bounds__(NW * 64) void k_bwd_rows(int first_front, int N, int64_t ldx, const int32_t* __restrict__ fs2,
+                                                      const int32_t* __restrict__ fm, const int64_t* __restrict__ foff,
+                                                      const int64_t* __restrict__ fnode_ptr,
+                                                      const int32_t* __restrict__ fnodes, const double* __restrict__ front,
+                                                      const double* __restrict__ fvec2, double* __restrict__ x) {
   extern __shared__ double sv[];
+  constexpr int RB = NW * R, UNR = 8 / R, V = R * P;
   const int f = first_front + blockIdx.y;
   const int m = fm[f], s2 = fs2[f];
-  const int jlo = blockIdx.x * 4;
-  if (jlo >= s2) return;
+  const int j0 = blockIdx.x * RB;
+  if (j0 >= s2) return;
   const int64_t np = fnode_ptr[f];
-  stage_bwd<P>(sv, jlo, m, s2, N, ldx, np, fnodes, fvec2, x);
+  stage_bwd<P>(sv, j0 & ~63, m, s2, N, ldx, np, fnodes, fvec2, x);
   __syncthreads();
-  const int j = jlo + (threadIdx.x >> 6);
-  if (j >= s2) return;
-  const int node_j = fnodes[np + (j >> 1)];
-  if (node_j < 0) return;
-  const int lane = threadIdx.x & 63;
-  const double* col = front + foff[f] + (int64_t)j * m;   // column j of the lower part = column j of [L11^-1; Z]
-  double acc[P];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const double* F = front + foff[f];
+  int jq[R];
 #pragma unroll
-  for (int u = 0; u < P; ++u) acc[u] = 0.0;
-  for (int i = j + lane; i < m; i += 64) {
-    const double a = col[i];
-#pragma unroll
-    for (int u = 0; u < P; ++u) acc[u] += a * sv[i * P + u];
+  for (int q = 0; q < R; ++q) {
+    const int j = j0 + wave + NW * q;
+    jq[q] = j < s2 ? j : m;                                   // rows past the owned block: every term masked
   }
+  // the lane that will hold output (q, u) after the reduction looks its node up now, under the matrix loads
+  const int oidx = multi_reduce_index<V>(lane & (V - 1));
+  const int oj = j0 + wave + NW * (oidx / P);
+  const int onode = (lane < V && oj < s2) ? fnodes[np + (oj >> 1)] : -1;
+  double acc[V];
 #pragma unroll
-  for (int u = 0; u < P; ++u) acc[u] = wave_sum(acc[u]);
-  if (lane == 0) {
+  for (int v = 0; v < V; ++v) acc[v] = 0.0;
+  for (int c = (j0 + wave) & ~63; c < m; c += 64 * UNR) {
+    double a[UNR][R];
 #pragma unroll
-    for (int u = 0; u < P; ++u) x[vidx<P>((int64_t)(j & 1) * N + node_j, u, ldx)] = acc[u];
+    for (int t = 0; t < UNR; ++t) {
+      const int i = c + 64 * t + lane;
+#pragma unroll
+      for (int q = 0; q < R; ++q) a[t][q] = (i < m && i >= jq[q]) ? F[i + (int64_t)jq[q] * m] : 0.0;
+    }
+#pragma unroll
+    for (int t = 0; t < UNR; ++t) {
+      const int i = c + 64 * t + lane;
+      if (i < m) {
+#pragma unroll
+        for (int u = 0; u < P; ++u) {
+          const double vi = sv[i * P + u];
+#pragma unroll
+          for (int q = 0; q < R; ++q) acc[q * P + u] += a[t][q] * vi;
+        }
+      }
+    }
   }
+  multi_reduce<V>(acc, lane);
+  if (onode >= 0) x[vidx<P>((int64_t)(oj & 1) * N + onode, oidx % P, ldx)] = acc[0];
 }
 
 // columns (ld) -> interleaved [i][P] and back
@@ -714,7 +830,7 @@ void launch_factor(plfem_ctx* c, double sigma, int stop_level, int stop_step, in
       const bool stop_here = (lev == stop_level && kb == stop_step);
       const int k0 = kb * NB;
       const int max_trail = li.max_m - k0 - 16;   // upper bound of the trailing order after this step
-      hipLaunchKernelGGL(k_ldl_diag, dim3(li.count), dim3(256), 0, st, li.first, kb, c->d_fs2, c->d_fm, c->d_foff,
+      hipLaunchKernelGGL(k_ldl_diag, dim3(li.count, 1 + (k0 + 63) / 64), dim3(64), 0, st, li.first, kb, c->d_fs2, c->d_fm, c->d_foff,
                          c->d_fnode_ptr, c->d_front, c->d_dinv, c->d_delta, c->d_tbuf, c->d_counters);
       if (stop_here && stop_stage == 1) return;
       if (kb > 0)
@@ -767,20 +883,22 @@ static void launch_solve_p(plfem_ctx* c, const double* rhs, double* x, int64_t l
     const LevelInfo& li = c->levels[lev];
     if (li.max_s2 <= 0) continue;
     const size_t lds = sizeof(double) * P * (li.max_m + 1);
-    if (li.count <= DOT_FORM_MAX_FRONTS)
-      hipLaunchKernelGGL(k_bwd_dot<P>, dim3((li.max_s2 + 3) / 4, li.count), dim3(256), lds, st, li.first, c->N, ldx,
-                         c->d_fs2, c->d_fm, c->d_foff, c->d_fnode_ptr, c->d_fnodes, c->d_front, c->d_fvec2, x);
-    else {
-      // optional live timing of this kernel (bench.py roofline): HIP events on the launch stream
-      const bool timed = c->prof_on && c->prof_n < (int)c->prof_ev.size() / 2;
-      if (timed) (void)hipEventRecord(c->prof_ev[2 * c->prof_n], st);
+    // optional live timing of the backward kernel (bench.py roofline): HIP events on the launch stream
+    const bool timed = c->prof_on && li.count > DOT_FORM_MAX_FRONTS && c->prof_n < (int)c->prof_ev.size() / 2;
+    if (timed) (void)hipEventRecord(c->prof_ev[2 * c->prof_n], st);
+    if (lev == c->L)          // leaf fronts (about as many owned rows as boundary columns): tile form
       hipLaunchKernelGGL((k_bwd<P, NW>), dim3((li.max_s2 + 63) / 64, li.count), dim3(NW * 64), lds, st, li.first, c->N, ldx,
                          c->d_fs2, c->d_fm, c->d_foff, c->d_fnode_ptr, c->d_fnodes, c->d_front, c->d_fvec2, x);
-      if (timed) {
-        (void)hipEventRecord(c->prof_ev[2 * c->prof_n + 1], st);
-        c->prof_bytes += li.bwd_bytes + 8.0 * (P - 1) * li.bwd_vec_doubles;
-        ++c->prof_n;
-      }
+    else if (li.count <= DOT_FORM_MAX_FRONTS)   // few large fronts: one row per wave, most blocks
+      hipLaunchKernelGGL((k_bwd_rows<P, 8, 1>), dim3((li.max_s2 + 7) / 8, li.count), dim3(512), lds, st, li.first, c->N, ldx,
+                         c->d_fs2, c->d_fm, c->d_foff, c->d_fnode_ptr, c->d_fnodes, c->d_front, c->d_fvec2, x);
+    else
+      hipLaunchKernelGGL((k_bwd_rows<P, 8, 2>), dim3((li.max_s2 + 15) / 16, li.count), dim3(512), lds, st, li.first, c->N, ldx,
+                         c->d_fs2, c->d_fm, c->d_foff, c->d_fnode_ptr, c->d_fnodes, c->d_front, c->d_fvec2, x);
+    if (timed) {
+      (void)hipEventRecord(c->prof_ev[2 * c->prof_n + 1], st);
+      c->prof_bytes += li.bwd_bytes + 8.0 * (P - 1) * li.bwd_vec_doubles;
+      ++c->prof_n;
     }
   }
 }
