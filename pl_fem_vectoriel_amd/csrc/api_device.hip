@@ -39,8 +39,8 @@ int dalloc(plfem_ctx* c, T** dst, size_t count) {
   return PLFEM_OK;
 }
 
-template <class T>
-int upload(plfem_ctx* c, T** dst, const std::vector<T>& src) {
+template <class T, class A>
+int upload(plfem_ctx* c, T** dst, const std::vector<T, A>& src) {
   int rc = dalloc(c, dst, src.size());
   if (rc != PLFEM_OK) return rc;
   if (c->slab && !src.empty())

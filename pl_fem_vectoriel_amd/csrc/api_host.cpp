@@ -71,6 +71,7 @@ namespace {
 struct ArrayRef { const void* ptr; int64_t bytes; };
 template <class T>
 ArrayRef ref(const std::vector<T>& v) { return {v.data(), (int64_t)(v.size() * sizeof(T))}; }
+ArrayRef ref(const plfem::rawvec_i32& v) { return {v.data(), (int64_t)(v.size() * sizeof(int32_t))}; }
 
 bool lookup(const Symbolic& S, const char* name, ArrayRef& r) {
   std::string n(name ? name : "");

@@ -218,16 +218,16 @@ __global__ __launch_bounds__(64) void k_ldl_diag(int first_front, int kb, const 
 //   T (32 x 16) = L[k, j>=c0] (A: tbuf, contiguous in q) * X<k[j, c] (B: upper mirror, contiguous in c);
 //   the accumulator register r of lane (lr, lk) holds T[lk + 4 r][lr], which is exactly the B operand
 //   of k-step r of the second product  Xnew = -X[k,k] * T  -- no cross-lane movement.
-__global__ __launch_bounds__(256) void k_ldl_invrow(int first_front, int kb, const int32_t* __restrict__ fs2,
-                                                    const int32_t* __restrict__ fm, const int64_t* __restrict__ foff,
-                                                    const int64_t* __restrict__ fnode_ptr, double* __restrict__ front,
-                                                    const double* __restrict__ dinv, const double* __restrict__ tbuf) {
+__device__ __forceinline__ void ldl_invrow_block(int bx, int first_front, int kb, const int32_t* __restrict__ fs2,
+                                                 const int32_t* __restrict__ fm, const int64_t* __restrict__ foff,
+                                                 const int64_t* __restrict__ fnode_ptr, double* __restrict__ front,
+                                                 const double* __restrict__ dinv, const double* __restrict__ tbuf) {
   const int f = first_front + blockIdx.y;
   const int s2 = fs2[f];
   const int k0 = kb * NB;
   if (k0 >= s2 || k0 == 0) return;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int c0 = (blockIdx.x * 4 + wave) * 16;
+  const int c0 = (bx * 4 + wave) * 16;
   if (c0 >= k0) return;
   const int nbk = min(NB, s2 - k0);
   const int m = fm[f];
@@ -279,18 +279,18 @@ __global__ __launch_bounds__(256) void k_ldl_invrow(int first_front, int kb, con
 
 // Panel below the pivot block: Y = R X^T (= R L^-T), W = Y D^-1 (= the L panel).  Saves W, Y for the
 // update kernel and writes W into F (columns of the pivot block) and mirrored (rows).
-__global__ __launch_bounds__(256) void k_ldl_panel(int first_front, int kb, const int32_t* __restrict__ fs2,
-                                                   const int32_t* __restrict__ fm, const int64_t* __restrict__ foff,
-                                                   const int64_t* __restrict__ fnode_ptr, double* __restrict__ front,
-                                                   const double* __restrict__ dinv, const double* __restrict__ delta,
-                                                   double* __restrict__ wbuf, double* __restrict__ rbuf) {
+__device__ __forceinline__ void ldl_panel_block(int bx, int first_front, int kb, const int32_t* __restrict__ fs2,
+                                                const int32_t* __restrict__ fm, const int64_t* __restrict__ foff,
+                                                const int64_t* __restrict__ fnode_ptr, double* __restrict__ front,
+                                                const double* __restrict__ dinv, const double* __restrict__ delta,
+                                                double* __restrict__ wbuf, double* __restrict__ rbuf) {
   const int f = first_front + blockIdx.y;
   const int s2 = fs2[f];
   const int k0 = kb * NB;
   if (k0 >= s2) return;
   const int m = fm[f];
   const int nbk = min(NB, s2 - k0);
-  const int i0 = k0 + nbk + blockIdx.x * 64;
+  const int i0 = k0 + nbk + bx * 64;
   if (i0 >= m) return;
   double* F = front + foff[f];
   const double* D = dinv + (int64_t)f * NB * NB;
@@ -327,6 +327,18 @@ __global__ __launch_bounds__(256) void k_ldl_panel(int first_front, int kb, cons
       F[(int64_t)i * m + (k0 + c)] = w;
     }
   }
+}
+
+// The triangular-inverse update and the panel only depend on the pivot kernel, so one launch runs both:
+// blocks [0, n_inv) of x are invrow blocks, the rest panel blocks.
+__global__ __launch_bounds__(256) void k_ldl_invrow_panel(int n_inv, int first_front, int kb, const int32_t* __restrict__ fs2,
+                                                          const int32_t* __restrict__ fm, const int64_t* __restrict__ foff,
+                                                          const int64_t* __restrict__ fnode_ptr, double* __restrict__ front,
+                                                          const double* __restrict__ dinv, const double* __restrict__ delta,
+                                                          const double* __restrict__ tbuf, double* __restrict__ wbuf,
+                                                          double* __restrict__ rbuf) {
+  if ((int)blockIdx.x < n_inv) ldl_invrow_block(blockIdx.x, first_front, kb, fs2, fm, foff, fnode_ptr, front, dinv, tbuf);
+  else ldl_panel_block(blockIdx.x - n_inv, first_front, kb, fs2, fm, foff, fnode_ptr, front, dinv, delta, wbuf, rbuf);
 }
 
 // Trailing update: F[i,j] -= sum_c W[i,c] Y[j,c] for i, j >= k0 + nbk, one 32x32 tile per wave as 2x2
@@ -810,7 +822,7 @@ __global__ __launch_bounds__(256) void k_deinterleave(int64_t n, const double* _
 
 void launch_factor(plfem_ctx* c, double sigma, int stop_level, int stop_step, int stop_stage) {
   // stop_*: debugging aid (plfem_debug_factor_until); stop_level < 0 = run to completion.
-  // stages: 0 assembled, 1 diag, 2 invrow, 3 panel, 4 update, 5 level done
+  // stages: 0 assembled, 1 diag, 2 or 3 invrow + panel (one launch), 4 update, 5 level done
   hipStream_t st = c->stream;
   (void)hipMemsetAsync(c->d_counters, 0, 4 * sizeof(int32_t), st);
   for (int lev = c->L; lev >= 0; --lev) {
@@ -833,15 +845,16 @@ void launch_factor(plfem_ctx* c, double sigma, int stop_level, int stop_step, in
       hipLaunchKernelGGL(k_ldl_diag, dim3(li.count, 1 + (k0 + 63) / 64), dim3(64), 0, st, li.first, kb, c->d_fs2, c->d_fm, c->d_foff,
                          c->d_fnode_ptr, c->d_front, c->d_dinv, c->d_delta, c->d_tbuf, c->d_counters);
       if (stop_here && stop_stage == 1) return;
-      if (kb > 0)
-        hipLaunchKernelGGL(k_ldl_invrow, dim3((k0 + 63) / 64, li.count), dim3(256), 0, st, li.first, kb, c->d_fs2,
-                           c->d_fm, c->d_foff, c->d_fnode_ptr, c->d_front, c->d_dinv, c->d_tbuf);
-      if (stop_here && stop_stage == 2) return;
+      {
+        const int n_inv = kb > 0 ? (k0 + 63) / 64 : 0;
+        const int n_pan = max_trail > 0 ? (max_trail + 63) / 64 : 0;
+        if (n_inv + n_pan > 0)
+          hipLaunchKernelGGL(k_ldl_invrow_panel, dim3(n_inv + n_pan, li.count), dim3(256), 0, st, n_inv, li.first, kb,
+                             c->d_fs2, c->d_fm, c->d_foff, c->d_fnode_ptr, c->d_front, c->d_dinv, c->d_delta, c->d_tbuf,
+                             c->d_wbuf, c->d_rbuf);
+      }
+      if (stop_here && (stop_stage == 2 || stop_stage == 3)) return;
       if (max_trail > 0) {
-        hipLaunchKernelGGL(k_ldl_panel, dim3((max_trail + 63) / 64, li.count), dim3(256), 0, st, li.first, kb,
-                           c->d_fs2, c->d_fm, c->d_foff, c->d_fnode_ptr, c->d_front, c->d_dinv, c->d_delta, c->d_wbuf,
-                           c->d_rbuf);
-        if (stop_here && stop_stage == 3) return;
         dim3 ug((max_trail + 63) / 64, (max_trail + 63) / 64, li.count);
         hipLaunchKernelGGL(k_ldl_update, ug, dim3(256), 0, st, li.first, kb, c->d_fs2, c->d_fm, c->d_foff,
                            c->d_fnode_ptr, c->d_front, c->d_wbuf, c->d_rbuf);

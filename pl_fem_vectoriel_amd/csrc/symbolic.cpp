@@ -72,7 +72,33 @@ void parallel_for(int64_t n, int nthreads, F f, int64_t min_parallel = 4096) {
   });
 }
 
+// run f(task) for task in [0, ntasks), tasks handed out one at a time (uneven task sizes)
+template <class F>
+void parallel_tasks(int ntasks, int nthreads, F f) {
+  Pool* pool = g_pool;
+  if (nthreads <= 1 || ntasks <= 1 || !pool) {
+    for (int q = 0; q < ntasks; ++q) f(q);
+    return;
+  }
+  std::atomic<int> next{0};
+  pool->run([&](int) {
+    for (int q = next.fetch_add(1, std::memory_order_relaxed); q < ntasks; q = next.fetch_add(1, std::memory_order_relaxed)) f(q);
+  });
+}
+
 inline int pad8(int x) { return (x + 7) & ~7; }
+
+// PLFEM_SYM_TRACE=1: sub-phase wall times of the analysis on stderr (tuning aid)
+struct Trace {
+  bool on = getenv("PLFEM_SYM_TRACE") != nullptr;
+  clk::time_point t = clk::now();
+  void lap(const char* what) {
+    if (!on) return;
+    auto n = clk::now();
+    fprintf(stderr, "[sym] %-22s %8.3f ms\n", what, secs(t, n) * 1e3);
+    t = n;
+  }
+};
 
 // ------------------------------------------------------------------------------------------------
 // P2 numbering, scikit-fem compatible (MeshTri sort_t + build_entities + ElementTriP2 dof layout)
@@ -262,41 +288,53 @@ void nd_tree(Symbolic& S, int leaf_elems, int nthreads) {
   while (L > 0 && ((int64_t)1 << L) > ne) --L;
   S.L = L;
   S.nfronts = (1 << (L + 1)) - 1;
-  std::vector<double> cx(ne), cy(ne);
+  Trace tr;
+  // element centroids and extents along both axes (for counting elements a cut line would straddle)
+  std::vector<double> cx(ne), cy(ne), exlo(ne), exhi(ne), eylo(ne), eyhi(ne);
+  std::vector<int32_t> perm(ne), scratch(ne);
   const double* X = S.doflocs.data();
   const double* Y = X + N;
-  for (int e = 0; e < ne; ++e) {
-    int32_t a = S.tsorted[e], b = S.tsorted[(size_t)ne + e], c = S.tsorted[(size_t)2 * ne + e];
-    cx[e] = (X[a] + X[b] + X[c]) / 3.0;
-    cy[e] = (Y[a] + Y[b] + Y[c]) / 3.0;
-  }
-  // element extents along both axes (for counting elements a cut line would straddle)
-  std::vector<double> exlo(ne), exhi(ne), eylo(ne), eyhi(ne);
-  for (int e = 0; e < ne; ++e) {
-    int32_t a = S.tsorted[e], b = S.tsorted[(size_t)ne + e], c = S.tsorted[(size_t)2 * ne + e];
-    exlo[e] = std::min(X[a], std::min(X[b], X[c])); exhi[e] = std::max(X[a], std::max(X[b], X[c]));
-    eylo[e] = std::min(Y[a], std::min(Y[b], Y[c])); eyhi[e] = std::max(Y[a], std::max(Y[b], Y[c]));
-  }
-  std::vector<int32_t> perm(ne);
-  std::iota(perm.begin(), perm.end(), 0);
+  parallel_for(ne, nthreads, [&](int64_t b_, int64_t e_, int) {
+    for (int64_t e = b_; e < e_; ++e) {
+      int32_t a = S.tsorted[e], b = S.tsorted[(size_t)ne + e], c = S.tsorted[(size_t)2 * ne + e];
+      cx[e] = (X[a] + X[b] + X[c]) / 3.0;
+      cy[e] = (Y[a] + Y[b] + Y[c]) / 3.0;
+      exlo[e] = std::min(X[a], std::min(X[b], X[c])); exhi[e] = std::max(X[a], std::max(X[b], X[c]));
+      eylo[e] = std::min(Y[a], std::min(Y[b], Y[c])); eyhi[e] = std::max(Y[a], std::max(Y[b], Y[c]));
+      perm[e] = (int32_t)e;
+    }
+  });
+  tr.lap("tree: centroids");
   S.leaf_of_elem.resize(ne);
   S.leaf_elem_ptr.assign((size_t)(1 << L) + 1, 0);
   constexpr int NBIN = 512;
-  // Recursive bisection.  Large subdomains: the cut is an axis-parallel line chosen among NBIN-1
-  // candidates per axis to minimise the number of straddled elements (~ separator size) subject to
-  // a balance window; small subdomains: plain median split along the longer extent.
-  std::function<void(int, int, int, int, int)> split = [&](int lo, int hi, int level, int idx, int depth_par) {
-    if (level == L) {
-      S.leaf_elem_ptr[idx] = lo;
-      for (int q = lo; q < hi; ++q) S.leaf_of_elem[perm[q]] = idx;
-      return;
-    }
-    const int n = hi - lo;
+  struct Hist {
     double x0 = 1e300, x1 = -1e300, y0 = 1e300, y1 = -1e300;
-    for (int q = lo; q < hi; ++q) {
-      int e = perm[q];
-      x0 = std::min(x0, cx[e]); x1 = std::max(x1, cx[e]);
-      y0 = std::min(y0, cy[e]); y1 = std::max(y1, cy[e]);
+    int32_t cnt[2][NBIN + 1];
+    int32_t diff[2][NBIN + 2];
+  };
+  // Bisection of perm[lo, hi).  Large subdomains: the cut is an axis-parallel line chosen among NBIN-1
+  // candidates per axis to minimise the number of straddled elements (~ separator size) subject to
+  // a balance window; small subdomains: plain median split along the longer extent.  par: the passes
+  // over the elements run on the pool (top of the tree, where there are fewer nodes than threads).
+  // The result does not depend on par or on the order of perm inside [lo, hi).
+  auto bisect = [&](int lo, int hi, int level, bool par) -> int {
+    const int n = hi - lo;
+    const int nt = (par && g_pool) ? g_pool->nt : 1;
+    std::vector<Hist> hs(nt);
+    auto bbox = [&](int64_t b, int64_t e_, int tid) {
+      Hist& h = hs[tid];
+      for (int64_t q = lo + b; q < lo + e_; ++q) {
+        int e = perm[q];
+        h.x0 = std::min(h.x0, cx[e]); h.x1 = std::max(h.x1, cx[e]);
+        h.y0 = std::min(h.y0, cy[e]); h.y1 = std::max(h.y1, cy[e]);
+      }
+    };
+    if (nt > 1) parallel_for(n, nt, bbox, 1); else bbox(0, n, 0);
+    double x0 = 1e300, x1 = -1e300, y0 = 1e300, y1 = -1e300;
+    for (const Hist& h : hs) {
+      x0 = std::min(x0, h.x0); x1 = std::max(x1, h.x1);
+      y0 = std::min(y0, h.y0); y1 = std::max(y1, h.y1);
     }
     int mid = -1;
     const int remaining = L - level;            // every leaf below must stay non-empty
@@ -307,43 +345,81 @@ void nd_tree(Symbolic& S, int leaf_elems, int nthreads) {
       constexpr double RHO = 2.2;
       const double ideal = (double)ne / (double)((int64_t)2 << level);
       const double clo = ideal / RHO, chi = ideal * RHO;
+      const double a0s[2] = {x0, y0}, a1s[2] = {x1, y1};
+      const double scales[2] = {x1 > x0 ? NBIN / (x1 - x0) : 0.0, y1 > y0 ? NBIN / (y1 - y0) : 0.0};
+      auto hist = [&](int64_t b, int64_t e_, int tid) {
+        Hist& h = hs[tid];
+        std::memset(h.cnt, 0, sizeof(h.cnt));
+        std::memset(h.diff, 0, sizeof(h.diff));
+        for (int axis = 0; axis < 2; ++axis) {
+          const double a0 = a0s[axis], scale = scales[axis];
+          if (!(scale > 0.0)) continue;
+          const double* c = axis ? cy.data() : cx.data();
+          const double* elo = axis ? eylo.data() : exlo.data();
+          const double* ehi = axis ? eyhi.data() : exhi.data();
+          int32_t* cnt = h.cnt[axis];
+          int32_t* diff = h.diff[axis];
+          for (int64_t q = lo + b; q < lo + e_; ++q) {
+            int e = perm[q];
+            int bc = std::min(NBIN - 1, std::max(0, (int)((c[e] - a0) * scale)));
+            cnt[bc]++;
+            // thresholds t_j = a0 + j/scale, j = 1..NBIN-1; the element touches the cut line iff
+            // elo <= t_j <= ehi (closed: a line running along mesh edges still costs its nodes)
+            int j0 = (int)std::ceil((elo[e] - a0) * scale - 1e-9);
+            int j1 = (int)std::floor((ehi[e] - a0) * scale + 1e-9);
+            j0 = std::max(j0, 1); j1 = std::min(j1, NBIN - 1);
+            if (j0 <= j1) { diff[j0]++; diff[j1 + 1]--; }
+          }
+        }
+      };
+      if (nt > 1) parallel_for(n, nt, hist, 1); else hist(0, n, 0);
       double best_cost = 1e300, best_thr = 0;
       int best_axis = -1;
       for (int axis = 0; axis < 2; ++axis) {
-        const double a0 = axis ? y0 : x0, a1 = axis ? y1 : x1;
-        if (!(a1 > a0)) continue;
-        const std::vector<double>& c = axis ? cy : cx;
-        const std::vector<double>& elo = axis ? eylo : exlo;
-        const std::vector<double>& ehi = axis ? eyhi : exhi;
-        const double scale = NBIN / (a1 - a0);
-        int32_t cnt[NBIN + 1] = {0};
-        int32_t diff[NBIN + 2] = {0};
-        for (int q = lo; q < hi; ++q) {
-          int e = perm[q];
-          int bc = std::min(NBIN - 1, std::max(0, (int)((c[e] - a0) * scale)));
-          cnt[bc]++;
-          // thresholds t_j = a0 + j/scale, j = 1..NBIN-1; the element touches the cut line iff
-          // elo <= t_j <= ehi (closed: a line running along mesh edges still costs its nodes)
-          int j0 = (int)std::ceil((elo[e] - a0) * scale - 1e-9);
-          int j1 = (int)std::floor((ehi[e] - a0) * scale + 1e-9);
-          j0 = std::max(j0, 1); j1 = std::min(j1, NBIN - 1);
-          if (j0 <= j1) { diff[j0]++; diff[j1 + 1]--; }
-        }
+        if (!(scales[axis] > 0.0)) continue;
         int64_t below = 0, strad = 0;
         for (int j = 1; j < NBIN; ++j) {
-          below += cnt[j - 1];
-          strad += diff[j];
+          for (int t = 0; t < nt; ++t) {
+            if (t > 0 && (int64_t)t * ((n + nt - 1) / nt) >= n) break;     // chunk never ran: its arrays are stale
+            below += hs[t].cnt[axis][j - 1];
+            strad += hs[t].diff[axis][j];
+          }
           double f = (double)below / n;
           if (below < clo || below > chi || n - below < clo || n - below > chi) continue;
           if (below < min_side || n - below < min_side) continue;
           double cost = (double)strad * (1.0 + 0.5 * std::fabs(f - 0.5));
-          if (cost < best_cost) { best_cost = cost; best_thr = a0 + j / scale; best_axis = axis; }
+          if (cost < best_cost) { best_cost = cost; best_thr = a0s[axis] + j / scales[axis]; best_axis = axis; }
         }
       }
       if (best_axis >= 0) {
-        const std::vector<double>& c = best_axis ? cy : cx;
-        auto it = std::partition(perm.begin() + lo, perm.begin() + hi, [&](int32_t e) { return c[e] < best_thr; });
-        mid = (int)(it - perm.begin());
+        const double* c = best_axis ? cy.data() : cx.data();
+        if (nt > 1) {
+          // stable two-pass partition through scratch
+          std::vector<int64_t> nl(nt + 1, 0);
+          const int64_t chunk = (n + nt - 1) / nt;
+          parallel_for(n, nt, [&](int64_t b, int64_t e_, int tid) {
+            int64_t k = 0;
+            for (int64_t q = lo + b; q < lo + e_; ++q) k += c[perm[q]] < best_thr;
+            nl[tid + 1] = k;
+          }, 1);
+          for (int t = 0; t < nt; ++t) nl[t + 1] += nl[t];
+          const int64_t nleft = nl[nt];
+          parallel_for(n, nt, [&](int64_t b, int64_t e_, int tid) {
+            int64_t wl = lo + nl[tid], wr = lo + nleft + (b - nl[tid]);
+            for (int64_t q = lo + b; q < lo + e_; ++q) {
+              int32_t e = perm[q];
+              if (c[e] < best_thr) scratch[wl++] = e; else scratch[wr++] = e;
+            }
+          }, 1);
+          (void)chunk;
+          parallel_for(n, nt, [&](int64_t b, int64_t e_, int) {
+            std::memcpy(perm.data() + lo + b, scratch.data() + lo + b, sizeof(int32_t) * (size_t)(e_ - b));
+          }, 1);
+          mid = lo + (int)nleft;
+        } else {
+          auto it = std::partition(perm.begin() + lo, perm.begin() + hi, [&](int32_t e) { return c[e] < best_thr; });
+          mid = (int)(it - perm.begin());
+        }
         if (mid - lo < min_side || hi - mid < min_side) mid = -1;
       }
     }
@@ -353,23 +429,43 @@ void nd_tree(Symbolic& S, int leaf_elems, int nthreads) {
       std::nth_element(perm.begin() + lo, perm.begin() + mid, perm.begin() + hi,
                        [&](int32_t a, int32_t b) { return key[a] < key[b] || (key[a] == key[b] && a < b); });
     }
-    if (depth_par > 0 && n > 8192) {
-      std::thread th([&] { split(lo, mid, level + 1, 2 * idx, depth_par - 1); });
-      split(mid, hi, level + 1, 2 * idx + 1, depth_par - 1);
-      th.join();
-    } else {
-      split(lo, mid, level + 1, 2 * idx, 0);
-      split(mid, hi, level + 1, 2 * idx + 1, 0);
-    }
+    return mid;
   };
-  int par_depth = 0;
-  while ((1 << par_depth) < nthreads) ++par_depth;
-  split(0, ne, 0, 0, nthreads > 1 ? par_depth : 0);
+  std::function<void(int, int, int, int)> subtree = [&](int lo, int hi, int level, int idx) {
+    if (level == L) {
+      S.leaf_elem_ptr[idx] = lo;
+      // keep element ids ascending inside every leaf (deterministic assembly order)
+      std::sort(perm.begin() + lo, perm.begin() + hi);
+      for (int q = lo; q < hi; ++q) S.leaf_of_elem[perm[q]] = idx;
+      return;
+    }
+    const int mid = bisect(lo, hi, level, false);
+    subtree(lo, mid, level + 1, 2 * idx);
+    subtree(mid, hi, level + 1, 2 * idx + 1);
+  };
+  // top of the tree breadth-first with pool-parallel passes, then one task per subtree
+  struct Node { int lo, hi, idx; };
+  std::vector<Node> cur{{0, ne, 0}};
+  int level = 0;
+  if (nthreads > 1 && g_pool) {
+    int top = 0;
+    while ((1 << top) < 2 * nthreads) ++top;       // ~2 subtrees per thread, handed out dynamically
+    for (; level < std::min(top, L); ++level) {
+      std::vector<Node> next;
+      next.reserve(2 * cur.size());
+      for (const Node& nd : cur) {
+        const int mid = bisect(nd.lo, nd.hi, level, nd.hi - nd.lo >= 4096);
+        next.push_back({nd.lo, mid, 2 * nd.idx});
+        next.push_back({mid, nd.hi, 2 * nd.idx + 1});
+      }
+      cur.swap(next);
+    }
+  }
+  tr.lap("tree: top levels");
+  parallel_tasks((int)cur.size(), nthreads, [&](int q) { subtree(cur[q].lo, cur[q].hi, level, cur[q].idx); });
+  tr.lap("tree: subtrees");
   S.leaf_elem_ptr[(size_t)1 << L] = ne;
-  S.leaf_elems = perm;
-  // keep element ids ascending inside every leaf (deterministic assembly order)
-  for (int lf = 0; lf < (1 << L); ++lf)
-    std::sort(S.leaf_elems.begin() + S.leaf_elem_ptr[lf], S.leaf_elems.begin() + S.leaf_elem_ptr[lf + 1]);
+  S.leaf_elems = std::move(perm);
 }
 
 inline int bitlen(uint32_t x) {
@@ -383,6 +479,7 @@ std::string build_fronts(Symbolic& S, int nthreads) {
   const std::vector<int32_t>& nadj = S.nadj;
   const int N = S.N, ne = S.ne, L = S.L, nf = S.nfronts;
   // owner front of every non-Dirichlet node = deepest tree node containing all its elements
+  Trace tr;
   S.owner.assign(N, -1);
   bool orphan = false;
   parallel_for(N, nthreads, [&](int64_t b, int64_t e_, int) {
@@ -400,71 +497,96 @@ std::string build_fronts(Symbolic& S, int nthreads) {
     }
   }, 8192);
   if (orphan) return "mesh has a vertex that belongs to no element";
-  // per-front node lists, bottom-up, level by level (fronts of one level are independent).
-  // lists[f] = own (ascending ids) ++ boundary (ascending ids)
-  std::vector<std::vector<int32_t>> own(nf), bnd(nf);
-  std::vector<std::vector<int32_t>> inv0(nf), inv1(nf);   // parent local (unpadded own++bnd) -> child bnd index
-  const int leaf0 = (1 << L) - 1;
-  parallel_for((int64_t)1 << L, nthreads, [&](int64_t b, int64_t e_, int) {
-    std::vector<int32_t> tmp;
-    for (int64_t lf = b; lf < e_; ++lf) {
-      int f = leaf0 + (int)lf;
-      tmp.clear();
-      for (int32_t q = S.leaf_elem_ptr[lf]; q < S.leaf_elem_ptr[lf + 1]; ++q) {
-        int32_t e = S.leaf_elems[q];
-        for (int a = 0; a < 6; ++a) {
-          int32_t i = S.edof[(size_t)a * ne + e];
-          if (!S.bmask[i]) tmp.push_back(i);
+  tr.lap("fronts: owner");
+  // Per-front node lists, bottom-up, level by level (fronts of one level are independent):
+  // own (ascending ids) and boundary (ascending ids).  One flat buffer per level and list, front q of the
+  // level owning the slot [off[q], off[q+1]) sized by an upper bound (6 nodes per leaf element; the two
+  // children's boundary lists for an internal front), so no per-front heap allocation.
+  struct LevelBuf {
+    std::vector<int64_t> off;
+    rawvec_i32 own, bnd, o0, o1, c0, c1;     // o*/c*: index in child 0/1's boundary list of each own / boundary node
+  };
+  std::vector<LevelBuf> lv(L + 1);
+  S.fs.resize(nf); S.fb.resize(nf); S.fs_true.resize(nf); S.fb_true.resize(nf);
+  const int leaf0 = (1 << L) - 1, nleaf = 1 << L;
+  {
+    LevelBuf& lb = lv[L];
+    lb.off.assign((size_t)nleaf + 1, 0);
+    for (int lf = 0; lf < nleaf; ++lf) lb.off[lf + 1] = lb.off[lf] + 6 * (int64_t)(S.leaf_elem_ptr[lf + 1] - S.leaf_elem_ptr[lf]);
+    lb.own.resize(lb.off[nleaf]);
+    lb.bnd.resize(lb.off[nleaf]);
+    parallel_for(nleaf, nthreads, [&](int64_t b, int64_t e_, int) {
+      std::vector<int32_t> tmp;
+      for (int64_t lf = b; lf < e_; ++lf) {
+        const int f = leaf0 + (int)lf;
+        tmp.clear();
+        for (int32_t q = S.leaf_elem_ptr[lf]; q < S.leaf_elem_ptr[lf + 1]; ++q) {
+          int32_t e = S.leaf_elems[q];
+          for (int a = 0; a < 6; ++a) {
+            int32_t i = S.edof[(size_t)a * ne + e];
+            if (!S.bmask[i]) tmp.push_back(i);
+          }
         }
+        std::sort(tmp.begin(), tmp.end());
+        tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
+        int32_t* ow = lb.own.data() + lb.off[lf];
+        int32_t* bd = lb.bnd.data() + lb.off[lf];
+        int no = 0, nb = 0;
+        for (int32_t i : tmp) {
+          if (S.owner[i] == f) ow[no++] = i; else bd[nb++] = i;
+        }
+        S.fs_true[f] = no;
+        S.fb_true[f] = nb;
       }
-      std::sort(tmp.begin(), tmp.end());
-      tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
-      own[f].reserve(tmp.size());
-      bnd[f].reserve(tmp.size());
-      for (int32_t i : tmp) (S.owner[i] == f ? own[f] : bnd[f]).push_back(i);
-    }
-  }, 64);
+    }, 64);
+  }
+  tr.lap("fronts: leaves");
   for (int lev = L - 1; lev >= 0; --lev) {
-    const int first = (1 << lev) - 1;
-    parallel_for((int64_t)1 << lev, nthreads, [&](int64_t b, int64_t e_, int) {
+    const int first = (1 << lev) - 1, n = 1 << lev;
+    LevelBuf& pb = lv[lev];
+    const LevelBuf& cb = lv[lev + 1];
+    pb.off.assign((size_t)n + 1, 0);
+    for (int q = 0; q < n; ++q) {
+      const int f = first + q;
+      pb.off[q + 1] = pb.off[q] + S.fb_true[2 * f + 1] + S.fb_true[2 * f + 2];
+    }
+    const int64_t cap = pb.off[n];
+    pb.own.resize(cap); pb.bnd.resize(cap); pb.o0.resize(cap); pb.o1.resize(cap); pb.c0.resize(cap); pb.c1.resize(cap);
+    parallel_for(n, nthreads, [&](int64_t b, int64_t e_, int) {
       for (int64_t q = b; q < e_; ++q) {
         const int f = first + (int)q;
-        const auto& b0 = bnd[2 * f + 1];
-        const auto& b1 = bnd[2 * f + 2];
-        const size_t cap = b0.size() + b1.size();
-        std::vector<int32_t> bn, o0, o1, c0, c1;
-        bn.reserve(cap); c0.reserve(cap); c1.reserve(cap);
-        size_t i0 = 0, i1 = 0;
-        while (i0 < b0.size() || i1 < b1.size()) {     // merge the two ascending boundary lists
+        const int32_t* b0 = cb.bnd.data() + cb.off[2 * q];
+        const int32_t* b1 = cb.bnd.data() + cb.off[2 * q + 1];
+        const int n0 = S.fb_true[2 * f + 1], n1 = S.fb_true[2 * f + 2];
+        const int64_t o = pb.off[q];
+        int32_t *ow = pb.own.data() + o, *bd = pb.bnd.data() + o;
+        int32_t *o0 = pb.o0.data() + o, *o1 = pb.o1.data() + o, *c0 = pb.c0.data() + o, *c1 = pb.c1.data() + o;
+        int no = 0, nb = 0, i0 = 0, i1 = 0;
+        while (i0 < n0 || i1 < n1) {     // merge the two ascending boundary lists
           int32_t v, p0 = -1, p1 = -1;
-          if (i1 >= b1.size() || (i0 < b0.size() && b0[i0] < b1[i1])) { v = b0[i0]; p0 = (int32_t)i0++; }
-          else if (i0 >= b0.size() || b1[i1] < b0[i0]) { v = b1[i1]; p1 = (int32_t)i1++; }
-          else { v = b0[i0]; p0 = (int32_t)i0++; p1 = (int32_t)i1++; }
-          if (S.owner[v] == f) { own[f].push_back(v); o0.push_back(p0); o1.push_back(p1); }
-          else { bn.push_back(v); c0.push_back(p0); c1.push_back(p1); }
+          if (i1 >= n1 || (i0 < n0 && b0[i0] < b1[i1])) { v = b0[i0]; p0 = i0++; }
+          else if (i0 >= n0 || b1[i1] < b0[i0]) { v = b1[i1]; p1 = i1++; }
+          else { v = b0[i0]; p0 = i0++; p1 = i1++; }
+          if (S.owner[v] == f) { ow[no] = v; o0[no] = p0; o1[no] = p1; ++no; }
+          else { bd[nb] = v; c0[nb] = p0; c1[nb] = p1; ++nb; }
         }
-        bnd[f] = std::move(bn);
-        o0.insert(o0.end(), c0.begin(), c0.end());
-        o1.insert(o1.end(), c1.begin(), c1.end());
-        inv0[f] = std::move(o0);
-        inv1[f] = std::move(o1);
+        S.fs_true[f] = no;
+        S.fb_true[f] = nb;
       }
     }, 2);
   }
-  if (!bnd[0].empty()) return "internal error: root front has boundary nodes";
+  tr.lap("fronts: levels");
+  if (S.fb_true[0] != 0) return "internal error: root front has boundary nodes";
   {
     int64_t tot = 0;
-    for (int f = 0; f < nf; ++f) tot += (int64_t)own[f].size();
+    for (int f = 0; f < nf; ++f) tot += S.fs_true[f];
     if (tot != S.nsolve) return "internal error: owned nodes do not partition the interior DOFs";
   }
   // flatten with padding to multiples of 8 nodes (16 DOFs)
-  S.fs.resize(nf); S.fb.resize(nf); S.fs_true.resize(nf); S.fb_true.resize(nf);
   S.fnode_ptr.assign((size_t)nf + 1, 0);
   S.foff.assign((size_t)nf + 1, 0);
   S.factor_flops = 0; S.solve_entries = 0; S.max_m = 0;
   for (int f = 0; f < nf; ++f) {
-    S.fs_true[f] = (int32_t)own[f].size();
-    S.fb_true[f] = (int32_t)bnd[f].size();
     S.fs[f] = pad8(S.fs_true[f]);
     S.fb[f] = pad8(S.fb_true[f]);
     int64_t mn = S.fs[f] + S.fb[f];
@@ -476,38 +598,54 @@ std::string build_fronts(Symbolic& S, int nthreads) {
     S.max_m = std::max<int>(S.max_m, (int)m);
   }
   const int64_t tot = S.fnode_ptr[nf];
-  S.fnodes.assign(tot, -1);
-  S.cinv0.assign(tot, -1);
-  S.cinv1.assign(tot, -1);
-  S.epos.assign((size_t)6 * ne, -1);
-  parallel_for(nf, nthreads, [&](int64_t b, int64_t e_, int) {
-    for (int64_t f = b; f < e_; ++f) {
+  S.fnodes.resize(tot);                  // uninitialised: every entry (padding included) is written below
+  S.cinv0.resize(tot);
+  S.cinv1.resize(tot);
+  S.epos.resize((size_t)6 * ne);
+  auto put = [](int32_t* dst, const int32_t* src, int count, int padded) {
+    if (src) std::copy(src, src + count, dst);
+    else std::fill(dst, dst + count, -1);
+    std::fill(dst + count, dst + padded, -1);
+  };
+  constexpr int FB = 32;                 // fronts per task
+  parallel_tasks((nf + FB - 1) / FB, nthreads, [&](int task) {
+    for (int f = task * FB; f < std::min(nf, (task + 1) * FB); ++f) {
+      const int level = bitlen((uint32_t)f + 1) - 1;
+      const int64_t q = f - ((1 << level) - 1);
+      const LevelBuf& b = lv[level];
+      const int64_t o = b.off[q];
+      const int no = S.fs_true[f], nb = S.fb_true[f], fs = S.fs[f], fb = S.fb[f];
       int32_t* fn = S.fnodes.data() + S.fnode_ptr[f];
-      std::copy(own[f].begin(), own[f].end(), fn);
-      std::copy(bnd[f].begin(), bnd[f].end(), fn + S.fs[f]);
-      if (f < leaf0) {
-        int32_t* c0 = S.cinv0.data() + S.fnode_ptr[f];
-        int32_t* c1 = S.cinv1.data() + S.fnode_ptr[f];
-        const int so = S.fs_true[f];
-        for (int q = 0; q < so; ++q) { c0[q] = inv0[f][q]; c1[q] = inv1[f][q]; }
-        for (int q = 0; q < S.fb_true[f]; ++q) { c0[S.fs[f] + q] = inv0[f][so + q]; c1[S.fs[f] + q] = inv1[f][so + q]; }
-      } else {
+      int32_t* c0 = S.cinv0.data() + S.fnode_ptr[f];
+      int32_t* c1 = S.cinv1.data() + S.fnode_ptr[f];
+      put(fn, b.own.data() + o, no, fs);
+      put(fn + fs, b.bnd.data() + o, nb, fb);
+      const bool leaf = f >= leaf0;
+      put(c0, leaf ? nullptr : b.o0.data() + o, no, fs);
+      put(c0 + fs, leaf ? nullptr : b.c0.data() + o, nb, fb);
+      put(c1, leaf ? nullptr : b.o1.data() + o, no, fs);
+      put(c1 + fs, leaf ? nullptr : b.c1.data() + o, nb, fb);
+      if (leaf) {
         // element node positions inside their leaf front (binary search in the two ascending lists)
-        const int lf = (int)f - leaf0;
-        for (int32_t q = S.leaf_elem_ptr[lf]; q < S.leaf_elem_ptr[lf + 1]; ++q) {
-          int32_t e = S.leaf_elems[q];
+        const int lf = f - leaf0;
+        const int32_t* ow = b.own.data() + o;
+        const int32_t* bd = b.bnd.data() + o;
+        for (int32_t qe = S.leaf_elem_ptr[lf]; qe < S.leaf_elem_ptr[lf + 1]; ++qe) {
+          int32_t e = S.leaf_elems[qe];
           for (int a = 0; a < 6; ++a) {
             int32_t i = S.edof[(size_t)a * ne + e];
-            if (S.bmask[i]) continue;
-            int32_t pos;
-            if (S.owner[i] == (int)f) pos = (int32_t)(std::lower_bound(own[f].begin(), own[f].end(), i) - own[f].begin());
-            else pos = S.fs[f] + (int32_t)(std::lower_bound(bnd[f].begin(), bnd[f].end(), i) - bnd[f].begin());
+            int32_t pos = -1;
+            if (!S.bmask[i]) {
+              if (S.owner[i] == f) pos = (int32_t)(std::lower_bound(ow, ow + no, i) - ow);
+              else pos = fs + (int32_t)(std::lower_bound(bd, bd + nb, i) - bd);
+            }
             S.epos[(size_t)a * ne + e] = pos;
           }
         }
       }
     }
-  }, 64);
+  });
+  tr.lap("fronts: flatten");
   return "";
 }
 

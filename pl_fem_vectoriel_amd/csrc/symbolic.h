@@ -10,10 +10,25 @@
 //     complete binary tree of dense frontal matrices.
 #pragma once
 #include <cstdint>
+#include <memory>
 #include <string>
 #include <vector>
 
 namespace plfem {
+
+// std::vector whose resize() leaves the new elements uninitialised: the big index arrays of the front
+// tree are filled in parallel, and a value-initialising resize would first touch every page serially.
+template <class T>
+struct default_init_allocator : std::allocator<T> {
+  template <class U>
+  struct rebind { using other = default_init_allocator<U>; };
+  using std::allocator<T>::allocator;
+  template <class U>
+  void construct(U* ptr) noexcept { ::new (static_cast<void*>(ptr)) U; }
+  template <class U, class... Args>
+  void construct(U* ptr, Args&&... args) { ::new (static_cast<void*>(ptr)) U(std::forward<Args>(args)...); }
+};
+using rawvec_i32 = std::vector<int32_t, default_init_allocator<int32_t>>;
 
 struct Symbolic {
   // ---- mesh / P2 numbering (scikit-fem compatible) ------------------------------------------
@@ -39,12 +54,12 @@ struct Symbolic {
   std::vector<int32_t> leaf_of_elem;   // [ne]
   std::vector<int32_t> leaf_elem_ptr;  // [2^L + 1]
   std::vector<int32_t> leaf_elems;     // [ne] element ids grouped by leaf
-  std::vector<int32_t> epos;           // [6][ne] local node index of each element node in its leaf front, -1 = Dirichlet
+  rawvec_i32 epos;                     // [6][ne] local node index of each element node in its leaf front, -1 = Dirichlet
   std::vector<int32_t> fs, fb;         // [nfronts] padded (multiple of 8) counts of owned / boundary nodes
   std::vector<int32_t> fs_true, fb_true;
   std::vector<int64_t> fnode_ptr;      // [nfronts+1] offsets into fnodes/cinv*
-  std::vector<int32_t> fnodes;         // node (scalar DOF) id per local node, -1 = padding
-  std::vector<int32_t> cinv0, cinv1;   // per local node of an internal front: index in child's boundary list or -1
+  rawvec_i32 fnodes;                   // node (scalar DOF) id per local node, -1 = padding
+  rawvec_i32 cinv0, cinv1;             // per local node of an internal front: index in child's boundary list or -1
   std::vector<int64_t> foff;           // [nfronts+1] offsets (in doubles) of the dense front matrices, m = 2(fs+fb)
   std::vector<int32_t> owner;          // [N] front that eliminates the node, -1 for Dirichlet nodes
   // statistics
