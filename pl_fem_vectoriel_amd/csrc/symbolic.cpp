@@ -110,15 +110,20 @@ std::string p2_numbering(int nv, int ne, const double* p, const int32_t* t, Symb
   int32_t* t0 = S.tsorted.data();
   int32_t* t1 = t0 + ne;
   int32_t* t2 = t1 + ne;
-  for (int e = 0; e < ne; ++e) {
-    int32_t a = t[e], b = t[ne + e], c = t[2 * (size_t)ne + e];
-    if (a < 0 || b < 0 || c < 0 || a >= nv || b >= nv || c >= nv) return "mesh.t refers to a vertex outside mesh.p";
-    if (a > b) std::swap(a, b);
-    if (b > c) std::swap(b, c);
-    if (a > b) std::swap(a, b);
-    if (a == b || b == c) return "degenerate element (repeated vertex)";
-    t0[e] = a; t1[e] = b; t2[e] = c;
-  }
+  std::atomic<int> bad_t{0};
+  parallel_for(ne, g_pool ? g_pool->nt : 1, [&](int64_t eb_, int64_t ee_, int) {
+    for (int64_t e = eb_; e < ee_; ++e) {
+      int32_t a = t[e], b = t[ne + e], c = t[2 * (size_t)ne + e];
+      if (a < 0 || b < 0 || c < 0 || a >= nv || b >= nv || c >= nv) { bad_t.store(1); continue; }
+      if (a > b) std::swap(a, b);
+      if (b > c) std::swap(b, c);
+      if (a > b) std::swap(a, b);
+      if (a == b || b == c) { bad_t.store(2); continue; }
+      t0[e] = a; t1[e] = b; t2[e] = c;
+    }
+  });
+  if (bad_t.load() == 1) return "mesh.t refers to a vertex outside mesh.p";
+  if (bad_t.load() == 2) return "degenerate element (repeated vertex)";
   // edges bucketed by their smaller vertex: local edges (0,1),(1,2),(0,2) -> (t0,t1),(t1,t2),(t0,t2)
   std::vector<int32_t> cnt((size_t)nv + 1, 0);
   for (int e = 0; e < ne; ++e) { cnt[t0[e] + 1] += 2; cnt[t1[e] + 1] += 1; }
@@ -250,7 +255,7 @@ void csr_pattern(Symbolic& S, int nthreads) {
   std::vector<int64_t> soff((size_t)N + 1);
   soff[0] = 0;
   for (int i = 0; i < N; ++i) soff[i + 1] = soff[i] + 6 * (int64_t)(nptr[i + 1] - nptr[i]);
-  std::vector<int32_t> scratch((size_t)soff[N]);
+  rawvec_i32 scratch((size_t)soff[N]);
   S.rowptr.assign((size_t)N + 1, 0);
   parallel_for(N, nthreads, [&](int64_t b, int64_t e_, int) {
     for (int64_t i = b; i < e_; ++i) {

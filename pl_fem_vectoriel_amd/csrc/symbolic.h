@@ -42,8 +42,8 @@ struct Symbolic {
   std::vector<int32_t> int_index;  // [N] DOF -> interior index or -1
   // ---- scalar CSR pattern (full N x N, shared by every block of A and B) ----------------------
   std::vector<int32_t> rowptr;     // [N+1]
-  std::vector<int32_t> colind;     // [nnz]
-  std::vector<int32_t> slot_row;   // [nnz] row of every CSR slot
+  rawvec_i32 colind;               // [nnz]
+  rawvec_i32 slot_row;             // [nnz] row of every CSR slot
   // node -> adjacent elements (ascending element ids): the contributions to row i come from these
   std::vector<int32_t> nptr;       // [N+1]
   std::vector<int32_t> nadj;       // [6 ne] element id
