@@ -182,11 +182,11 @@ int plfem_timings(plfem_ctx* ctx, double* out_host /* [8] */);
 
 /* ---------------------------------------------------------------------------------------------
  * Live timing of the dominant kernel (bench.py "roofline"; no reference counterpart): between
- * begin and end every launch of the tile-form backward-sweep kernel (k_bwd, the largest single
+ * begin and end every launch of the tile-form forward-sweep kernel (k_fwd, the largest single
  * consumer of GPU time in a solve) is bracketed by HIP events on the context's stream.
  * out_host[3] = { launches timed, total microseconds, total algorithmic bytes of those launches }
  * with algorithmic bytes of one launch = 8 B x sum over the level's fronts of
- * (s2 m - s2^2/2 + m + s2): the entries of [L11^-T | Z^T] read once + staged vector + result.
+ * (s2 m - s2^2/2 + P (m + s2)): the entries of [L11^-1 ; Z] read once + P staged / written vectors.
  * ------------------------------------------------------------------------------------------- */
 int plfem_profile_begin(plfem_ctx* ctx, int32_t max_launches);
 int plfem_profile_end(plfem_ctx* ctx, double* out_host /* [3] */);

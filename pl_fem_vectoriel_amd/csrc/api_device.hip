@@ -206,10 +206,10 @@ int create_impl(plfem_ctx* c, const plfem_symbolic* sym, int device, void* strea
       li.max_m = std::max(li.max_m, fm[f]);
       li.max_s2 = std::max(li.max_s2, fs2[f]);
       li.max_b2 = std::max(li.max_b2, fm[f] - fs2[f]);
-      // backward sweep of one front: columns i in [j, m) for every owned row j of [L11^-T | Z^T], the staged
-      // vector (m) and the owned part of the solution (s2)
-      li.bwd_bytes += 8.0 * ((double)fs2[f] * fm[f] - 0.5 * (double)fs2[f] * fs2[f] + fm[f] + fs2[f]);
-      li.bwd_vec_doubles += fm[f] + fs2[f];
+      // one sweep over a front reads the s2 (s2 + 1) / 2 + s2 b2 entries of [L11^-1 ; Z] once, stages s2 (forward)
+      // or m (backward) vector entries and writes m (forward) or s2 (backward)
+      li.sweep_bytes += 8.0 * ((double)fs2[f] * fm[f] - 0.5 * (double)fs2[f] * fs2[f] + fm[f] + fs2[f]);
+      li.sweep_vec_doubles += fm[f] + fs2[f];
     }
     if (li.count > 65535) { c->err = "front tree level exceeds the launch grid limit"; return PLFEM_EINVAL; }
   }
@@ -478,8 +478,56 @@ static int lanczos_block(plfem_ctx* c, int k, int ncv, double tol, int maxiter, 
   const int first_new_col = 0;
   (void)first_new_col;
   int cstart = 0;                 // first column computed in the current cycle
+  // Ritz values / residuals of the projected matrix of order mm_ (a multiple of P); fills theta, Svec, order
+  auto ritz_check = [&](int mm_) -> int {
+    int rc = check_launch(c, "block lanczos step");
+    if (rc != PLFEM_OK) return rc;
+    HIP_TRY(c, hipMemcpyAsync(hH, c->d_Hcols, sizeof(double) * ld * ld, hipMemcpyDeviceToHost, st));
+    int32_t* hc = reinterpret_cast<int32_t*>(c->h_pinned + 4096);
+    HIP_TRY(c, hipMemcpyAsync(hc, c->d_counters, sizeof(int32_t) * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipStreamSynchronize(st));
+    if (hc[2] != 0) { c->err = "block Lanczos: rank-deficient block (Krylov space exhausted)"; return PLFEM_ESINGULAR; }
+    for (int j = cstart; j < mm_; ++j)
+      for (int i = 0; i < ld; ++i) T[(size_t)j * ld + i] = hH[(size_t)j * ld + i];
+    // symmetric mm x mm projected matrix from the upper triangle
+    Tm.assign((size_t)mm_ * mm_, 0.0);
+    for (int j = 0; j < mm_; ++j)
+      for (int i = 0; i <= j; ++i) {
+        double v = T[(size_t)j * ld + i];
+        if (!std::isfinite(v)) { c->err = "block Lanczos breakdown: non-finite projected matrix"; return PLFEM_ESINGULAR; }
+        Tm[(size_t)j * mm_ + i] = v;
+        Tm[(size_t)i * mm_ + j] = v;
+      }
+    tridiag_eigh(mm_, Tm, Svec, theta);
+    order.resize(mm_);
+    std::iota(order.begin(), order.end(), 0);
+    std::sort(order.begin(), order.end(), [&](int a, int b) { return std::fabs(theta[a]) > std::fabs(theta[b]); });
+    // residual of Ritz pair i: || R_m S[mm-P:mm, i] ||, R_m = T[mm:mm+P, mm-P:mm] (upper triangular)
+    auto resid = [&](int id) {
+      double r2 = 0.0;
+      for (int a = 0; a < P; ++a) {
+        double v = 0.0;
+        for (int b = a; b < P; ++b) v += T[(size_t)(mm_ - P + b) * ld + (mm_ + a)] * Svec[(size_t)id * mm_ + (mm_ - P + b)];
+        r2 += v * v;
+      }
+      return std::sqrt(r2);
+    };
+    nconv = 0;
+    max_rel_res = 0.0;
+    for (int q = 0; q < k; ++q) {
+      int id = order[q];
+      double rel = resid(id) / std::max(std::fabs(theta[id]), 3.7e-11);
+      max_rel_res = std::max(max_rel_res, rel);
+      if (rel <= tol) ++nconv;
+    }
+    return PLFEM_OK;
+  };
+  // PLFEM_LANCZOS_CHECK=j (tuning aid): also test convergence every j block steps inside a cycle.  Off by
+  // default: each test is a stream synchronisation plus a dense eigensolve on the host.
+  static const int check_every = getenv("PLFEM_LANCZOS_CHECK") ? atoi(getenv("PLFEM_LANCZOS_CHECK")) : 0;
   while (true) {
     cstart = c0;
+    bool early = false;
     while (c0 + P <= m) {
       const int nc = c0 + P;
       plfem::launch_solve_block(c, c->d_BV + (size_t)c0 * n, c->d_w, n);       // W = OP V_j
@@ -495,47 +543,14 @@ static int lanczos_block(plfem_ctx* c, int k, int ncv, double tol, int maxiter, 
       plfem::launch_chol_block(c, c->d_G, P, Hblk + nc, ld, c->d_Rinv);         // R -> T[nc:nc+P, c0:c0+P]
       plfem::launch_block_scale(c, c->d_w, c->d_bw, n, c->d_Rinv, c->d_V + (size_t)nc * n, c->d_BV + (size_t)nc * n, n);
       c0 = nc;
+      if (check_every > 0 && c0 + P <= m && c0 >= k + P && ((c0 / P) % check_every) == 0) {
+        TRY(ritz_check(c0));
+        cstart = c0;
+        if (nconv >= k) { early = true; break; }
+      }
     }
     mm = c0;
-    TRY(check_launch(c, "block lanczos step"));
-    HIP_TRY(c, hipMemcpyAsync(hH, c->d_Hcols, sizeof(double) * ld * ld, hipMemcpyDeviceToHost, st));
-    int32_t* hc = reinterpret_cast<int32_t*>(c->h_pinned + 4096);
-    HIP_TRY(c, hipMemcpyAsync(hc, c->d_counters, sizeof(int32_t) * 4, hipMemcpyDeviceToHost, st));
-    HIP_TRY(c, hipStreamSynchronize(st));
-    if (hc[2] != 0) { c->err = "block Lanczos: rank-deficient block (Krylov space exhausted)"; return PLFEM_ESINGULAR; }
-    for (int j = cstart; j < mm; ++j)
-      for (int i = 0; i < ld; ++i) T[(size_t)j * ld + i] = hH[(size_t)j * ld + i];
-    // symmetric mm x mm projected matrix from the upper triangle
-    Tm.assign((size_t)mm * mm, 0.0);
-    for (int j = 0; j < mm; ++j)
-      for (int i = 0; i <= j; ++i) {
-        double v = T[(size_t)j * ld + i];
-        if (!std::isfinite(v)) { c->err = "block Lanczos breakdown: non-finite projected matrix"; return PLFEM_ESINGULAR; }
-        Tm[(size_t)j * mm + i] = v;
-        Tm[(size_t)i * mm + j] = v;
-      }
-    tridiag_eigh(mm, Tm, Svec, theta);
-    order.resize(mm);
-    std::iota(order.begin(), order.end(), 0);
-    std::sort(order.begin(), order.end(), [&](int a, int b) { return std::fabs(theta[a]) > std::fabs(theta[b]); });
-    // residual of Ritz pair i: || R_m S[mm-P:mm, i] ||, R_m = T[mm:mm+P, mm-P:mm] (upper triangular)
-    auto resid = [&](int id) {
-      double r2 = 0.0;
-      for (int a = 0; a < P; ++a) {
-        double v = 0.0;
-        for (int b = a; b < P; ++b) v += T[(size_t)(mm - P + b) * ld + (mm + a)] * Svec[(size_t)id * mm + (mm - P + b)];
-        r2 += v * v;
-      }
-      return std::sqrt(r2);
-    };
-    nconv = 0;
-    max_rel_res = 0.0;
-    for (int q = 0; q < k; ++q) {
-      int id = order[q];
-      double rel = resid(id) / std::max(std::fabs(theta[id]), 3.7e-11);
-      max_rel_res = std::max(max_rel_res, rel);
-      if (rel <= tol) ++nconv;
-    }
+    if (!early) TRY(ritz_check(mm));
     if (nconv >= k || restarts >= maxiter) { done = nconv >= k; break; }
     int pk = k + std::min(nconv, (mm - k) / 2);
     pk = std::max(pk, k + (mm - k) / 4);

@@ -22,8 +22,8 @@ struct LevelInfo {
   int max_m = 0;    // DOFs
   int max_s2 = 0;
   int max_b2 = 0;
-  double bwd_bytes = 0;   // algorithmic bytes one k_bwd / k_bwd_dot launch of this level moves (1 rhs)
-  double bwd_vec_doubles = 0;   // vector doubles (staged + written) per rhs of that launch
+  double sweep_bytes = 0;   // algorithmic bytes one forward (or backward) sweep launch of this level moves (1 rhs)
+  double sweep_vec_doubles = 0;   // vector doubles (staged + written) per rhs of that launch
 };
 
 }  // namespace plfem

@@ -878,7 +878,6 @@ static void launch_solve_p(plfem_ctx* c, const double* rhs, double* x, int64_t l
   else
     for (int u = 0; u < P; ++u) (void)hipMemsetAsync(x + (int64_t)u * ldx, 0, sizeof(double) * c->n2, st);
   constexpr int DOT_FORM_MAX_FRONTS = 32;   // levels with at most this many fronts use the dot-form kernels
-  constexpr int NW = (P == 1) ? 4 : 8;      // waves per tile-form block: the P-fold LDS vector serves more waves
   for (int lev = c->L; lev >= 0; --lev) {
     const LevelInfo& li = c->levels[lev];
     const int leaf = lev == c->L ? 1 : 0;
@@ -887,20 +886,28 @@ static void launch_solve_p(plfem_ctx* c, const double* rhs, double* x, int64_t l
       hipLaunchKernelGGL(k_fwd_dot<P>, dim3((li.max_m + 3) / 4, li.count), dim3(256), lds, st, li.first, c->N, ldx, leaf,
                          c->d_fs2, c->d_fm, c->d_foff, c->d_fnode_ptr, c->d_fnodes, c->d_cinv0, c->d_cinv1, c->d_front,
                          c->d_delta, rhs, c->d_fvec, c->d_fvec2);
-    else
-      hipLaunchKernelGGL((k_fwd<P, NW>), dim3((li.max_m + 63) / 64, li.count), dim3(NW * 64), lds, st, li.first, c->N, ldx, leaf,
+    else {
+      // optional live timing of this kernel (bench.py roofline): HIP events on the launch stream
+      const bool timed = c->prof_on && c->prof_n < (int)c->prof_ev.size() / 2;
+      if (timed) (void)hipEventRecord(c->prof_ev[2 * c->prof_n], st);
+      hipLaunchKernelGGL((k_fwd<P, 4>), dim3((li.max_m + 63) / 64, li.count), dim3(256), lds, st, li.first, c->N, ldx, leaf,
                          c->d_fs2, c->d_fm, c->d_foff, c->d_fnode_ptr, c->d_fnodes, c->d_cinv0, c->d_cinv1, c->d_front,
                          c->d_delta, rhs, c->d_fvec, c->d_fvec2);
+      if (timed) {
+        (void)hipEventRecord(c->prof_ev[2 * c->prof_n + 1], st);
+        c->prof_bytes += li.sweep_bytes + 8.0 * (P - 1) * li.sweep_vec_doubles;
+        ++c->prof_n;
+      }
+    }
   }
   for (int lev = 0; lev <= c->L; ++lev) {
     const LevelInfo& li = c->levels[lev];
     if (li.max_s2 <= 0) continue;
     const size_t lds = sizeof(double) * P * (li.max_m + 1);
-    // optional live timing of the backward kernel (bench.py roofline): HIP events on the launch stream
-    const bool timed = c->prof_on && li.count > DOT_FORM_MAX_FRONTS && c->prof_n < (int)c->prof_ev.size() / 2;
-    if (timed) (void)hipEventRecord(c->prof_ev[2 * c->prof_n], st);
+    // measured at C1 (P = 4): 8 waves per block in every backward form, 2 rows per wave at the mid levels;
+    // the forward tile kernel is best with 4 waves (scripts/gpu_trace_levels.sh prints the per-level table)
     if (lev == c->L)          // leaf fronts (about as many owned rows as boundary columns): tile form
-      hipLaunchKernelGGL((k_bwd<P, NW>), dim3((li.max_s2 + 63) / 64, li.count), dim3(NW * 64), lds, st, li.first, c->N, ldx,
+      hipLaunchKernelGGL((k_bwd<P, 8>), dim3((li.max_s2 + 63) / 64, li.count), dim3(512), lds, st, li.first, c->N, ldx,
                          c->d_fs2, c->d_fm, c->d_foff, c->d_fnode_ptr, c->d_fnodes, c->d_front, c->d_fvec2, x);
     else if (li.count <= DOT_FORM_MAX_FRONTS)   // few large fronts: one row per wave, most blocks
       hipLaunchKernelGGL((k_bwd_rows<P, 8, 1>), dim3((li.max_s2 + 7) / 8, li.count), dim3(512), lds, st, li.first, c->N, ldx,
@@ -908,11 +915,6 @@ static void launch_solve_p(plfem_ctx* c, const double* rhs, double* x, int64_t l
     else
       hipLaunchKernelGGL((k_bwd_rows<P, 8, 2>), dim3((li.max_s2 + 15) / 16, li.count), dim3(512), lds, st, li.first, c->N, ldx,
                          c->d_fs2, c->d_fm, c->d_foff, c->d_fnode_ptr, c->d_fnodes, c->d_front, c->d_fvec2, x);
-    if (timed) {
-      (void)hipEventRecord(c->prof_ev[2 * c->prof_n + 1], st);
-      c->prof_bytes += li.bwd_bytes + 8.0 * (P - 1) * li.bwd_vec_doubles;
-      ++c->prof_n;
-    }
   }
 }
 

@@ -34,7 +34,7 @@ for L in range(nlev):
 rows = list(csv.DictReader(open(sys.argv[1])))
 agg = {}
 for r in rows:
-    m = re.search(r"(k_(?:fwd|bwd)(?:_dot|_rows|_split)?)<(\d+)", r["Kernel_Name"])
+    m = re.search(r"(k_(?:fwd|bwd)(?:_dot|_rows|_split|_rt)?)<(\d+)", r["Kernel_Name"])
     if not m:
         continue
     name, P = m.group(1), int(m.group(2))
