@@ -8,6 +8,7 @@
 #include <numeric>
 
 #include "device.h"
+#include "host_eig.h"
 
 using plfem::LevelInfo;
 using plfem::Symbolic;
@@ -63,114 +64,6 @@ int check_launch(plfem_ctx* c, const char* what) {
   return PLFEM_OK;
 }
 
-// Dense symmetric eigen-decomposition: Householder tridiagonalisation + implicit-shift QL
-// (the classical EISPACK tred2 / tql2 pair).  A: n x n column major (destroyed), V: eigenvectors in
-// columns, w: eigenvalues (unordered).
-void tridiag_eigh(int n, std::vector<double>& A, std::vector<double>& V, std::vector<double>& w) {
-  std::vector<double> e(n, 0.0);
-  w.assign(n, 0.0);
-  V = A;   // work in V, row-major view z[i][j] = V[i*n + j] (A symmetric: layout irrelevant on entry)
-  auto z = [&](int i, int j) -> double& { return V[(size_t)i * n + j]; };
-  // ---- tred2: reduce to tridiagonal form, accumulate the transformation in z
-  for (int i = n - 1; i > 0; --i) {
-    int l = i - 1;
-    double h = 0.0, scale = 0.0;
-    if (l > 0) {
-      for (int k = 0; k <= l; ++k) scale += std::fabs(z(i, k));
-      if (scale == 0.0) {
-        e[i] = z(i, l);
-      } else {
-        for (int k = 0; k <= l; ++k) { z(i, k) /= scale; h += z(i, k) * z(i, k); }
-        double f = z(i, l);
-        double g = (f >= 0.0) ? -std::sqrt(h) : std::sqrt(h);
-        e[i] = scale * g;
-        h -= f * g;
-        z(i, l) = f - g;
-        f = 0.0;
-        for (int j = 0; j <= l; ++j) {
-          z(j, i) = z(i, j) / h;
-          g = 0.0;
-          for (int k = 0; k <= j; ++k) g += z(j, k) * z(i, k);
-          for (int k = j + 1; k <= l; ++k) g += z(k, j) * z(i, k);
-          e[j] = g / h;
-          f += e[j] * z(i, j);
-        }
-        double hh = f / (h + h);
-        for (int j = 0; j <= l; ++j) {
-          f = z(i, j);
-          e[j] = g = e[j] - hh * f;
-          for (int k = 0; k <= j; ++k) z(j, k) -= (f * e[k] + g * z(i, k));
-        }
-      }
-    } else {
-      e[i] = z(i, l);
-    }
-    w[i] = h;
-  }
-  w[0] = 0.0;
-  e[0] = 0.0;
-  for (int i = 0; i < n; ++i) {
-    int l = i - 1;
-    if (w[i] != 0.0) {
-      for (int j = 0; j <= l; ++j) {
-        double g = 0.0;
-        for (int k = 0; k <= l; ++k) g += z(i, k) * z(k, j);
-        for (int k = 0; k <= l; ++k) z(k, j) -= g * z(k, i);
-      }
-    }
-    w[i] = z(i, i);
-    z(i, i) = 1.0;
-    for (int j = 0; j <= l; ++j) z(j, i) = z(i, j) = 0.0;
-  }
-  // ---- tql2: eigenvalues / vectors of the tridiagonal matrix (d = w, e), rotations applied to z
-  for (int i = 1; i < n; ++i) e[i - 1] = e[i];
-  e[n - 1] = 0.0;
-  for (int l = 0; l < n; ++l) {
-    int iter = 0, m;
-    do {
-      for (m = l; m < n - 1; ++m) {
-        double dd = std::fabs(w[m]) + std::fabs(w[m + 1]);
-        if (std::fabs(e[m]) <= 2.3e-16 * dd) break;
-      }
-      if (m != l) {
-        if (iter++ == 120) break;   // no convergence: leave the current approximation
-        double g = (w[l + 1] - w[l]) / (2.0 * e[l]);
-        double r = std::hypot(g, 1.0);
-        g = w[m] - w[l] + e[l] / (g + (g >= 0.0 ? std::fabs(r) : -std::fabs(r)));
-        double s = 1.0, c = 1.0, p = 0.0;
-        int i;
-        for (i = m - 1; i >= l; --i) {
-          double f = s * e[i], b = c * e[i];
-          e[i + 1] = (r = std::hypot(f, g));
-          if (r == 0.0) {
-            w[i + 1] -= p;
-            e[m] = 0.0;
-            break;
-          }
-          s = f / r;
-          c = g / r;
-          g = w[i + 1] - p;
-          r = (w[i] - g) * s + 2.0 * c * b;
-          w[i + 1] = g + (p = s * r);
-          g = c * r - b;
-          for (int k = 0; k < n; ++k) {
-            f = z(k, i + 1);
-            z(k, i + 1) = s * z(k, i) + c * f;
-            z(k, i) = c * z(k, i) - s * f;
-          }
-        }
-        if (r == 0.0 && i >= l) continue;
-        w[l] -= p;
-        e[l] = g;
-        e[m] = 0.0;
-      }
-    } while (m != l);
-  }
-  // z(k, i) = component k of eigenvector i  ->  column-major V: V[i*n + k]; currently V[k*n + i]: transpose
-  for (int i = 0; i < n; ++i)
-    for (int k = i + 1; k < n; ++k) std::swap(V[(size_t)i * n + k], V[(size_t)k * n + i]);
-}
-
 void free_all(plfem_ctx* c) {
   if (c->own_slab && c->slab) (void)hipFree(c->slab);
   if (c->h_pinned) (void)hipHostFree(c->h_pinned);
@@ -178,6 +71,8 @@ void free_all(plfem_ctx* c) {
     for (auto& e : pr)
       if (e) (void)hipEventDestroy(e);
   for (auto& e : c->prof_ev) (void)hipEventDestroy(e);
+  for (auto& e : c->ev_step)
+    if (e) (void)hipEventDestroy(e);
 }
 
 int create_impl(plfem_ctx* c, const plfem_symbolic* sym, int device, void* stream, int max_ncv, void* workspace,
@@ -190,6 +85,7 @@ int create_impl(plfem_ctx* c, const plfem_symbolic* sym, int device, void* strea
     HIP_TRY(c, hipSetDevice(device));
     for (int q = 0; q < 5; ++q)
       for (int r = 0; r < 2; ++r) HIP_TRY(c, hipEventCreate(&c->ev[q][r]));
+    for (int r = 0; r < 2; ++r) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_step[r], hipEventDisableTiming));
     HIP_TRY(c, hipEventRecord(c->ev[4][0], c->stream));
   }
   c->nv = S.nv; c->ne = S.ne; c->N = S.N; c->nnz = (int)S.colind.size(); c->nsolve = S.nsolve;
@@ -290,7 +186,9 @@ int create_impl(plfem_ctx* c, const plfem_symbolic* sym, int device, void* strea
   HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, 4 * sizeof(int32_t), c->stream));
   {
     const size_t nc1p = (size_t)max_ncv + 2 + plfem::BLOCK_P;
-    HIP_TRY(c, hipHostMalloc((void**)&c->h_pinned, sizeof(double) * (8192 + nc1p * nc1p), hipHostMallocDefault));
+    // [0, 8192): scalars / counters / core table; then the projected matrix (nc1p^2); then two block-step slots
+    HIP_TRY(c, hipHostMalloc((void**)&c->h_pinned, sizeof(double) * (8192 + nc1p * nc1p + 2 * nc1p * plfem::BLOCK_P), hipHostMallocDefault));
+    c->h_slots = c->h_pinned + 8192 + nc1p * nc1p;
   }
   HIP_TRY(c, hipEventRecord(c->ev[4][1], c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -475,82 +373,123 @@ static int lanczos_block(plfem_ctx* c, int k, int ncv, double tol, int maxiter, 
   bool done = false;
   std::vector<double> theta, Svec, Tm;
   std::vector<int> order;
-  const int first_new_col = 0;
-  (void)first_new_col;
-  int cstart = 0;                 // first column computed in the current cycle
-  // Ritz values / residuals of the projected matrix of order mm_ (a multiple of P); fills theta, Svec, order
-  auto ritz_check = [&](int mm_) -> int {
+  // One block step = one pass over the factors for P vectors + CGS2 + CholQR, all asynchronous.  The
+  // P new columns of the projected matrix and the rank flag follow it into a pinned slot, then an event.
+  int32_t* hcnt = reinterpret_cast<int32_t*>(c->h_pinned + 4096);
+  auto launch_step = [&](int c0_, int slot) -> int {
+    const int nc = c0_ + P;
+    plfem::launch_solve_block(c, c->d_BV + (size_t)c0_ * n, c->d_w, n);      // W = OP V_j
+    double* Hblk = c->d_Hcols + (size_t)c0_ * ld;                             // T[0:nc, c0:c0+P]
+    plfem::launch_panel_dot_block(c, c->d_BV, nc, c->d_w, n, Hblk, ld);
+    plfem::launch_panel_axpy_block(c, c->d_V, nc, Hblk, ld, c->d_w, n);
+    plfem::launch_panel_dot_block(c, c->d_BV, nc, c->d_w, n, c->d_hblk, ld);  // CGS2 second pass
+    plfem::launch_panel_axpy_block(c, c->d_V, nc, c->d_hblk, ld, c->d_w, n);
+    plfem::launch_mat_add(c, nc, Hblk, ld, c->d_hblk, ld);
+    plfem::launch_spmv_b_block(c, c->d_w, c->d_bw, n);
+    plfem::launch_panel_dot_block(c, c->d_w, P, c->d_bw, n, c->d_G, P);       // Gram matrix W^T B W
+    plfem::launch_chol_block(c, c->d_G, P, Hblk + nc, ld, c->d_Rinv);         // R -> T[nc:nc+P, c0:c0+P]
+    plfem::launch_block_scale(c, c->d_w, c->d_bw, n, c->d_Rinv, c->d_V + (size_t)nc * n, c->d_BV + (size_t)nc * n, n);
     int rc = check_launch(c, "block lanczos step");
     if (rc != PLFEM_OK) return rc;
-    HIP_TRY(c, hipMemcpyAsync(hH, c->d_Hcols, sizeof(double) * ld * ld, hipMemcpyDeviceToHost, st));
-    int32_t* hc = reinterpret_cast<int32_t*>(c->h_pinned + 4096);
-    HIP_TRY(c, hipMemcpyAsync(hc, c->d_counters, sizeof(int32_t) * 4, hipMemcpyDeviceToHost, st));
-    HIP_TRY(c, hipStreamSynchronize(st));
-    if (hc[2] != 0) { c->err = "block Lanczos: rank-deficient block (Krylov space exhausted)"; return PLFEM_ESINGULAR; }
-    for (int j = cstart; j < mm_; ++j)
-      for (int i = 0; i < ld; ++i) T[(size_t)j * ld + i] = hH[(size_t)j * ld + i];
-    // symmetric mm x mm projected matrix from the upper triangle
-    Tm.assign((size_t)mm_ * mm_, 0.0);
+    HIP_TRY(c, hipMemcpyAsync(c->h_slots + (size_t)slot * ld * P, Hblk, sizeof(double) * ld * P, hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipMemcpyAsync(hcnt + 4 * slot, c->d_counters, sizeof(int32_t) * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipEventRecord(c->ev_step[slot], st));
+    return PLFEM_OK;
+  };
+  // wait for the step in `slot` and copy its columns [c0_, c0_ + P) into the host copy of T
+  auto absorb_step = [&](int c0_, int slot) -> int {
+    HIP_TRY(c, hipEventSynchronize(c->ev_step[slot]));
+    if (hcnt[4 * slot + 2] != 0) { c->err = "block Lanczos: rank-deficient block (Krylov space exhausted)"; return PLFEM_ESINGULAR; }
+    const double* src = c->h_slots + (size_t)slot * ld * P;
+    for (int j = 0; j < P; ++j)
+      for (int i = 0; i < ld; ++i) {
+        const double v = src[(size_t)j * ld + i];
+        if (!std::isfinite(v)) { c->err = "block Lanczos breakdown: non-finite projected matrix"; return PLFEM_ESINGULAR; }
+        T[(size_t)(c0_ + j) * ld + i] = v;
+      }
+    return PLFEM_OK;
+  };
+  auto fill_tm = [&](int mm_) {
+    Tm.assign((size_t)mm_ * mm_, 0.0);     // symmetric mm x mm projected matrix from the upper triangle
     for (int j = 0; j < mm_; ++j)
       for (int i = 0; i <= j; ++i) {
-        double v = T[(size_t)j * ld + i];
-        if (!std::isfinite(v)) { c->err = "block Lanczos breakdown: non-finite projected matrix"; return PLFEM_ESINGULAR; }
+        const double v = T[(size_t)j * ld + i];
         Tm[(size_t)j * mm_ + i] = v;
         Tm[(size_t)i * mm_ + j] = v;
       }
-    tridiag_eigh(mm_, Tm, Svec, theta);
+  };
+  // residual of Ritz pair `id`: || R_m s[mm-P:mm] ||, R_m = T[mm:mm+P, mm-P:mm] (upper triangular);
+  // last(id, b) = component mm - P + b of its eigenvector
+  auto count_converged = [&](int mm_, auto last) {
     order.resize(mm_);
     std::iota(order.begin(), order.end(), 0);
     std::sort(order.begin(), order.end(), [&](int a, int b) { return std::fabs(theta[a]) > std::fabs(theta[b]); });
-    // residual of Ritz pair i: || R_m S[mm-P:mm, i] ||, R_m = T[mm:mm+P, mm-P:mm] (upper triangular)
-    auto resid = [&](int id) {
+    nconv = 0;
+    max_rel_res = 0.0;
+    for (int q = 0; q < std::min(k, mm_); ++q) {
+      const int id = order[q];
       double r2 = 0.0;
       for (int a = 0; a < P; ++a) {
         double v = 0.0;
-        for (int b = a; b < P; ++b) v += T[(size_t)(mm_ - P + b) * ld + (mm_ + a)] * Svec[(size_t)id * mm_ + (mm_ - P + b)];
+        for (int b = a; b < P; ++b) v += T[(size_t)(mm_ - P + b) * ld + (mm_ + a)] * last(id, b);
         r2 += v * v;
       }
-      return std::sqrt(r2);
-    };
-    nconv = 0;
-    max_rel_res = 0.0;
-    for (int q = 0; q < k; ++q) {
-      int id = order[q];
-      double rel = resid(id) / std::max(std::fabs(theta[id]), 3.7e-11);
+      const double rel = std::sqrt(r2) / std::max(std::fabs(theta[id]), 3.7e-11);
       max_rel_res = std::max(max_rel_res, rel);
       if (rel <= tol) ++nconv;
     }
-    return PLFEM_OK;
   };
-  // PLFEM_LANCZOS_CHECK=j (tuning aid): also test convergence every j block steps inside a cycle.  Off by
-  // default: each test is a stream synchronisation plus a dense eigensolve on the host.
-  static const int check_every = getenv("PLFEM_LANCZOS_CHECK") ? atoi(getenv("PLFEM_LANCZOS_CHECK")) : 0;
+  std::vector<double> Ylast;
+  // convergence test only: Ritz values + last block of every Ritz vector (no eigenvector matrix)
+  auto quick_check = [&](int mm_) {
+    fill_tm(mm_);
+    plfem::sym_eig_last_rows(mm_, P, Tm, Ylast, theta);
+    count_converged(mm_, [&](int id, int b) { return Ylast[(size_t)id * P + b]; });
+  };
+  // full Ritz decomposition (theta, Svec, order): before a restart and for the final rotation
+  auto full_check = [&](int mm_) {
+    fill_tm(mm_);
+    plfem::sym_eig(mm_, Tm, Svec, theta);
+    count_converged(mm_, [&](int id, int b) { return Svec[(size_t)id * mm_ + (mm_ - P + b)]; });
+  };
+  // Pipeline: while the GPU runs block step j + 1, the host tests convergence on the projected matrix of
+  // step j; the extra step in flight when the test succeeds is simply not used.
   while (true) {
-    cstart = c0;
-    bool early = false;
-    while (c0 + P <= m) {
-      const int nc = c0 + P;
-      plfem::launch_solve_block(c, c->d_BV + (size_t)c0 * n, c->d_w, n);       // W = OP V_j
-      nop += P; ++nblock;
-      double* Hblk = c->d_Hcols + (size_t)c0 * ld;                              // T[0:nc, c0:c0+P]
-      plfem::launch_panel_dot_block(c, c->d_BV, nc, c->d_w, n, Hblk, ld);
-      plfem::launch_panel_axpy_block(c, c->d_V, nc, Hblk, ld, c->d_w, n);
-      plfem::launch_panel_dot_block(c, c->d_BV, nc, c->d_w, n, c->d_hblk, ld);  // CGS2 second pass
-      plfem::launch_panel_axpy_block(c, c->d_V, nc, c->d_hblk, ld, c->d_w, n);
-      plfem::launch_mat_add(c, nc, Hblk, ld, c->d_hblk, ld);
-      plfem::launch_spmv_b_block(c, c->d_w, c->d_bw, n);
-      plfem::launch_panel_dot_block(c, c->d_w, P, c->d_bw, n, c->d_G, P);       // Gram matrix W^T B W
-      plfem::launch_chol_block(c, c->d_G, P, Hblk + nc, ld, c->d_Rinv);         // R -> T[nc:nc+P, c0:c0+P]
-      plfem::launch_block_scale(c, c->d_w, c->d_bw, n, c->d_Rinv, c->d_V + (size_t)nc * n, c->d_BV + (size_t)nc * n, n);
-      c0 = nc;
-      if (check_every > 0 && c0 + P <= m && c0 >= k + P && ((c0 / P) % check_every) == 0) {
-        TRY(ritz_check(c0));
-        cstart = c0;
-        if (nconv >= k) { early = true; break; }
-      }
-    }
+    int pend_c0 = -1, pend_slot = 0, slot = 0;
+    bool converged = false;
     mm = c0;
-    if (!early) TRY(ritz_check(mm));
+    while (true) {
+      int new_c0 = -1, new_slot = 0;
+      if (c0 + P <= m) {
+        TRY(launch_step(c0, slot));
+        nop += P; ++nblock;
+        new_c0 = c0; new_slot = slot;
+        c0 += P; slot ^= 1;
+      }
+      if (pend_c0 >= 0) {
+        TRY(absorb_step(pend_c0, pend_slot));
+        mm = pend_c0 + P;
+        if (mm >= k + P && new_c0 >= 0) {          // (the last step of a cycle gets the full test below)
+          quick_check(mm);
+          if (nconv >= k) { converged = true; break; }
+        }
+      }
+      pend_c0 = new_c0; pend_slot = new_slot;
+      if (pend_c0 < 0) break;                       // basis full and every step absorbed
+    }
+    if (converged) {
+      full_check(mm);
+      if (nconv < k) {                              // the two eigensolvers disagree at the threshold: resume
+        converged = false;
+        TRY(absorb_step(c0 - P, slot ^ 1));         // the step in flight
+        if (c0 + P <= m) continue;
+        mm = c0;
+        full_check(mm);
+      }
+    } else {
+      mm = c0;
+      full_check(mm);
+    }
     if (nconv >= k || restarts >= maxiter) { done = nconv >= k; break; }
     int pk = k + std::min(nconv, (mm - k) / 2);
     pk = std::max(pk, k + (mm - k) / 4);
@@ -689,7 +628,7 @@ extern "C" int plfem_lanczos_shift_invert(plfem_ctx* c, int32_t k, int32_t ncv, 
         Tm[(size_t)j * m + i] = v;
         Tm[(size_t)i * m + j] = v;
       }
-    tridiag_eigh(m, Tm, Svec, theta);
+    plfem::sym_eig(m, Tm, Svec, theta);
     order.resize(m);
     std::iota(order.begin(), order.end(), 0);
     std::sort(order.begin(), order.end(), [&](int a, int b) { return std::fabs(theta[a]) > std::fabs(theta[b]); });

@@ -70,13 +70,15 @@ struct plfem_ctx {
   double* d_post = nullptr;       // post-processing partial sums
   int npartial = 0;
   double* h_pinned = nullptr;     // pinned staging
+  double* h_slots = nullptr;      // pinned: new projected-matrix columns of the two block steps in flight
   char* slab = nullptr;           // the one device allocation every buffer above is carved from
   size_t slab_off = 0, slab_bytes = 0;
   bool own_slab = false;
   int64_t workspace_need = 0;
   // state
   bool assembled = false, factored = false;
-  // live kernel timing (plfem_profile_*): event pairs around every tile-form backward-sweep launch
+  hipEvent_t ev_step[2] = {nullptr, nullptr};   // block Lanczos: completion of the two block steps in flight
+  // live kernel timing (plfem_profile_*): event pairs around every tile-form forward-sweep launch
   bool prof_on = false;
   int prof_n = 0;
   double prof_bytes = 0;

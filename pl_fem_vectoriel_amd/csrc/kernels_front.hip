@@ -741,6 +741,83 @@ __device__ __forceinline__ void multi_reduce(double (&a)[V], int lane) {
   for (int off = V; off < 64; off <<= 1) a[0] += __shfl_xor(a[0], off);
 }
 
+// Forward sweep, row form (top of the tree: few large fronts): row r of [L11^-1 ; Z] is contiguous in the mirrored
+// upper storage, a wave owns R rows and runs along their columns; NW R rows share one staged right-hand side.
+template <int P, int NW, int R>
+__global__ __launch_bounds__(NW * 64) void k_fwd_rows(int first_front, int N, int64_t ldx, int leaf_level,
+                                                      const int32_t* __restrict__ fs2, const int32_t* __restrict__ fm,
+                                                      const int64_t* __restrict__ foff, const int64_t* __restrict__ fnode_ptr,
+                                                      const int32_t* __restrict__ fnodes, const int32_t* __restrict__ cinv0,
+                                                      const int32_t* __restrict__ cinv1, const double* __restrict__ front,
+                                                      const double* __restrict__ delta, const double* __restrict__ rhs,
+                                                      double* __restrict__ fvec, double* __restrict__ fvec2) {
+  extern __shared__ double sv[];
+  constexpr int RB = NW * R, UNR = 8 / R, V = R * P;
+  const int f = first_front + blockIdx.y;
+  const int m = fm[f], s2 = fs2[f];
+  const int j0 = blockIdx.x * RB;
+  if (j0 >= m) return;
+  const int64_t np = fnode_ptr[f];
+  const int need = min(s2, j0 + RB);                      // rows < s2 only read r[0 .. row]
+  for (int i = threadIdx.x; i < need; i += NW * 64) {
+    double v[P];
+    gather_rhs<P>(v, f, i, s2, N, ldx, leaf_level, np, fs2, fnode_ptr, fnodes, cinv0, cinv1, rhs, fvec);
+#pragma unroll
+    for (int u = 0; u < P; ++u) sv[i * P + u] = v[u];
+  }
+  __syncthreads();
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const double* F = front + foff[f];
+  int ce[R], cmax = 0;
+#pragma unroll
+  for (int q = 0; q < R; ++q) {
+    const int r = j0 + wave + NW * q;
+    ce[q] = r < m ? ((r < s2) ? r + 1 : s2) : 0;
+    cmax = max(cmax, ce[q]);
+  }
+  double acc[V];
+#pragma unroll
+  for (int v = 0; v < V; ++v) acc[v] = 0.0;
+  for (int c = 0; c < cmax; c += 64 * UNR) {
+    double a[UNR][R];
+#pragma unroll
+    for (int t = 0; t < UNR; ++t) {
+      const int i = c + 64 * t + lane;
+#pragma unroll
+      for (int q = 0; q < R; ++q) a[t][q] = (i < ce[q]) ? F[(int64_t)(j0 + wave + NW * q) * m + i] : 0.0;
+    }
+#pragma unroll
+    for (int t = 0; t < UNR; ++t) {
+      const int i = c + 64 * t + lane;
+      if (i < cmax) {
+#pragma unroll
+        for (int u = 0; u < P; ++u) {
+          const double vi = sv[i * P + u];
+#pragma unroll
+          for (int q = 0; q < R; ++q) acc[q * P + u] += a[t][q] * vi;
+        }
+      }
+    }
+  }
+  multi_reduce<V>(acc, lane);
+  if (lane < V) {
+    const int idx = multi_reduce_index<V>(lane);
+    const int r = j0 + wave + NW * (idx / P), u = idx % P;
+    if (r < m) {
+      if (r < s2) {
+        fvec2[(2 * np + r) * P + u] = acc[0] / delta[2 * np + r];
+      } else {
+        double w[P];
+        gather_rhs<P>(w, f, r, s2, N, ldx, leaf_level, np, fs2, fnode_ptr, fnodes, cinv0, cinv1, nullptr, fvec);
+        double wu = w[0];
+#pragma unroll
+        for (int q = 1; q < P; ++q) wu = (u == q) ? w[q] : wu;
+        fvec[(2 * np + r) * P + u] = wu - acc[0];
+      }
+    }
+  }
+}
+
 // Backward sweep, row form: x_j = sum_{i >= j} [L11^-1 ; Z](i, j) v_i with v = [ys ; -x_b] staged in LDS.
 // Column j of the lower storage is contiguous in i, so a wave reads 512-byte runs; a wave owns R rows
 // (j0 + wave + NW q) and keeps R x 8/R loads in flight; a block (NW waves) shares one staged vector for NW R rows.
@@ -882,7 +959,16 @@ static void launch_solve_p(plfem_ctx* c, const double* rhs, double* x, int64_t l
     const LevelInfo& li = c->levels[lev];
     const int leaf = lev == c->L ? 1 : 0;
     const size_t lds = sizeof(double) * P * (li.max_s2 + 1);
-    if (li.count <= DOT_FORM_MAX_FRONTS)
+    static const int fmax = getenv("PLFEM_FWD_ROWS_MAX") ? atoi(getenv("PLFEM_FWD_ROWS_MAX")) : 32;
+    if (li.count <= 8)
+      hipLaunchKernelGGL((k_fwd_rows<P, 8, 1>), dim3((li.max_m + 7) / 8, li.count), dim3(512), lds, st, li.first, c->N, ldx, leaf,
+                         c->d_fs2, c->d_fm, c->d_foff, c->d_fnode_ptr, c->d_fnodes, c->d_cinv0, c->d_cinv1, c->d_front,
+                         c->d_delta, rhs, c->d_fvec, c->d_fvec2);
+    else if (li.count <= fmax)
+      hipLaunchKernelGGL((k_fwd_rows<P, 8, 2>), dim3((li.max_m + 15) / 16, li.count), dim3(512), lds, st, li.first, c->N, ldx, leaf,
+                         c->d_fs2, c->d_fm, c->d_foff, c->d_fnode_ptr, c->d_fnodes, c->d_cinv0, c->d_cinv1, c->d_front,
+                         c->d_delta, rhs, c->d_fvec, c->d_fvec2);
+    else if (li.count <= DOT_FORM_MAX_FRONTS)
       hipLaunchKernelGGL(k_fwd_dot<P>, dim3((li.max_m + 3) / 4, li.count), dim3(256), lds, st, li.first, c->N, ldx, leaf,
                          c->d_fs2, c->d_fm, c->d_foff, c->d_fnode_ptr, c->d_fnodes, c->d_cinv0, c->d_cinv1, c->d_front,
                          c->d_delta, rhs, c->d_fvec, c->d_fvec2);

@@ -407,7 +407,7 @@ void launch_post(plfem_ctx* c, int k, double* evecs, int ncore, double* out_host
                  double* modes_int) {
   hipStream_t st = c->stream;
   const int N = c->N;
-  hipMemsetAsync(c->d_counters + 1, 0, sizeof(int32_t), st);
+  (void)hipMemsetAsync(c->d_counters + 1, 0, sizeof(int32_t), st);
   hipLaunchKernelGGL(k_core_mask, dim3((N + 255) / 256), dim3(256), 0, st, N, c->d_doflocs, c->d_cores, ncore,
                      c->d_bmask, c->d_coremask, c->d_counters);
   const int nblocks = (N + POST_ROWS - 1) / POST_ROWS;
@@ -423,10 +423,10 @@ void launch_post(plfem_ctx* c, int k, double* evecs, int ncore, double* out_host
                        N, c->nsolve, c->d_interior, evecs, modes_int);
   // results to the host
   double* hs = c->h_pinned;
-  hipMemcpyAsync(hs, sums, sizeof(double) * k * 5, hipMemcpyDeviceToHost, st);
+  (void)hipMemcpyAsync(hs, sums, sizeof(double) * k * 5, hipMemcpyDeviceToHost, st);
   int32_t* hc = reinterpret_cast<int32_t*>(c->h_pinned + 4096);
-  hipMemcpyAsync(hc, c->d_counters, sizeof(int32_t) * 4, hipMemcpyDeviceToHost, st);
-  hipStreamSynchronize(st);
+  (void)hipMemcpyAsync(hc, c->d_counters, sizeof(int32_t) * 4, hipMemcpyDeviceToHost, st);
+  (void)hipStreamSynchronize(st);
   for (int mode = 0; mode < k; ++mode) {
     const double* s = hs + mode * 5;
     double nrm2 = s[0] + s[1];

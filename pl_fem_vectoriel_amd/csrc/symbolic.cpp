@@ -350,7 +350,7 @@ void nd_tree(Symbolic& S, int leaf_elems, int nthreads) {
       constexpr double RHO = 2.2;
       const double ideal = (double)ne / (double)((int64_t)2 << level);
       const double clo = ideal / RHO, chi = ideal * RHO;
-      const double a0s[2] = {x0, y0}, a1s[2] = {x1, y1};
+      const double a0s[2] = {x0, y0};
       const double scales[2] = {x1 > x0 ? NBIN / (x1 - x0) : 0.0, y1 > y0 ? NBIN / (y1 - y0) : 0.0};
       auto hist = [&](int64_t b, int64_t e_, int tid) {
         Hist& h = hs[tid];

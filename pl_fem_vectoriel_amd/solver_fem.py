@@ -108,6 +108,9 @@ class TrueVectorialMaxwellSolver:
     REF_TOL = 1e-7           # solver_fem.py:197
     MAXITER = 12000          # solver_fem.py:197
     OVERSAMPLE = 12          # solver_fem.py:196
+    BASIS_FACTOR = 6         # Lanczos basis = 6 k columns (SciPy's default is 2k + 1): the driver tests convergence
+    BASIS_MAX = 160          # after every block step, so a long basis costs memory, not work, and avoids restarts
+    BASIS_BYTES = 16e9       # cap of the four basis panels (V, BV and their restart doubles)
 
     def __init__(self, geometry, use_pml: bool = False, n_modes: Optional[int] = None, device: Optional[int] = None,
                  eig_tol: float = 1e-10, leaf_elems: int = 0, reuse_symbolic: bool = True, mesh_refinement: float = 1.0,
@@ -155,6 +158,11 @@ class TrueVectorialMaxwellSolver:
             ent["t_context"] = time.perf_counter() - t0
         return ent
 
+    def _basis_size(self, k: int, n2: int) -> int:
+        floor = max(2 * k + 1, 20)
+        by_memory = int(self.BASIS_BYTES // (32 * max(n2, 1)))
+        return max(floor, min(self.BASIS_FACTOR * k, self.BASIS_MAX, max(by_memory, floor)))
+
     def clear_cache(self):
         for ent in self._cache.values():
             if ent["ctx"] is not None:
@@ -192,16 +200,16 @@ class TrueVectorialMaxwellSolver:
         """Résout [A]{Ht} = β² [B]{Ht} (``solver_fem.py:171-239``) on the GPU."""
         g = self.geometry
         t_start = time.perf_counter()
-        # request size and Lanczos basis: solver_fem.py:196 and scipy's default ncv = max(2k+1, 20)
+        # request size: solver_fem.py:196; Lanczos basis: see BASIS_FACTOR (never below scipy's max(2k+1, 20))
         nv, ne = mesh.p.shape[1], mesh.t.shape[1]
         n_req_guess = n_modes_target + self.OVERSAMPLE
-        ent = self._analysis(mesh, need_ctx=True, max_ncv=max(2 * n_req_guess + 1, 20))
+        ent = self._analysis(mesh, need_ctx=True, max_ncv=self._basis_size(n_req_guess, 2 * (nv + 2 * ne)))
         sym, ctx = ent["sym"], ent["ctx"]
         N_solve = sym.nsolve
         n_req = min(n_modes_target + self.OVERSAMPLE, 2 * N_solve - 4)
         if n_req < 1:
             raise ValueError("mesh too small for the requested number of modes")
-        ncv = min(max(2 * n_req + 1, 20), 2 * N_solve)
+        ncv = min(self._basis_size(n_req, 2 * sym.N), 2 * N_solve, ctx.max_ncv)
         cores = _core_table(g)
         t0 = time.perf_counter()
         self._assemble_device(ctx)
