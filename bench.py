@@ -144,7 +144,7 @@ def main():
         if os.path.exists(pmc):
             traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
         roof = {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                "traffic": traffic, "kernel": "k_fwd<4, 8>", "launches": kprof["launches"],
+                "traffic": traffic, "kernel": "k_fwd<4, 4>", "launches": kprof["launches"],
                 "avg_launch_us": kprof["total_us"] / kprof["launches"],
                 "algorithmic_bytes_per_launch": kprof["bytes"] / kprof["launches"]}
     ws.clear_cache()

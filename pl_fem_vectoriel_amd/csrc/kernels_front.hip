@@ -485,12 +485,12 @@ __global__ __launch_bounds__(256) void k_mirror_z(int first_front, const int32_t
 // vectors).
 //   forward : [ys; u] = [D^-1 L11^-1 r ;  w_b - Z r],     r = rhs_own + children's updates
 //   backward: x_own   = L11^-T ys - Z^T x_b
-// Forward: "tile" form (levels with many fronts): lane = output row, the block's waves split the columns,
-// partial sums meet in LDS in a fixed order; "dot" form (few large fronts): one wave per output row,
-// reduction across the lanes.  Backward: "row" form (k_bwd_rows: a wave owns R rows and runs along the
-// contiguous columns of the lower storage) except at the leaf level, where the fronts have about as many
-// owned rows as boundary columns and the tile form is faster.  All read contiguous runs of F thanks to the
-// mirrored storage.
+// Forward: "tile" form (levels with many fronts, k_fwd): lane = output row, the block's waves split the columns,
+// partial sums meet in LDS in a fixed order; "row" form (at most 32 fronts, k_fwd_rows): a wave owns R rows of
+// [L11^-1 ; Z] and runs along their columns in the mirrored upper storage.  Backward: row form (k_bwd_rows: the
+// contiguous columns of the lower storage) except at the leaf level, where the fronts have about as many owned
+// rows as boundary columns and the tile form (k_bwd) is faster.  All read contiguous runs of F thanks to the
+// mirrored storage; the cross-lane sums of the row forms use multi_reduce (V - 1 + log2(64 / V) shuffles).
 // Global vectors: column q of rhs / x at offset q*ldx.  Per-front vectors: [dof][P] interleaved.
 // ------------------------------------------------------------------------------------------------
 // global vector element (dof index i, right-hand side u): ldx > 0 -> separate columns (u*ldx + i),
@@ -498,11 +498,6 @@ __global__ __launch_bounds__(256) void k_mirror_z(int first_front, const int32_t
 template <int P>
 __device__ __forceinline__ int64_t vidx(int64_t i, int u, int64_t ldx) {
   return ldx ? (int64_t)u * ldx + i : i * P + u;
-}
-
-__device__ __forceinline__ double wave_sum(double v) {
-  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
-  return v;
 }
 
 // local right-hand side of local DOF i: global rhs (owned DOFs) + the children's updates
@@ -604,56 +599,6 @@ __global__ __launch_bounds__(NW * 64) void k_fwd(int first_front, int N, int64_t
   // (fetching the epilogue operands before the sum is slower: the dependent index -> value loads of
   // gather_rhs would sit in front of the matrix loads in the in-order memory counter)
   if (threadIdx.x < 64 && valid) {
-    if (r < s2) {
-      const double di = 1.0 / delta[2 * np + r];
-#pragma unroll
-      for (int u = 0; u < P; ++u) fvec2[(2 * np + r) * P + u] = acc[u] * di;
-    } else {
-      double w[P];
-      gather_rhs<P>(w, f, r, s2, N, ldx, leaf_level, np, fs2, fnode_ptr, fnodes, cinv0, cinv1, nullptr, fvec);
-#pragma unroll
-      for (int u = 0; u < P; ++u) fvec[(2 * np + r) * P + u] = w[u] - acc[u];
-    }
-  }
-}
-
-template <int P>
-__global__ __launch_bounds__(256) void k_fwd_dot(int first_front, int N, int64_t ldx, int leaf_level,
-                                                 const int32_t* __restrict__ fs2, const int32_t* __restrict__ fm,
-                                                 const int64_t* __restrict__ foff, const int64_t* __restrict__ fnode_ptr,
-                                                 const int32_t* __restrict__ fnodes, const int32_t* __restrict__ cinv0,
-                                                 const int32_t* __restrict__ cinv1, const double* __restrict__ front,
-                                                 const double* __restrict__ delta, const double* __restrict__ rhs,
-                                                 double* __restrict__ fvec, double* __restrict__ fvec2) {
-  extern __shared__ double sv[];
-  const int f = first_front + blockIdx.y;
-  const int m = fm[f], s2 = fs2[f];
-  if (blockIdx.x * 4 >= m) return;
-  const int64_t np = fnode_ptr[f];
-  const int need = min(s2, blockIdx.x * 4 + 4);       // rows < s2 only read r[0 .. row]
-  for (int i = threadIdx.x; i < need; i += 256) {
-    double v[P];
-    gather_rhs<P>(v, f, i, s2, N, ldx, leaf_level, np, fs2, fnode_ptr, fnodes, cinv0, cinv1, rhs, fvec);
-#pragma unroll
-    for (int u = 0; u < P; ++u) sv[i * P + u] = v[u];
-  }
-  __syncthreads();
-  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (r >= m) return;
-  const int lane = threadIdx.x & 63;
-  const double* col = front + foff[f] + (int64_t)r * m;  // column r of the upper part = row r of [L11^-1; Z]
-  const int ce = (r < s2) ? r + 1 : s2;
-  double acc[P];
-#pragma unroll
-  for (int u = 0; u < P; ++u) acc[u] = 0.0;
-  for (int c = lane; c < ce; c += 64) {
-    const double a = col[c];
-#pragma unroll
-    for (int u = 0; u < P; ++u) acc[u] += a * sv[c * P + u];
-  }
-#pragma unroll
-  for (int u = 0; u < P; ++u) acc[u] = wave_sum(acc[u]);
-  if (lane == 0) {
     if (r < s2) {
       const double di = 1.0 / delta[2 * np + r];
 #pragma unroll
@@ -954,22 +899,17 @@ static void launch_solve_p(plfem_ctx* c, const double* rhs, double* x, int64_t l
   if (ldx == 0) (void)hipMemsetAsync(x, 0, sizeof(double) * c->n2 * P, st);
   else
     for (int u = 0; u < P; ++u) (void)hipMemsetAsync(x + (int64_t)u * ldx, 0, sizeof(double) * c->n2, st);
-  constexpr int DOT_FORM_MAX_FRONTS = 32;   // levels with at most this many fronts use the dot-form kernels
+  constexpr int DOT_FORM_MAX_FRONTS = 32;   // levels with at most this many fronts use the row-form kernels in both sweeps
   for (int lev = c->L; lev >= 0; --lev) {
     const LevelInfo& li = c->levels[lev];
     const int leaf = lev == c->L ? 1 : 0;
     const size_t lds = sizeof(double) * P * (li.max_s2 + 1);
-    static const int fmax = getenv("PLFEM_FWD_ROWS_MAX") ? atoi(getenv("PLFEM_FWD_ROWS_MAX")) : 32;
     if (li.count <= 8)
       hipLaunchKernelGGL((k_fwd_rows<P, 8, 1>), dim3((li.max_m + 7) / 8, li.count), dim3(512), lds, st, li.first, c->N, ldx, leaf,
                          c->d_fs2, c->d_fm, c->d_foff, c->d_fnode_ptr, c->d_fnodes, c->d_cinv0, c->d_cinv1, c->d_front,
                          c->d_delta, rhs, c->d_fvec, c->d_fvec2);
-    else if (li.count <= fmax)
-      hipLaunchKernelGGL((k_fwd_rows<P, 8, 2>), dim3((li.max_m + 15) / 16, li.count), dim3(512), lds, st, li.first, c->N, ldx, leaf,
-                         c->d_fs2, c->d_fm, c->d_foff, c->d_fnode_ptr, c->d_fnodes, c->d_cinv0, c->d_cinv1, c->d_front,
-                         c->d_delta, rhs, c->d_fvec, c->d_fvec2);
     else if (li.count <= DOT_FORM_MAX_FRONTS)
-      hipLaunchKernelGGL(k_fwd_dot<P>, dim3((li.max_m + 3) / 4, li.count), dim3(256), lds, st, li.first, c->N, ldx, leaf,
+      hipLaunchKernelGGL((k_fwd_rows<P, 8, 2>), dim3((li.max_m + 15) / 16, li.count), dim3(512), lds, st, li.first, c->N, ldx, leaf,
                          c->d_fs2, c->d_fm, c->d_foff, c->d_fnode_ptr, c->d_fnodes, c->d_cinv0, c->d_cinv1, c->d_front,
                          c->d_delta, rhs, c->d_fvec, c->d_fvec2);
     else {
