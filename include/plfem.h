@@ -193,11 +193,17 @@ int plfem_profile_end(plfem_ctx* ctx, double* out_host /* [3] */);
 
 /* ---------------------------------------------------------------------------------------------
  * Debugging aids for the test-suite (no reference counterpart): run the factorisation only up to
- * a given (tree level, sweep step, stage: 0 assembled, 1 diag, 2 panel, 3 update, 4 level done),
- * and copy a slice of a named device workspace ("front","fvec","wbuf","rbuf","dinv","elem").
+ * a given (tree level, block step, stage: 0 assembled, 1 pivot block, 2 or 3 invrow + panel (one
+ * launch), 4 trailing update, 5 level done), and copy a slice of a named device workspace
+ * ("front","fvec","wbuf","rbuf","dinv","elem").
+ * plfem_debug_symeig: the host eigensolver of the Lanczos drivers (projected matrices of order
+ * <= ~200; needs no GPU).  a_host: n x n symmetric.  last_rows < 0: v_out[i*n + k] = component k of
+ * eigenvector i; last_rows = p >= 0: v_out[i*p + a] = component n-p+a of eigenvector i only (the
+ * cheap form used by the per-step convergence test).  w_out[n]: eigenvalues, same (arbitrary) order.
  * ------------------------------------------------------------------------------------------- */
 int plfem_debug_factor_until(plfem_ctx* ctx, double sigma, int32_t level, int32_t step, int32_t stage);
 int plfem_debug_copy(plfem_ctx* ctx, const char* name, int64_t offset, int64_t count, double* out_host);
+int plfem_debug_symeig(int32_t n, const double* a_host, int32_t last_rows, double* w_out, double* v_out);
 
 #ifdef __cplusplus
 }

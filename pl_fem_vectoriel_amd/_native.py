@@ -30,7 +30,7 @@ EXPORTS = (
     "plfem_assemble_hfield", "plfem_block_values_dev", "plfem_block_values_host", "plfem_spmv", "plfem_factor",
     "plfem_solve", "plfem_lanczos_shift_invert", "plfem_postprocess", "plfem_timings",
     "plfem_debug_factor_until", "plfem_debug_copy", "plfem_profile_begin", "plfem_profile_end",
-    "plfem_mesh_edge_count", "plfem_mesh_refine",
+    "plfem_mesh_edge_count", "plfem_mesh_refine", "plfem_debug_symeig",
 )
 
 _ARRAY_DTYPES = {
@@ -131,6 +131,24 @@ def mesh_refine(p, t):
     if rc != PLFEM_OK:
         raise ValueError(f"plfem_mesh_refine failed ({rc}): {err.value.decode()}")
     return p2, t2
+
+
+def debug_symeig(a, last_rows: int = -1):
+    """Host eigensolver of the Lanczos drivers (``plfem_debug_symeig``): returns ``(w, V)`` with eigenvector i
+    in row i of V — all n components, or only the last ``last_rows`` ones."""
+    lib = load_library()
+    a = np.ascontiguousarray(np.asarray(a, dtype=np.float64))
+    n = a.shape[0]
+    if a.shape != (n, n):
+        raise ValueError("square matrix expected")
+    w = np.empty(n, dtype=np.float64)
+    v = np.empty((n, n if last_rows < 0 else last_rows), dtype=np.float64)
+    lib.plfem_debug_symeig.argtypes = [ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]
+    lib.plfem_debug_symeig.restype = ctypes.c_int
+    rc = lib.plfem_debug_symeig(n, _ptr(a), int(last_rows), _ptr(w), _ptr(v))
+    if rc != PLFEM_OK:
+        raise ValueError(f"plfem_debug_symeig failed ({rc})")
+    return w, v
 
 
 class Symbolic:

@@ -7,6 +7,7 @@
 
 #include "../../include/plfem.h"
 #include "internal.h"
+#include "host_eig.h"
 
 using plfem::Symbolic;
 
@@ -163,4 +164,14 @@ extern "C" int plfem_mesh_refine(int32_t nv, int32_t ne, const double* p_host, c
     }
   }
   return PLFEM_OK;
+}
+
+// host eigensolver of the Lanczos drivers, exposed for the CPU test-suite
+extern "C" int plfem_debug_symeig(int32_t n, const double* a_host, int32_t last_rows, double* w_out, double* v_out) {
+  if (n < 1 || n > 4096 || !a_host || !w_out || !v_out || last_rows > n) return PLFEM_EINVAL;
+  std::vector<double> A(a_host, a_host + (size_t)n * n), V, w;
+  const bool ok = last_rows < 0 ? plfem::sym_eig(n, A, V, w) : plfem::sym_eig_last_rows(n, last_rows, A, V, w);
+  std::copy(w.begin(), w.end(), w_out);
+  std::copy(V.begin(), V.end(), v_out);
+  return ok ? PLFEM_OK : PLFEM_ENOCONV;
 }
