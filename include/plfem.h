@@ -195,7 +195,8 @@ int plfem_profile_end(plfem_ctx* ctx, double* out_host /* [3] */);
  * Debugging aids for the test-suite (no reference counterpart): run the factorisation only up to
  * a given (tree level, block step, stage: 0 assembled, 1 pivot block, 2 or 3 invrow + panel (one
  * launch), 4 trailing update, 5 level done), and copy a slice of a named device workspace
- * ("front","fvec","wbuf","rbuf","dinv","elem").
+ * ("front","fvec","wbuf","rbuf","dinv","elem"; "colind","slot_row": the device-built CSR index
+ * arrays, converted to double).
  * plfem_debug_symeig: the host eigensolver of the Lanczos drivers (projected matrices of order
  * <= ~200; needs no GPU).  a_host: n x n symmetric.  last_rows < 0: v_out[i*n + k] = component k of
  * eigenvector i; last_rows = p >= 0: v_out[i*p + a] = component n-p+a of eigenvector i only (the

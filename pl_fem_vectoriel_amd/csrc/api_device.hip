@@ -88,7 +88,7 @@ int create_impl(plfem_ctx* c, const plfem_symbolic* sym, int device, void* strea
     for (int r = 0; r < 2; ++r) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_step[r], hipEventDisableTiming));
     HIP_TRY(c, hipEventRecord(c->ev[4][0], c->stream));
   }
-  c->nv = S.nv; c->ne = S.ne; c->N = S.N; c->nnz = (int)S.colind.size(); c->nsolve = S.nsolve;
+  c->nv = S.nv; c->ne = S.ne; c->N = S.N; c->nnz = S.rowptr.empty() ? 0 : (int)S.rowptr[S.N]; c->nsolve = S.nsolve;
   c->L = S.L; c->nfronts = S.nfronts; c->n2 = 2 * (int64_t)S.N; c->max_ncv = max_ncv;
   // per-front DOF counts + level table
   std::vector<int32_t> fs2(S.nfronts), fm(S.nfronts);
@@ -114,8 +114,8 @@ int create_impl(plfem_ctx* c, const plfem_symbolic* sym, int device, void* strea
   TRY(upload(c, &c->d_tsorted, S.tsorted));
   TRY(upload(c, &c->d_edof, S.edof));
   TRY(upload(c, &c->d_rowptr, S.rowptr));
-  TRY(upload(c, &c->d_colind, S.colind));
-  TRY(upload(c, &c->d_slot_row, S.slot_row));
+  TRY(dalloc(c, &c->d_colind, (size_t)c->nnz));      // filled on the device by launch_pattern_fill below
+  TRY(dalloc(c, &c->d_slot_row, (size_t)c->nnz));
   TRY(upload(c, &c->d_nptr, S.nptr));
   TRY(upload(c, &c->d_nadj, S.nadj));
   TRY(upload(c, &c->d_nloc, S.nloc));
@@ -184,6 +184,8 @@ int create_impl(plfem_ctx* c, const plfem_symbolic* sym, int device, void* strea
   c->slab_bytes = need;
   TRY(place());                      // pass 1: place + upload
   HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, 4 * sizeof(int32_t), c->stream));
+  plfem::launch_pattern_fill(c);
+  TRY(check_launch(c, "pattern fill"));
   {
     const size_t nc1p = (size_t)max_ncv + 2 + plfem::BLOCK_P;
     // [0, 8192): scalars / counters / core table; then the projected matrix (nc1p^2); then two block-step slots
@@ -742,6 +744,14 @@ extern "C" int plfem_debug_copy(plfem_ctx* c, const char* name, int64_t offset, 
   else if (n == "delta") src = c->d_delta;
   else if (n == "fvec2") src = c->d_fvec2;
   else if (n == "elem") src = c->d_elem;
+  else if (n == "colind" || n == "slot_row") {            // int32 index arrays, delivered as doubles
+    if (offset + count > c->nnz) return PLFEM_EINVAL;
+    std::vector<int32_t> tmp((size_t)count);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpy(tmp.data(), (n == "colind" ? c->d_colind : c->d_slot_row) + offset, sizeof(int32_t) * count, hipMemcpyDeviceToHost));
+    for (int64_t q = 0; q < count; ++q) out_host[q] = (double)tmp[q];
+    return PLFEM_OK;
+  }
   else return PLFEM_EINVAL;
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   HIP_TRY(c, hipMemcpy(out_host, src + offset, sizeof(double) * count, hipMemcpyDeviceToHost));

@@ -54,7 +54,7 @@ extern "C" int plfem_symbolic_info(const plfem_symbolic* sym, int64_t* info) {
   info[PLFEM_INFO_NEDGES] = S.nedges;
   info[PLFEM_INFO_N] = S.N;
   info[PLFEM_INFO_NSOLVE] = S.nsolve;
-  info[PLFEM_INFO_NNZ] = (int64_t)S.colind.size();
+  info[PLFEM_INFO_NNZ] = S.rowptr.empty() ? 0 : (int64_t)S.rowptr[S.N];
   info[PLFEM_INFO_LEVELS] = S.L;
   info[PLFEM_INFO_NFRONTS] = S.nfronts;
   info[PLFEM_INFO_FRONT_DOUBLES] = S.foff.empty() ? 0 : S.foff.back();
@@ -71,38 +71,38 @@ extern "C" int plfem_symbolic_info(const plfem_symbolic* sym, int64_t* info) {
 namespace {
 struct ArrayRef { const void* ptr; int64_t bytes; };
 template <class T>
-ArrayRef ref(const std::vector<T>& v) { return {v.data(), (int64_t)(v.size() * sizeof(T))}; }
-ArrayRef ref(const plfem::rawvec_i32& v) { return {v.data(), (int64_t)(v.size() * sizeof(int32_t))}; }
+ArrayRef aref(const std::vector<T>& v) { return {v.data(), (int64_t)(v.size() * sizeof(T))}; }
+ArrayRef aref(const plfem::rawvec_i32& v) { return {v.data(), (int64_t)(v.size() * sizeof(int32_t))}; }
 
 bool lookup(const Symbolic& S, const char* name, ArrayRef& r) {
   std::string n(name ? name : "");
-  if (n == "edof") r = ref(S.edof);
-  else if (n == "tsorted") r = ref(S.tsorted);
-  else if (n == "edges") r = ref(S.edges);
-  else if (n == "doflocs") r = ref(S.doflocs);
-  else if (n == "bmask") r = ref(S.bmask);
-  else if (n == "interior") r = ref(S.interior);
-  else if (n == "int_index") r = ref(S.int_index);
-  else if (n == "rowptr") r = ref(S.rowptr);
-  else if (n == "colind") r = ref(S.colind);
-  else if (n == "slot_row") r = ref(S.slot_row);
-  else if (n == "nptr") r = ref(S.nptr);
-  else if (n == "nadj") r = ref(S.nadj);
-  else if (n == "nloc") r = ref(S.nloc);
-  else if (n == "leaf_of_elem") r = ref(S.leaf_of_elem);
-  else if (n == "leaf_elem_ptr") r = ref(S.leaf_elem_ptr);
-  else if (n == "leaf_elems") r = ref(S.leaf_elems);
-  else if (n == "epos") r = ref(S.epos);
-  else if (n == "owner") r = ref(S.owner);
-  else if (n == "fs") r = ref(S.fs);
-  else if (n == "fb") r = ref(S.fb);
-  else if (n == "fs_true") r = ref(S.fs_true);
-  else if (n == "fb_true") r = ref(S.fb_true);
-  else if (n == "fnode_ptr") r = ref(S.fnode_ptr);
-  else if (n == "fnodes") r = ref(S.fnodes);
-  else if (n == "cinv0") r = ref(S.cinv0);
-  else if (n == "cinv1") r = ref(S.cinv1);
-  else if (n == "foff") r = ref(S.foff);
+  if (n == "edof") r = aref(S.edof);
+  else if (n == "tsorted") r = aref(S.tsorted);
+  else if (n == "edges") r = aref(S.edges);
+  else if (n == "doflocs") r = aref(S.doflocs);
+  else if (n == "bmask") r = aref(S.bmask);
+  else if (n == "interior") r = aref(S.interior);
+  else if (n == "int_index") r = aref(S.int_index);
+  else if (n == "rowptr") r = aref(S.rowptr);
+  else if (n == "colind") { plfem::ensure_pattern(S); r = aref(S.colind); }
+  else if (n == "slot_row") { plfem::ensure_pattern(S); r = aref(S.slot_row); }
+  else if (n == "nptr") r = aref(S.nptr);
+  else if (n == "nadj") r = aref(S.nadj);
+  else if (n == "nloc") r = aref(S.nloc);
+  else if (n == "leaf_of_elem") r = aref(S.leaf_of_elem);
+  else if (n == "leaf_elem_ptr") r = aref(S.leaf_elem_ptr);
+  else if (n == "leaf_elems") r = aref(S.leaf_elems);
+  else if (n == "epos") r = aref(S.epos);
+  else if (n == "owner") r = aref(S.owner);
+  else if (n == "fs") r = aref(S.fs);
+  else if (n == "fb") r = aref(S.fb);
+  else if (n == "fs_true") r = aref(S.fs_true);
+  else if (n == "fb_true") r = aref(S.fb_true);
+  else if (n == "fnode_ptr") r = aref(S.fnode_ptr);
+  else if (n == "fnodes") r = aref(S.fnodes);
+  else if (n == "cinv0") r = aref(S.cinv0);
+  else if (n == "cinv1") r = aref(S.cinv1);
+  else if (n == "foff") r = aref(S.foff);
   else return false;
   return true;
 }

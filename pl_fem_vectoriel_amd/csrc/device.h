@@ -94,6 +94,7 @@ namespace plfem {
 // kernels_assembly.hip
 void launch_element_matrices(plfem_ctx* c, int ncore, double eps_core, double eps_clad, double k0, double alpha_p);
 void launch_csr_gather(plfem_ctx* c);
+void launch_pattern_fill(plfem_ctx* c);   // colind / slot_row from the node -> element adjacency (once per context)
 void launch_spmv(plfem_ctx* c, int which, const double* x, double* y);
 void launch_spmv_b_block(plfem_ctx* c, const double* x, double* y, int64_t ld);   // y_q = B x_q, BLOCK_P vectors
 // kernels_front.hip

@@ -120,6 +120,105 @@ __global__ __launch_bounds__(256) void k_element_matrices(
   }
 }
 
+// CSR column lists of the scalar pattern: row i = ascending union of the DOFs of the elements adjacent to node i
+// (what coo_matrix(...).tocsr() leaves of asm()'s triplets, reference solver_fem.py:153-156).  The row length is
+// known (closed form on the host).  Ordinary rows (at most 10 adjacent elements): one lane per row reads its 6 d
+// candidates once into an LDS row (stride 65 words: conflict-free) and emits the next larger candidate rowlen
+// times.  High-degree rows (the centre vertex of a core's point rings has 16 rho neighbours) are done by the whole
+// block: every candidate finds the number of distinct smaller ones and, if it is the first of its value, its slot.
+// The slots of the 128 rows of a block are contiguous, so they are collected in LDS and written back coalesced.
+constexpr int PATTERN_CAP = 64, PATTERN_OUT = 4096, PATTERN_BIG = 1536;
+__global__ __launch_bounds__(128) void k_pattern_fill(int N, int ne, const int32_t* __restrict__ nptr,
+                                                      const int32_t* __restrict__ nadj, const int32_t* __restrict__ edof,
+                                                      const int32_t* __restrict__ rowptr, int32_t* __restrict__ colind,
+                                                      int32_t* __restrict__ slot_row) {
+  __shared__ int32_t cand[128][PATTERN_CAP + 1];
+  __shared__ int32_t outbuf[PATTERN_OUT];
+  __shared__ uint8_t outrow[PATTERN_OUT];
+  __shared__ int32_t big[PATTERN_BIG];
+  __shared__ uint8_t bigfirst[PATTERN_BIG];
+  __shared__ int32_t biglist[128];
+  __shared__ int nbig;
+  const int i0 = blockIdx.x * 128;
+  const int i = i0 + threadIdx.x;
+  const int base = rowptr[i0], end = rowptr[min(i0 + 128, N)];
+  const bool buffered = end - base <= PATTERN_OUT;
+  if (threadIdx.x == 0) nbig = 0;
+  __syncthreads();
+  auto put = [&](int k, int col, int local_row) {
+    if (buffered) { outbuf[k - base] = col; outrow[k - base] = (uint8_t)local_row; }
+    else { colind[k] = col; slot_row[k] = i0 + local_row; }
+  };
+  if (i < N) {
+    const int q0 = nptr[i], q1 = nptr[i + 1];
+    const int nc = 6 * (q1 - q0);
+    int32_t* mine = cand[threadIdx.x];
+    if (nc > PATTERN_CAP && nc <= PATTERN_BIG) {
+      biglist[atomicAdd(&nbig, 1)] = threadIdx.x;           // order irrelevant: every slot has one writer
+    } else {
+      const bool staged = nc <= PATTERN_CAP;
+      if (staged) {
+        for (int q = q0; q < q1; ++q) {
+          const int e = nadj[q];
+#pragma unroll
+          for (int a = 0; a < 6; ++a) mine[6 * (q - q0) + a] = edof[(size_t)a * ne + e];
+        }
+      }
+      int prev = -1;
+      for (int k = rowptr[i]; k < rowptr[i + 1]; ++k) {
+        int best = 0x7fffffff;
+        if (staged) {
+          for (int j = 0; j < nc; ++j) {
+            const int v = mine[j];
+            best = (v > prev && v < best) ? v : best;
+          }
+        } else {                                            // more than PATTERN_BIG candidates: slow but correct
+          for (int q = q0; q < q1; ++q) {
+            const int e = nadj[q];
+#pragma unroll
+            for (int a = 0; a < 6; ++a) {
+              const int v = edof[(size_t)a * ne + e];
+              best = (v > prev && v < best) ? v : best;
+            }
+          }
+        }
+        put(k, best, threadIdx.x);
+        prev = best;
+      }
+    }
+  }
+  __syncthreads();
+  const int nb = nbig;
+  for (int b = 0; b < nb; ++b) {
+    const int lr = biglist[b], r = i0 + lr;
+    const int q0 = nptr[r], nc = 6 * (nptr[r + 1] - q0);
+    for (int j = threadIdx.x; j < nc; j += 128) big[j] = edof[(size_t)(j % 6) * ne + nadj[q0 + j / 6]];
+    __syncthreads();
+    for (int j = threadIdx.x; j < nc; j += 128) {
+      const int v = big[j];
+      bool first = true;
+      for (int m = 0; m < j; ++m) first = first && big[m] != v;
+      bigfirst[j] = first;
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < nc; j += 128) {
+      if (!bigfirst[j]) continue;
+      const int v = big[j];
+      int rank = 0;
+      for (int m = 0; m < nc; ++m) rank += (bigfirst[m] && big[m] < v) ? 1 : 0;
+      const int k = rowptr[r] + rank;
+      if (k < rowptr[r + 1]) put(k, v, lr);
+    }
+    __syncthreads();
+  }
+  if (buffered) {
+    for (int k = base + threadIdx.x; k < end; k += 128) {
+      colind[k] = outbuf[k - base];
+      slot_row[k] = i0 + outrow[k - base];
+    }
+  }
+}
+
 // Ordered gather of the element-matrix entries into the shared scalar CSR pattern: one lane per CSR
 // slot (i, j) walks the elements adjacent to node i in ascending order and adds the entry of every
 // element that also contains node j -- deterministic, no float atomics, every value written once.
@@ -237,6 +336,11 @@ void launch_element_matrices(plfem_ctx* c, int ncore, double eps_core, double ep
   int grid = (c->ne + EPB - 1) / EPB;
   hipLaunchKernelGGL(k_element_matrices, dim3(grid), dim3(256), 0, c->stream, c->ne, c->N, c->d_tsorted,
                      c->d_doflocs, c->d_cores, ncore, 1.0 / eps_core, 1.0 / eps_clad, k0 * k0, alpha_p, c->d_elem);
+}
+
+void launch_pattern_fill(plfem_ctx* c) {
+  hipLaunchKernelGGL(k_pattern_fill, dim3((c->N + 127) / 128), dim3(128), 0, c->stream, c->N, c->ne, c->d_nptr, c->d_nadj,
+                     c->d_edof, c->d_rowptr, c->d_colind, c->d_slot_row);
 }
 
 void launch_csr_gather(plfem_ctx* c) {

@@ -223,65 +223,94 @@ std::string p2_numbering(int nv, int ne, const double* p, const int32_t* t, Symb
   return "";
 }
 
-// node -> adjacent elements (CSR), elements ascending within each node
-void node_to_elem(Symbolic& S) {
+// node -> adjacent elements (CSR), elements ascending within each node.  Every thread scans the whole
+// element table but only files the nodes of its own range: sequential reads, no shared counters.
+void node_to_elem(Symbolic& S, int nthreads) {
   const int N = S.N, ne = S.ne;
   std::vector<int32_t>& ptr = S.nptr;
   std::vector<int32_t>& adj = S.nadj;
   std::vector<uint8_t>& loc = S.nloc;
   ptr.assign((size_t)N + 1, 0);
-  for (int a = 0; a < 6; ++a)
-    for (int e = 0; e < ne; ++e) ptr[S.edof[(size_t)a * ne + e] + 1]++;
-  for (int i = 0; i < N; ++i) ptr[i + 1] += ptr[i];
   adj.resize((size_t)6 * ne);
   loc.resize((size_t)6 * ne);
-  std::vector<int32_t> fill(ptr.begin(), ptr.end() - 1);
-  for (int e = 0; e < ne; ++e)
-    for (int a = 0; a < 6; ++a) {
-      int32_t i = S.edof[(size_t)a * ne + e];
-      adj[fill[i]] = e;
-      loc[fill[i]] = (uint8_t)a;
-      fill[i]++;
+  const int32_t* d = S.edof.data();
+  parallel_for(N, nthreads, [&](int64_t b, int64_t e_, int) {
+    for (size_t q = 0; q < (size_t)6 * ne; ++q) {
+      const int32_t i = d[q];
+      if (i >= b && i < e_) ptr[i + 1]++;
     }
+  }, 8192);
+  for (int i = 0; i < N; ++i) ptr[i + 1] += ptr[i];
+  parallel_for(N, nthreads, [&](int64_t b, int64_t e_, int) {
+    std::vector<int32_t> fill(ptr.begin() + b, ptr.begin() + e_);
+    for (int e = 0; e < ne; ++e)
+      for (int a = 0; a < 6; ++a) {
+        const int32_t i = d[(size_t)a * ne + e];
+        if (i >= b && i < e_) {
+          int32_t& f = fill[i - b];
+          adj[f] = e;
+          loc[f] = (uint8_t)a;
+          ++f;
+        }
+      }
+  }, 8192);
 }
 
 // ------------------------------------------------------------------------------------------------
-// scalar CSR pattern: row i = sorted union of the DOFs of the elements adjacent to node i
+// scalar CSR pattern: row i = sorted union of the DOFs of the elements adjacent to node i.
+// Row lengths have a closed form that needs no manifold assumption:
+//   vertex v with d adjacent elements and a incident edges: itself + a neighbour vertices + a incident edges
+//     + d opposite edges (one per element, all distinct)            = 1 + 2a + d
+//   edge node with m adjacent elements (1 or 2): 2 + m vertices, itself + 2m other edges  = 3 + 3m
+// so rowptr (and nnz) cost O(N); the column lists themselves are built by the device (k_pattern_fill) or,
+// on demand, by ensure_pattern below.
 // ------------------------------------------------------------------------------------------------
-void csr_pattern(Symbolic& S, int nthreads) {
-  const int N = S.N, ne = S.ne;
-  const std::vector<int32_t>& nptr = S.nptr;
-  const std::vector<int32_t>& nadj = S.nadj;
-  std::vector<int64_t> soff((size_t)N + 1);
-  soff[0] = 0;
-  for (int i = 0; i < N; ++i) soff[i + 1] = soff[i] + 6 * (int64_t)(nptr[i + 1] - nptr[i]);
-  rawvec_i32 scratch((size_t)soff[N]);
-  S.rowptr.assign((size_t)N + 1, 0);
-  parallel_for(N, nthreads, [&](int64_t b, int64_t e_, int) {
-    for (int64_t i = b; i < e_; ++i) {
-      int32_t* s = scratch.data() + soff[i];
-      int n = 0;
-      for (int32_t q = nptr[i]; q < nptr[i + 1]; ++q) {
-        int32_t e = nadj[q];
-        for (int a = 0; a < 6; ++a) s[n++] = S.edof[(size_t)a * ne + e];
-      }
-      std::sort(s, s + n);
-      S.rowptr[i + 1] = (int32_t)(std::unique(s, s + n) - s);
+void csr_rowptr(Symbolic& S, int nthreads) {
+  const int N = S.N, nv = S.nv, nedges = S.nedges;
+  std::vector<int32_t> inc((size_t)nv, 0);                  // edges incident to each vertex
+  const int32_t* ea = S.edges.data();
+  parallel_for(nv, nthreads, [&](int64_t b, int64_t e_, int) {
+    for (size_t q = 0; q < (size_t)2 * nedges; ++q) {
+      const int32_t v = ea[q];
+      if (v >= b && v < e_) inc[v]++;
     }
-  });
-  for (int i = 0; i < N; ++i) S.rowptr[i + 1] += S.rowptr[i];
-  const int64_t nnz = S.rowptr[N];
+  }, 8192);
+  S.rowptr.assign((size_t)N + 1, 0);
+  for (int i = 0; i < N; ++i) {
+    const int d = S.nptr[i + 1] - S.nptr[i];
+    S.rowptr[i + 1] = S.rowptr[i] + (i < nv ? 1 + 2 * inc[i] + d : 3 + 3 * d);
+  }
+  S.colind.clear();
+  S.slot_row.clear();
+}
+
+}  // namespace
+
+void ensure_pattern(const Symbolic& S) {
+  const int N = S.N, ne = S.ne;
+  const int64_t nnz = S.rowptr.empty() ? 0 : S.rowptr[N];
+  if ((int64_t)S.colind.size() == nnz && (int64_t)S.slot_row.size() == nnz) return;
   S.colind.resize(nnz);
   S.slot_row.resize(nnz);
-  parallel_for(N, nthreads, [&](int64_t b, int64_t e_, int) {
-    for (int64_t i = b; i < e_; ++i) {
-      const int32_t* s = scratch.data() + soff[i];
-      const int32_t r0 = S.rowptr[i], len = S.rowptr[i + 1] - r0;
-      std::copy(s, s + len, S.colind.data() + r0);
-      std::fill(S.slot_row.data() + r0, S.slot_row.data() + r0 + len, (int32_t)i);
+  std::vector<int32_t> s;
+  for (int i = 0; i < N; ++i) {
+    s.clear();
+    for (int32_t q = S.nptr[i]; q < S.nptr[i + 1]; ++q) {
+      const int32_t e = S.nadj[q];
+      for (int a = 0; a < 6; ++a) s.push_back(S.edof[(size_t)a * ne + e]);
     }
-  });
+    std::sort(s.begin(), s.end());
+    const int32_t len = (int32_t)(std::unique(s.begin(), s.end()) - s.begin());
+    const int32_t r0 = S.rowptr[i];
+    // the closed-form length is exact for every mesh p2_numbering accepts; keep the arrays in bounds regardless
+    const int32_t n = std::min(len, S.rowptr[i + 1] - r0);
+    std::copy(s.begin(), s.begin() + n, S.colind.begin() + r0);
+    std::fill(S.colind.begin() + r0 + n, S.colind.begin() + S.rowptr[i + 1], -1);
+    std::fill(S.slot_row.begin() + r0, S.slot_row.begin() + S.rowptr[i + 1], (int32_t)i);
+  }
 }
+
+namespace {
 
 // ------------------------------------------------------------------------------------------------
 // element-based geometric nested dissection: complete binary tree of depth L over the elements
@@ -675,8 +704,8 @@ std::string build_symbolic(int nv, int ne, const double* p, const int32_t* t, in
   if (!err.empty()) return err;
   if (S.nsolve < 1) return "mesh has no interior DOF";
   auto t1 = clk::now();
-  node_to_elem(S);
-  csr_pattern(S, nthreads);
+  node_to_elem(S, nthreads);
+  csr_rowptr(S, nthreads);
   auto t2 = clk::now();
   nd_tree(S, leaf_elems, nthreads);
   auto t3 = clk::now();

@@ -41,9 +41,11 @@ struct Symbolic {
   std::vector<int32_t> interior;   // [nsolve] ascending DOF ids
   std::vector<int32_t> int_index;  // [N] DOF -> interior index or -1
   // ---- scalar CSR pattern (full N x N, shared by every block of A and B) ----------------------
+  // rowptr comes from closed-form row lengths; the column lists are built on the DEVICE (k_pattern_fill) for
+  // the hot path and on the host only on demand (ensure_pattern: plfem_symbolic_get("colind" / "slot_row")).
   std::vector<int32_t> rowptr;     // [N+1]
-  rawvec_i32 colind;               // [nnz]
-  rawvec_i32 slot_row;             // [nnz] row of every CSR slot
+  mutable rawvec_i32 colind;       // [nnz]  (lazy on the host)
+  mutable rawvec_i32 slot_row;     // [nnz] row of every CSR slot (lazy on the host)
   // node -> adjacent elements (ascending element ids): the contributions to row i come from these
   std::vector<int32_t> nptr;       // [N+1]
   std::vector<int32_t> nadj;       // [6 ne] element id
@@ -73,6 +75,10 @@ struct Symbolic {
 // Returns empty string on success, error message otherwise.
 std::string build_symbolic(int nv, int ne, const double* p, const int32_t* t, int leaf_elems,
                            int nthreads, Symbolic& S);
+
+// Host copy of the CSR column lists (sorted union of the DOFs of the elements adjacent to each node); no-op
+// if already built.  Not thread-safe against concurrent first calls on the same Symbolic.
+void ensure_pattern(const Symbolic& S);
 
 // P2 numbering only (fills nv..int_index of S): what uniform red refinement needs, since the refined
 // mesh's vertices are exactly the P2 nodes of the coarse mesh (new vertex id = nv + edge id).

@@ -344,3 +344,38 @@ def test_sweep_driver_on_gpu_matches_direct_solves(gpu_device, built_library):
         direct = TrueVectorialMaxwellSolver(g, device=gpu_device).solve_vectorial_modes(mesh, it.n_modes)
         ref = np.array([m["n_eff"] for m in direct])
         assert len(ref) == len(table[it.index]) and np.abs(ref - table[it.index]).max() < 1e-10
+
+
+def _fan_mesh(nfan, rings=2):
+    """A vertex of degree nfan (centre of a disc triangulated as a fan) plus `rings` rings around it."""
+    ang = np.linspace(0.0, 2 * np.pi, nfan, endpoint=False)
+    pts = [np.zeros((2, 1))]
+    for r in range(1, rings + 1):
+        pts.append(r * np.stack([np.cos(ang + 0.5 * r * np.pi / nfan), np.sin(ang + 0.5 * r * np.pi / nfan)]))
+    p = np.concatenate(pts, axis=1)
+    tris = [[0, 1 + j, 1 + (j + 1) % nfan] for j in range(nfan)]
+    for r in range(1, rings):
+        a0, b0 = 1 + (r - 1) * nfan, 1 + r * nfan
+        for j in range(nfan):
+            j1 = (j + 1) % nfan
+            tris += [[a0 + j, b0 + j, a0 + j1], [a0 + j1, b0 + j, b0 + j1]]
+    return np.ascontiguousarray(p), np.ascontiguousarray(np.array(tris, dtype=np.int32).T)
+
+
+@pytest.mark.parametrize("nfan", [8, 16, 40, 300])
+def test_device_built_csr_pattern_matches_host(nfan, gpu_device, built_library):
+    """colind / slot_row are built on the device (k_pattern_fill: per-lane rows, cooperative high-degree rows,
+    slow path beyond 256 adjacent elements); the host builds its own copy on demand.  Both must agree."""
+    p, t = _fan_mesh(nfan)
+    sym = _native.Symbolic(p, t, leaf_elems=8)
+    ctx = _native.Context(sym, gpu_device)
+    nnz = sym.info["nnz"]
+    np.testing.assert_array_equal(ctx.debug_copy("colind", 0, nnz).astype(np.int64), sym.array("colind"))
+    np.testing.assert_array_equal(ctx.debug_copy("slot_row", 0, nnz).astype(np.int64), sym.array("slot_row"))
+    ctx.close()
+
+
+def test_device_built_csr_pattern_on_lantern_mesh(small):
+    nnz = small.sym.info["nnz"]
+    np.testing.assert_array_equal(small.ctx.debug_copy("colind", 0, nnz).astype(np.int64), small.sym.array("colind"))
+    np.testing.assert_array_equal(small.ctx.debug_copy("slot_row", 0, nnz).astype(np.int64), small.sym.array("slot_row"))

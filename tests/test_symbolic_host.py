@@ -164,3 +164,34 @@ def test_malformed_meshes_are_rejected(built_library):
         _native.Symbolic(p[:, :3], np.array([[0], [1], [2]]))
     with pytest.raises(ValueError):
         TriMesh(p, np.array([[0, 1], [1, 2]]))
+
+
+def test_closed_form_row_lengths_on_irregular_topology(built_library):
+    """rowptr comes from closed-form row lengths (1 + 2a + d per vertex, 3 + 3m per edge node); they must equal
+    the lengths of the sorted unique column lists also where the element fan around a vertex is not a disc:
+    a bow-tie vertex, a mesh with a hole, isolated strips."""
+    import scipy.sparse as sp
+    from scipy.spatial import Delaunay
+    rng = np.random.default_rng(11)
+    pts = rng.random((2, 400))
+    tri = Delaunay(pts.T).simplices.T.astype(np.int32)
+    cen = pts[:, tri].mean(axis=1)
+    keep = (np.hypot(cen[0] - 0.5, cen[1] - 0.5) > 0.18) & (rng.random(tri.shape[1]) > 0.25)   # hole + random removals
+    cases = [(pts, tri[:, keep])]
+    # bow tie: two triangles sharing only vertex 2, plus a fan attached to one of them
+    p = np.array([[0.0, 1.0, 0.5, 0.0, 1.0, 1.5], [0.0, 0.0, 0.5, 1.0, 1.0, 0.2]])
+    t = np.array([[0, 1, 2], [2, 3, 4], [1, 5, 2]], dtype=np.int32).T
+    cases.append((p, t))
+    for p, t in cases:
+        used = np.unique(t)
+        remap = -np.ones(p.shape[1], dtype=np.int32); remap[used] = np.arange(len(used), dtype=np.int32)
+        p, t = np.ascontiguousarray(p[:, used]), remap[t]
+        sym = _native.Symbolic(p, t, leaf_elems=4, nthreads=3)
+        ed = sym.array("edof").reshape(6, -1)
+        rows = np.broadcast_to(ed.T[:, :, None], (ed.shape[1], 6, 6)).ravel()
+        cols = np.broadcast_to(ed.T[:, None, :], (ed.shape[1], 6, 6)).ravel()
+        P = sp.coo_matrix((np.ones(rows.size), (rows, cols)), shape=(sym.N, sym.N)).tocsr()
+        P.sort_indices()
+        np.testing.assert_array_equal(sym.array("rowptr"), P.indptr)
+        np.testing.assert_array_equal(sym.array("colind"), P.indices)
+        assert sym.info["nnz"] == P.nnz
