@@ -762,11 +762,7 @@ extern "C" int plfem_debug_copy(plfem_ctx* c, const char* name, int64_t offset, 
 extern "C" int plfem_profile_begin(plfem_ctx* c, int32_t max_launches) {
   if (!c || max_launches < 1) return PLFEM_EINVAL;
   HIP_TRY(c, hipSetDevice(c->device));
-  while ((int)c->prof_ev.size() < 2 * max_launches) {
-    hipEvent_t e;
-    HIP_TRY(c, hipEventCreate(&e));
-    c->prof_ev.push_back(e);
-  }
+  c->prof_max = max_launches;                        // event pairs are created on demand at the launch site
   c->prof_n = 0;
   c->prof_bytes = 0;
   c->prof_on = true;

@@ -80,7 +80,7 @@ struct plfem_ctx {
   hipEvent_t ev_step[2] = {nullptr, nullptr};   // block Lanczos: completion of the two block steps in flight
   // live kernel timing (plfem_profile_*): event pairs around every tile-form forward-sweep launch
   bool prof_on = false;
-  int prof_n = 0;
+  int prof_n = 0, prof_max = 0;
   double prof_bytes = 0;
   std::vector<hipEvent_t> prof_ev;
   double sigma = 0.0, k0 = 0.0;

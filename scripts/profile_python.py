@@ -1,25 +1,29 @@
-"""Host-side overhead hunting at C1: wall time of a cold solve vs its accounted phases, and the cost of
-tearing the previous solver / mode list down (what bench.py's loop pays between steps)."""
-import cProfile, os, pstats, sys, time
+"""Host-side overhead hunting at C1: where the wall time of bench.py's cold-step loop goes beyond the phases
+solve_vectorial_modes accounts for (construction, teardown of the previous solver / mode list)."""
+import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from pl_fem_vectoriel_amd import MCFGeometry, generate_mesh
 from pl_fem_vectoriel_amd.solver_fem import TrueVectorialMaxwellSolver
 g = MCFGeometry(7, 8.0, 1.5, 1.535, 1.0, wavelength_um=1.55)
 mesh = generate_mesh(g, 1.0, 1)
-def once():
-    s = TrueVectorialMaxwellSolver(g, device=0, reuse_symbolic=False)
-    m = s.solve_vectorial_modes(mesh, 10)
-    return s, m
-for _ in range(3): s, m = once()
-for rep in range(4):
+solver = modes = None
+for it in range(8):
     torch.cuda.synchronize(); t0 = time.perf_counter()
-    s2, m2 = once()
+    s = TrueVectorialMaxwellSolver(g, device=0, reuse_symbolic=False)
     t1 = time.perf_counter()
-    st = s2.last_stats
+    m = s.solve_vectorial_modes(mesh, 10)
+    t2 = time.perf_counter()
+    old_modes, modes = modes, m
+    del old_modes
+    t3 = time.perf_counter()
+    ent = list(solver._cache.values()) if solver is not None else []
+    old_solver, solver = solver, s
+    if old_solver is not None:
+        c = old_solver.__dict__.get("_last_ent")
+    del old_solver
+    t4 = time.perf_counter()
+    st = s.last_stats
     acc = st['t_symbolic'] + st['t_context'] + st['t_device'] + st['t_copy_out']
-    ta = time.perf_counter(); del m; tb = time.perf_counter(); del s; tc = time.perf_counter()
-    print(f"solve wall {1e3*(t1-t0):.2f} ms  t_total {1e3*st['t_total']:.2f}  accounted {1e3*acc:.2f} | del modes {1e3*(tb-ta):.2f} ms  del solver {1e3*(tc-tb):.2f} ms")
-    s, m = s2, m2
-pr = cProfile.Profile(); pr.enable(); s2, m2 = once(); del m; del s; pr.disable()
-pstats.Stats(pr).sort_stats('tottime').print_stats(14)
+    print({k: round(1e3 * st[k], 2) for k in ('t_symbolic', 't_context', 't_device', 't_copy_out')}, end="  ")
+    print(f"construct {1e3*(t1-t0):.2f}  solve {1e3*(t2-t1):.2f} (accounted {1e3*acc:.2f})  free modes {1e3*(t3-t2):.2f}  free solver {1e3*(t4-t3):.2f}  total {1e3*(t4-t0):.2f} ms")
