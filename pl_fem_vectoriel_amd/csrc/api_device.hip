@@ -138,8 +138,9 @@ int create_impl(plfem_ctx* c, const plfem_symbolic* sym, int device, void* strea
   const int64_t fnodes_total = S.fnode_ptr[S.nfronts];
   TRY(dalloc(c, &c->d_front, (size_t)S.foff[S.nfronts]));
   TRY(dalloc(c, &c->d_fvec, (size_t)2 * fnodes_total * plfem::BLOCK_P));
-  TRY(dalloc(c, &c->d_wbuf, (size_t)2 * fnodes_total * plfem::NB));
-  TRY(dalloc(c, &c->d_rbuf, (size_t)2 * fnodes_total * plfem::NB));
+  c->fnodes_total = fnodes_total;
+  TRY(dalloc(c, &c->d_wbuf, (size_t)4 * fnodes_total * plfem::NB));   // two halves: panels of even / odd block steps
+  TRY(dalloc(c, &c->d_rbuf, (size_t)4 * fnodes_total * plfem::NB));
   TRY(dalloc(c, &c->d_dinv, (size_t)S.nfronts * plfem::NB * plfem::NB));
   TRY(dalloc(c, &c->d_delta, (size_t)2 * fnodes_total));
   TRY(dalloc(c, &c->d_tbuf, (size_t)2 * fnodes_total * plfem::NB));

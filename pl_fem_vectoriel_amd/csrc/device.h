@@ -36,6 +36,7 @@ struct plfem_ctx {
   std::string err;
   // sizes
   int nv = 0, ne = 0, N = 0, nnz = 0, nsolve = 0, L = 0, nfronts = 0, max_ncv = 0;
+  int64_t fnodes_total = 0;       // sum over fronts of (padded) nodes = fnode_ptr[nfronts]
   int64_t n2 = 0;   // 2N
   std::vector<plfem::LevelInfo> levels;
   // ---- index structures on the device

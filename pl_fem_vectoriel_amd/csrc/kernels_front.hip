@@ -345,10 +345,20 @@ __global__ __launch_bounds__(256) void k_ldl_invrow_panel(int n_inv, int first_f
 // v_mfma_f64_16x16x4_f64 tiles.  MFMA operand map (gfx950): A[row = l&15][k = l>>4],
 // B[k = l>>4][col = l&15], D[row = (l>>4) + 4 r][col = l&15].  With A <- Y rows (j) and B <- W rows
 // (i) the accumulator register r of lane l is F[i0 + (l&15), j0 + (l>>4) + 4 r]: 128-B runs.
+// The read-modify-write of the trailing matrix is what bounds this kernel (2 flop/B at rank 32), so block
+// steps are paired and the matrix is rewritten once per PAIR:
+//   MODE 0, after an even step: a front that has a next step only updates the 32 columns of its next pivot
+//           block (all the next diag / panel kernels read); a front on its last step updates everything.
+//   MODE 1, after an odd step: rank-64 update of the trailing matrix with the panels of both steps
+//           (W0/Y0: the even step's, still valid for every row below the odd pivot block).
+// The panel kernel stores all NB columns of W and Y (zeros past nbk): fixed trip counts, and every operand
+// of a rank-32 batch (32 loads) plus the 16 loads of the tile itself are requested before the first MFMA.
+template <int MODE>
 __global__ __launch_bounds__(256) void k_ldl_update(int first_front, int kb, const int32_t* __restrict__ fs2,
                                                     const int32_t* __restrict__ fm, const int64_t* __restrict__ foff,
                                                     const int64_t* __restrict__ fnode_ptr, double* __restrict__ front,
-                                                    const double* __restrict__ wbuf, const double* __restrict__ rbuf) {
+                                                    const double* __restrict__ wbuf, const double* __restrict__ rbuf,
+                                                    const double* __restrict__ wbuf_prev, const double* __restrict__ rbuf_prev) {
   const int f = first_front + blockIdx.z;
   const int s2 = fs2[f];
   const int k0 = kb * NB;
@@ -360,22 +370,13 @@ __global__ __launch_bounds__(256) void k_ldl_update(int first_front, int kb, con
   const int i0 = t0 + (blockIdx.x * 2 + (wave & 1)) * 32;
   const int j0 = t0 + (blockIdx.y * 2 + (wave >> 1)) * 32;
   if (i0 >= m || j0 >= m) return;
+  // MODE 0 and a next step exists: only the columns of its pivot block now (32, or 16 if it is the front's
+  // last, partial block) -- everything to their right is updated once, by the rank-64 pass after that step
+  const bool next_only = MODE == 0 && t0 < s2;
+  if (next_only && j0 != t0) return;
   double* F = front + foff[f];
-  const double* W = wbuf + 2 * fnode_ptr[f] * NB;
-  const double* Y = rbuf + 2 * fnode_ptr[f] * NB;
   const int lr = lane & 15, lk = lane >> 4;
-  const bool iv1 = i0 + 16 < m, jv1 = j0 + 16 < m;
-  // every operand of the tile is requested before the first MFMA: the panel kernel stores all NB columns
-  // of W and Y (zeros past nbk), so the trip count is fixed and the 32 + 16 loads are in flight together
-  double a0[NB / 4], a1[NB / 4], b0[NB / 4], b1[NB / 4];
-#pragma unroll
-  for (int it = 0; it < NB / 4; ++it) {
-    const int64_t col = (int64_t)(4 * it + lk) * m;
-    a0[it] = Y[col + j0 + lr];
-    a1[it] = jv1 ? Y[col + j0 + 16 + lr] : 0.0;
-    b0[it] = W[col + i0 + lr];
-    b1[it] = iv1 ? W[col + i0 + 16 + lr] : 0.0;
-  }
+  const bool iv1 = i0 + 16 < m, jv1 = j0 + 16 < m && !(next_only && s2 - t0 <= 16);
   double fv[2][2][4];
 #pragma unroll
   for (int tj = 0; tj < 2; ++tj)
@@ -392,11 +393,25 @@ __global__ __launch_bounds__(256) void k_ldl_update(int first_front, int kb, con
 #pragma unroll
     for (int ti = 0; ti < 2; ++ti) acc[tj][ti] = (v4d){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-  for (int it = 0; it < NB / 4; ++it) {
-    acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[it], b0[it], acc[0][0], 0, 0, 0);
-    acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[it], b1[it], acc[0][1], 0, 0, 0);
-    acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[it], b0[it], acc[1][0], 0, 0, 0);
-    acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[it], b1[it], acc[1][1], 0, 0, 0);
+  for (int pass = 0; pass <= MODE; ++pass) {
+    const double* W = (pass == 0 ? wbuf : wbuf_prev) + 2 * fnode_ptr[f] * NB;
+    const double* Y = (pass == 0 ? rbuf : rbuf_prev) + 2 * fnode_ptr[f] * NB;
+    double a0[NB / 4], a1[NB / 4], b0[NB / 4], b1[NB / 4];
+#pragma unroll
+    for (int it = 0; it < NB / 4; ++it) {
+      const int64_t col = (int64_t)(4 * it + lk) * m;
+      a0[it] = Y[col + j0 + lr];
+      a1[it] = jv1 ? Y[col + j0 + 16 + lr] : 0.0;
+      b0[it] = W[col + i0 + lr];
+      b1[it] = iv1 ? W[col + i0 + 16 + lr] : 0.0;
+    }
+#pragma unroll
+    for (int it = 0; it < NB / 4; ++it) {
+      acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[it], b0[it], acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[it], b1[it], acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[it], b0[it], acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[it], b1[it], acc[1][1], 0, 0, 0);
+    }
   }
 #pragma unroll
   for (int tj = 0; tj < 2; ++tj) {
@@ -867,19 +882,27 @@ void launch_factor(plfem_ctx* c, double sigma, int stop_level, int stop_step, in
       hipLaunchKernelGGL(k_ldl_diag, dim3(li.count, 1 + (k0 + 63) / 64), dim3(64), 0, st, li.first, kb, c->d_fs2, c->d_fm, c->d_foff,
                          c->d_fnode_ptr, c->d_front, c->d_dinv, c->d_delta, c->d_tbuf, c->d_counters);
       if (stop_here && stop_stage == 1) return;
+      // W / Y of even and odd steps live in separate halves of wbuf / rbuf (see k_ldl_update)
+      const size_t half = (size_t)2 * c->fnodes_total * NB;
+      double* wb = c->d_wbuf + (kb & 1) * half;
+      double* rb = c->d_rbuf + (kb & 1) * half;
       {
         const int n_inv = kb > 0 ? (k0 + 63) / 64 : 0;
         const int n_pan = max_trail > 0 ? (max_trail + 63) / 64 : 0;
         if (n_inv + n_pan > 0)
           hipLaunchKernelGGL(k_ldl_invrow_panel, dim3(n_inv + n_pan, li.count), dim3(256), 0, st, n_inv, li.first, kb,
                              c->d_fs2, c->d_fm, c->d_foff, c->d_fnode_ptr, c->d_front, c->d_dinv, c->d_delta, c->d_tbuf,
-                             c->d_wbuf, c->d_rbuf);
+                             wb, rb);
       }
       if (stop_here && (stop_stage == 2 || stop_stage == 3)) return;
       if (max_trail > 0) {
         dim3 ug((max_trail + 63) / 64, (max_trail + 63) / 64, li.count);
-        hipLaunchKernelGGL(k_ldl_update, ug, dim3(256), 0, st, li.first, kb, c->d_fs2, c->d_fm, c->d_foff,
-                           c->d_fnode_ptr, c->d_front, c->d_wbuf, c->d_rbuf);
+        if ((kb & 1) == 0)
+          hipLaunchKernelGGL(k_ldl_update<0>, ug, dim3(256), 0, st, li.first, kb, c->d_fs2, c->d_fm, c->d_foff,
+                             c->d_fnode_ptr, c->d_front, wb, rb, wb, rb);
+        else
+          hipLaunchKernelGGL(k_ldl_update<1>, ug, dim3(256), 0, st, li.first, kb, c->d_fs2, c->d_fm, c->d_foff,
+                             c->d_fnode_ptr, c->d_front, wb, rb, c->d_wbuf, c->d_rbuf);
       }
       if (stop_here && stop_stage == 4) return;
     }
