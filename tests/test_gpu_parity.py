@@ -379,3 +379,33 @@ def test_device_built_csr_pattern_on_lantern_mesh(small):
     nnz = small.sym.info["nnz"]
     np.testing.assert_array_equal(small.ctx.debug_copy("colind", 0, nnz).astype(np.int64), small.sym.array("colind"))
     np.testing.assert_array_equal(small.ctx.debug_copy("slot_row", 0, nnz).astype(np.int64), small.sym.array("slot_row"))
+
+
+@pytest.mark.parametrize("arrangement", sorted(__import__("pl_fem_vectoriel_amd.geometry", fromlist=["ARRANGEMENTS"]).ARRANGEMENTS))
+def test_every_arrangement_matches_oracle(arrangement, gpu_device, built_library):
+    """All 13 cross-section types of geometry_unified.py:74-188 on coarse meshes: same modes as the oracle
+    (count after the reference's filters, n_eff, fields) and no pivot perturbation in the factorisation."""
+    from pl_fem_vectoriel_amd.geometry import ARRANGEMENTS
+    n, variant = ARRANGEMENTS[arrangement]
+    g = MCFGeometry(n, 8.0, 1.5, 1.535, 1.0, wavelength_um=1.55, variant=variant)
+    mesh = generate_mesh(g, 0.35, 0)
+    solver = TrueVectorialMaxwellSolver(g, device=gpu_device)
+    modes = solver.solve_vectorial_modes(mesh, n_modes_target=6)
+    ref = hfield.solve_vectorial_modes(g, MeshTriLite(mesh.p, mesh.t), n_modes_target=6, fused=True)
+    assert solver.last_stats["nconv"] == solver.last_stats["n_req"] == 18
+    assert solver.last_stats["pivot_perturbations"] == 0
+    assert len(modes) == len(ref)
+    ne = np.array([m["n_eff"] for m in ref])
+    gap = np.full(len(ne), np.inf)
+    if len(ne) > 1:
+        d = np.abs(np.diff(ne)) / ne[1:]
+        gap[:-1] = np.minimum(gap[:-1], d)
+        gap[1:] = np.minimum(gap[1:], d)
+    for a, b, isolated in zip(modes, ref, gap > 1e-5):
+        assert abs(a["n_eff"] - b["n_eff"]) < N_EFF_TOL
+        if isolated:      # inside a (near-)degenerate pair the basis, hence every per-mode scalar, is arbitrary
+            assert a["polarization"] == b["polarization"]
+            for key in ("confinement", "div_ratio", "PDL_dB"):
+                assert abs(a[key] - b[key]) <= 1e-5 * max(1.0, abs(b[key])), key
+    if modes:
+        assert mode_field_errors(modes, ref, rel_gap=1e-5).max() < FIELD_TOL
