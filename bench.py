@@ -79,9 +79,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise RuntimeError("bench.py needs a GPU: the eigenmode path has no CPU fallback")
+    # Rehearsal of the multi-rank path on a one-GPU box (not a measurement): PLFEM_BENCH_SAME_DEVICE=1 puts every
+    # rank on device 0 and PLFEM_BENCH_BACKEND=gloo replaces RCCL, which refuses two ranks on one device.
+    backend = os.environ.get("PLFEM_BENCH_BACKEND", "nccl")
+    if os.environ.get("PLFEM_BENCH_SAME_DEVICE"):
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     from pl_fem_vectoriel_amd import MCFGeometry, generate_mesh
     from pl_fem_vectoriel_amd.solver_fem import TrueVectorialMaxwellSolver
@@ -120,7 +128,7 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     stats = dict(solver.last_stats)
