@@ -158,7 +158,7 @@ int create_impl(plfem_ctx* c, const plfem_symbolic* sym, int device, void* strea
   TRY(dalloc(c, &c->d_Rinv, 64));
   TRY(dalloc(c, &c->d_t1, n2 * plfem::BLOCK_P));
   TRY(dalloc(c, &c->d_t2, n2 * plfem::BLOCK_P));
-  c->npartial = (int)((c->n2 + 2047) / 2048);
+  c->npartial = (int)((c->n2 + plfem::PANEL_CHUNK - 1) / plfem::PANEL_CHUNK);
   TRY(dalloc(c, &c->d_h, nc1 + 8));
   TRY(dalloc(c, &c->d_hacc, nc1 + 8));
   TRY(dalloc(c, &c->d_partial, (size_t)c->npartial * (nc1 + 8) * plfem::BLOCK_P));

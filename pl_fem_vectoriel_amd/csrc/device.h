@@ -12,6 +12,7 @@
 namespace plfem {
 
 constexpr int NB = 32;          // pivot-block width of the block LDL^T
+constexpr int PANEL_CHUNK = 1024; // rows per partial sum of the tall-skinny panel products
 constexpr int BLOCK_P = 4;      // right-hand sides per block solve / block Lanczos step
 constexpr int ELEM_FORMS = 8;   // Axx Axy Ayx Ayy Minv Dxx Dxy Dyy
 constexpr int ELEM_STRIDE = ELEM_FORMS * 36;

@@ -11,7 +11,7 @@ namespace plfem {
 namespace {
 
 typedef double v4d __attribute__((ext_vector_type(4)));
-constexpr int CHUNK = 2048;   // rows per partial sum
+constexpr int CHUNK = PANEL_CHUNK;   // rows per partial sum
 
 // partial[c * nchunks + chunk] = sum_{i in chunk} P[i, c] * w[i];  one wave per (chunk, column)
 __global__ __launch_bounds__(256) void k_panel_dot(int64_t n, int ncols, int nchunks, const double* __restrict__ P,
@@ -79,30 +79,63 @@ __global__ __launch_bounds__(256) void k_axpby(int64_t n, double a, const double
 }
 
 // ---- block (P-vector) variants for block Lanczos --------------------------------------------------
-// partial[(c*P + q) * nchunks + chunk] = sum_{i in chunk} Pm[i, c] * W[i, q]: one wave per (chunk, column c)
+// partial[(c*P + q) * nchunks + chunk] = sum_{i in chunk} Pm[i, c] * W[i, q].  One wave per (chunk, 4 columns):
+// the P values of W are loaded once for four columns of the panel (a wave per column re-read W from L2 ncols
+// times, which cost more than streaming the panel itself), two row groups per iteration = 16 loads in flight.
 template <int P>
 __global__ __launch_bounds__(256) void k_panel_dot_p(int64_t n, int ncols, int nchunks, const double* __restrict__ Pm,
                                                      const double* __restrict__ W, int64_t ldw,
                                                      double* __restrict__ partial) {
-  const int c = blockIdx.y * 4 + (threadIdx.x >> 6);
-  if (c >= ncols) return;
+  constexpr int CW = 4;                                  // columns per wave
+  const int c0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * CW;
+  if (c0 >= ncols) return;
   const int lane = threadIdx.x & 63;
   const int64_t i0 = (int64_t)blockIdx.x * CHUNK;
   const int64_t i1 = min(n, i0 + CHUNK);
-  const double* col = Pm + (int64_t)c * n;
-  double acc[P];
+  const double* col[CW];
 #pragma unroll
-  for (int q = 0; q < P; ++q) acc[q] = 0.0;
-  for (int64_t i = i0 + lane; i < i1; i += 64) {
-    const double a = col[i];
+  for (int t = 0; t < CW; ++t) col[t] = Pm + (int64_t)min(c0 + t, ncols - 1) * n;   // clamped: result discarded
+  double acc[CW][P];
 #pragma unroll
-    for (int q = 0; q < P; ++q) acc[q] += a * W[(int64_t)q * ldw + i];
+  for (int t = 0; t < CW; ++t)
+#pragma unroll
+    for (int q = 0; q < P; ++q) acc[t][q] = 0.0;
+  int64_t i = i0 + lane;
+  for (; i + 64 < i1; i += 128) {
+    double a[2][CW], w[2][P];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+      for (int t = 0; t < CW; ++t) a[h][t] = col[t][i + 64 * h];
+#pragma unroll
+      for (int q = 0; q < P; ++q) w[h][q] = W[(int64_t)q * ldw + i + 64 * h];
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int t = 0; t < CW; ++t)
+#pragma unroll
+        for (int q = 0; q < P; ++q) acc[t][q] += a[h][t] * w[h][q];
+  }
+  for (; i < i1; i += 64) {
+    double w[P];
+#pragma unroll
+    for (int q = 0; q < P; ++q) w[q] = W[(int64_t)q * ldw + i];
+#pragma unroll
+    for (int t = 0; t < CW; ++t) {
+      const double a = col[t][i];
+#pragma unroll
+      for (int q = 0; q < P; ++q) acc[t][q] += a * w[q];
+    }
   }
 #pragma unroll
-  for (int q = 0; q < P; ++q) {
-    double v = acc[q];
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
-    if (lane == 0) partial[((int64_t)c * P + q) * nchunks + blockIdx.x] = v;
+  for (int t = 0; t < CW; ++t) {
+#pragma unroll
+    for (int q = 0; q < P; ++q) {
+      double v = acc[t][q];
+      for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+      if (lane == 0 && c0 + t < ncols) partial[((int64_t)(c0 + t) * P + q) * nchunks + blockIdx.x] = v;
+    }
   }
 }
 
@@ -370,7 +403,7 @@ void launch_axpby(plfem_ctx* c, double a, const double* x, double b, const doubl
 void launch_panel_dot_block(plfem_ctx* c, const double* Pm, int ncols, const double* W, int64_t ldw, double* h, int ldh) {
   constexpr int P = BLOCK_P;
   const int nchunks = c->npartial;
-  hipLaunchKernelGGL(k_panel_dot_p<P>, dim3(nchunks, (ncols + 3) / 4), dim3(256), 0, c->stream, c->n2, ncols, nchunks,
+  hipLaunchKernelGGL(k_panel_dot_p<P>, dim3(nchunks, (ncols + 15) / 16), dim3(256), 0, c->stream, c->n2, ncols, nchunks,
                      Pm, W, ldw, c->d_partial);
   hipLaunchKernelGGL(k_panel_dot_finish_p, dim3(ncols * P), dim3(64), 0, c->stream, P, nchunks, c->d_partial, h, ldh);
 }
