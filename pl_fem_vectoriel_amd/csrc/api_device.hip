@@ -107,11 +107,34 @@ int create_impl(plfem_ctx* c, const plfem_symbolic* sym, int device, void* strea
       li.sweep_bytes += 8.0 * ((double)fs2[f] * fm[f] - 0.5 * (double)fs2[f] * fs2[f] + fm[f] + fs2[f]);
       li.sweep_vec_doubles += fm[f] + fs2[f];
     }
-    if (li.count > 65535) { c->err = "front tree level exceeds the launch grid limit"; return PLFEM_EINVAL; }
+  }
+  // launch lists of the sweep kernels
+  std::vector<int2> blk;
+  {
+    std::vector<int> order;
+    for (int lev = 0; lev <= S.L; ++lev) {
+      LevelInfo& li = c->levels[lev];
+      order.resize(li.count);
+      std::iota(order.begin(), order.end(), 0);
+      std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+        return (int64_t)fs2[li.first + a] * fm[li.first + a] > (int64_t)fs2[li.first + b] * fm[li.first + b];
+      });
+      li.fwd_rows = plfem::fwd_block_rows(li.count);
+      li.bwd_rows = plfem::bwd_block_rows(li.count, lev == S.L);
+      li.fwd_off = (int64_t)blk.size();
+      for (int q : order)
+        for (int t = 0; t * li.fwd_rows < fm[li.first + q]; ++t) blk.push_back(make_int2(li.first + q, t));
+      li.fwd_n = (int)(blk.size() - li.fwd_off);
+      li.bwd_off = (int64_t)blk.size();
+      for (int q : order)
+        for (int t = 0; t * li.bwd_rows < fs2[li.first + q]; ++t) blk.push_back(make_int2(li.first + q, t));
+      li.bwd_n = (int)(blk.size() - li.bwd_off);
+    }
   }
   auto place = [&]() -> int {
   c->slab_off = 0;
   TRY(upload(c, &c->d_tsorted, S.tsorted));
+  TRY(upload(c, &c->d_blk, blk));
   TRY(upload(c, &c->d_edof, S.edof));
   TRY(upload(c, &c->d_rowptr, S.rowptr));
   TRY(dalloc(c, &c->d_colind, (size_t)c->nnz));      // filled on the device by launch_pattern_fill below

@@ -13,6 +13,10 @@ namespace plfem {
 
 constexpr int NB = 32;          // pivot-block width of the block LDL^T
 constexpr int PANEL_CHUNK = 1024; // rows per partial sum of the tall-skinny panel products
+// sweep kernel forms by level (launch_solve_p and the launch lists must agree)
+constexpr int ROW_FORM_MAX_FRONTS = 32;   // levels with at most this many fronts use the row-form kernels in both sweeps
+inline int fwd_block_rows(int count) { return count <= 8 ? 8 : count <= ROW_FORM_MAX_FRONTS ? 16 : 64; }
+inline int bwd_block_rows(int count, bool leaf) { return leaf ? 64 : count <= ROW_FORM_MAX_FRONTS ? 8 : 16; }
 constexpr int BLOCK_P = 4;      // right-hand sides per block solve / block Lanczos step
 constexpr int ELEM_FORMS = 8;   // Axx Axy Ayx Ayy Minv Dxx Dxy Dyy
 constexpr int ELEM_STRIDE = ELEM_FORMS * 36;
@@ -23,6 +27,11 @@ struct LevelInfo {
   int max_m = 0;    // DOFs
   int max_s2 = 0;
   int max_b2 = 0;
+  // compact launch lists of the sweep kernels (d_blk): one entry per useful workgroup = (front, row block),
+  // fronts in order of decreasing work so that the long ones start first
+  int fwd_rows = 0, bwd_rows = 0;      // rows per workgroup of the forward / backward kernel of this level
+  int64_t fwd_off = 0, bwd_off = 0;    // first entry in d_blk
+  int fwd_n = 0, bwd_n = 0;            // entries = workgroups
   double sweep_bytes = 0;   // algorithmic bytes one forward (or backward) sweep launch of this level moves (1 rhs)
   double sweep_vec_doubles = 0;   // vector doubles (staged + written) per rhs of that launch
 };
@@ -41,6 +50,7 @@ struct plfem_ctx {
   int64_t n2 = 0;   // 2N
   std::vector<plfem::LevelInfo> levels;
   // ---- index structures on the device
+  int2* d_blk = nullptr;          // (front, row block) of every sweep workgroup, level by level
   int32_t *d_tsorted = nullptr, *d_edof = nullptr, *d_rowptr = nullptr, *d_colind = nullptr;
   int32_t *d_slot_row = nullptr, *d_nptr = nullptr, *d_nadj = nullptr, *d_interior = nullptr;
   uint8_t* d_nloc = nullptr;

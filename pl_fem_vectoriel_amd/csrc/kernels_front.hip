@@ -547,6 +547,7 @@ __device__ __forceinline__ void gather_rhs(double (&v)[P], int f, int i, int s2,
   }
 }
 
+constexpr int TILE_BATCH = 8;
 template <int P, int NW>
 __device__ __forceinline__ void tile_sum(double (&out)[P], const double* __restrict__ p, int64_t ld, bool valid,
                                          int cb, int ce, const double* __restrict__ v, double* __restrict__ red) {
@@ -555,21 +556,19 @@ __device__ __forceinline__ void tile_sum(double (&out)[P], const double* __restr
 #pragma unroll
   for (int u = 0; u < P; ++u) acc[u] = 0.0;
   if (valid) {
-    int c = cb + ((wave - cb) & (NW - 1));   // this wave's columns: c == wave (mod NW); 8 loads in flight per lane
-    for (; c + 7 * NW < ce; c += 8 * NW) {
-      double a[8];
+    // this wave's columns: c == wave (mod NW), TILE_BATCH predicated loads in flight per lane -- also for the
+    // last, partial batch (a one-load-per-iteration remainder loop costs a memory round trip per column)
+    for (int c = cb + ((wave - cb) & (NW - 1)); c < ce; c += TILE_BATCH * NW) {
+      double a[TILE_BATCH];
 #pragma unroll
-      for (int t = 0; t < 8; ++t) a[t] = p[(int64_t)(c + NW * t) * ld];
+      for (int t = 0; t < TILE_BATCH; ++t) a[t] = (c + NW * t < ce) ? p[(int64_t)(c + NW * t) * ld] : 0.0;
 #pragma unroll
-      for (int t = 0; t < 8; ++t) {
+      for (int t = 0; t < TILE_BATCH; ++t) {
+        if (c + NW * t < ce) {
 #pragma unroll
-        for (int u = 0; u < P; ++u) acc[u] += a[t] * v[(c + NW * t) * P + u];
+          for (int u = 0; u < P; ++u) acc[u] += a[t] * v[(c + NW * t) * P + u];
+        }
       }
-    }
-    for (; c < ce; c += NW) {
-      const double a = p[(int64_t)c * ld];
-#pragma unroll
-      for (int u = 0; u < P; ++u) acc[u] += a * v[c * P + u];
     }
   }
 #pragma unroll
@@ -585,7 +584,7 @@ __device__ __forceinline__ void tile_sum(double (&out)[P], const double* __restr
 }
 
 template <int P, int NW>
-__global__ __launch_bounds__(NW * 64) void k_fwd(int first_front, int N, int64_t ldx, int leaf_level,
+__global__ __launch_bounds__(NW * 64) void k_fwd(const int2* __restrict__ blk, int N, int64_t ldx, int leaf_level,
                                              const int32_t* __restrict__ fs2, const int32_t* __restrict__ fm,
                                              const int64_t* __restrict__ foff, const int64_t* __restrict__ fnode_ptr,
                                              const int32_t* __restrict__ fnodes, const int32_t* __restrict__ cinv0,
@@ -594,10 +593,10 @@ __global__ __launch_bounds__(NW * 64) void k_fwd(int first_front, int N, int64_t
                                              double* __restrict__ fvec, double* __restrict__ fvec2) {
   extern __shared__ double sv[];
   __shared__ double red[NW * P * 64];
-  const int f = first_front + blockIdx.y;
+  const int2 job = blk[blockIdx.x];
+  const int f = job.x;
   const int m = fm[f], s2 = fs2[f];
-  const int r0 = blockIdx.x * 64;
-  if (r0 >= m) return;
+  const int r0 = job.y * 64;
   const int64_t np = fnode_ptr[f];
   for (int i = threadIdx.x; i < s2; i += NW * 64) {
     double v[P];
@@ -646,17 +645,17 @@ __device__ __forceinline__ void stage_bwd(double* sv, int lo, int m, int s2, int
 }
 
 template <int P, int NW>
-__global__ __launch_bounds__(NW * 64) void k_bwd(int first_front, int N, int64_t ldx, const int32_t* __restrict__ fs2,
+__global__ __launch_bounds__(NW * 64) void k_bwd(const int2* __restrict__ blk, int N, int64_t ldx, const int32_t* __restrict__ fs2,
                                              const int32_t* __restrict__ fm, const int64_t* __restrict__ foff,
                                              const int64_t* __restrict__ fnode_ptr, const int32_t* __restrict__ fnodes,
                                              const double* __restrict__ front, const double* __restrict__ fvec2,
                                              double* __restrict__ x) {
   extern __shared__ double sv[];
   __shared__ double red[NW * P * 64];
-  const int f = first_front + blockIdx.y;
+  const int2 job = blk[blockIdx.x];
+  const int f = job.x;
   const int m = fm[f], s2 = fs2[f];
-  const int r0 = blockIdx.x * 64;
-  if (r0 >= s2) return;
+  const int r0 = job.y * 64;
   const int64_t np = fnode_ptr[f];
   stage_bwd<P>(sv, r0, m, s2, N, ldx, np, fnodes, fvec2, x);
   __syncthreads();
@@ -704,7 +703,7 @@ __device__ __forceinline__ void multi_reduce(double (&a)[V], int lane) {
 // Forward sweep, row form (top of the tree: few large fronts): row r of [L11^-1 ; Z] is contiguous in the mirrored
 // upper storage, a wave owns R rows and runs along their columns; NW R rows share one staged right-hand side.
 template <int P, int NW, int R>
-__global__ __launch_bounds__(NW * 64) void k_fwd_rows(int first_front, int N, int64_t ldx, int leaf_level,
+__global__ __launch_bounds__(NW * 64) void k_fwd_rows(const int2* __restrict__ blk, int N, int64_t ldx, int leaf_level,
                                                       const int32_t* __restrict__ fs2, const int32_t* __restrict__ fm,
                                                       const int64_t* __restrict__ foff, const int64_t* __restrict__ fnode_ptr,
                                                       const int32_t* __restrict__ fnodes, const int32_t* __restrict__ cinv0,
@@ -713,10 +712,10 @@ __global__ __launch_bounds__(NW * 64) void k_fwd_rows(int first_front, int N, in
                                                       double* __restrict__ fvec, double* __restrict__ fvec2) {
   extern __shared__ double sv[];
   constexpr int RB = NW * R, UNR = 8 / R, V = R * P;
-  const int f = first_front + blockIdx.y;
+  const int2 job = blk[blockIdx.x];
+  const int f = job.x;
   const int m = fm[f], s2 = fs2[f];
-  const int j0 = blockIdx.x * RB;
-  if (j0 >= m) return;
+  const int j0 = job.y * RB;
   const int64_t np = fnode_ptr[f];
   const int need = min(s2, j0 + RB);                      // rows < s2 only read r[0 .. row]
   for (int i = threadIdx.x; i < need; i += NW * 64) {
@@ -782,17 +781,17 @@ __global__ __launch_bounds__(NW * 64) void k_fwd_rows(int first_front, int N, in
 // Column j of the lower storage is contiguous in i, so a wave reads 512-byte runs; a wave owns R rows
 // (j0 + wave + NW q) and keeps R x 8/R loads in flight; a block (NW waves) shares one staged vector for NW R rows.
 template <int P, int NW, int R>
-__global__ __launch_bounds__(NW * 64) void k_bwd_rows(int first_front, int N, int64_t ldx, const int32_t* __restrict__ fs2,
+__global__ __launch_bounds__(NW * 64) void k_bwd_rows(const int2* __restrict__ blk, int N, int64_t ldx, const int32_t* __restrict__ fs2,
                                                       const int32_t* __restrict__ fm, const int64_t* __restrict__ foff,
                                                       const int64_t* __restrict__ fnode_ptr,
                                                       const int32_t* __restrict__ fnodes, const double* __restrict__ front,
                                                       const double* __restrict__ fvec2, double* __restrict__ x) {
   extern __shared__ double sv[];
   constexpr int RB = NW * R, UNR = 8 / R, V = R * P;
-  const int f = first_front + blockIdx.y;
+  const int2 job = blk[blockIdx.x];
+  const int f = job.x;
   const int m = fm[f], s2 = fs2[f];
-  const int j0 = blockIdx.x * RB;
-  if (j0 >= s2) return;
+  const int j0 = job.y * RB;
   const int64_t np = fnode_ptr[f];
   stage_bwd<P>(sv, j0 & ~63, m, s2, N, ldx, np, fnodes, fvec2, x);
   __syncthreads();
@@ -922,17 +921,22 @@ static void launch_solve_p(plfem_ctx* c, const double* rhs, double* x, int64_t l
   if (ldx == 0) (void)hipMemsetAsync(x, 0, sizeof(double) * c->n2 * P, st);
   else
     for (int u = 0; u < P; ++u) (void)hipMemsetAsync(x + (int64_t)u * ldx, 0, sizeof(double) * c->n2, st);
-  constexpr int DOT_FORM_MAX_FRONTS = 32;   // levels with at most this many fronts use the row-form kernels in both sweeps
+  // Kernel form by level: fwd_block_rows / bwd_block_rows (device.h); workgroups come from the compact launch
+  // lists of the context (no empty workgroups, large fronts first).  Measured at C1 (P = 4): 4 waves per block in
+  // the forward tile kernel, 8 in every backward form, 2 rows per wave at the mid levels
+  // (scripts/gpu_trace_levels.sh prints the per-level table).
   for (int lev = c->L; lev >= 0; --lev) {
     const LevelInfo& li = c->levels[lev];
     const int leaf = lev == c->L ? 1 : 0;
     const size_t lds = sizeof(double) * P * (li.max_s2 + 1);
-    if (li.count <= 8)
-      hipLaunchKernelGGL((k_fwd_rows<P, 8, 1>), dim3((li.max_m + 7) / 8, li.count), dim3(512), lds, st, li.first, c->N, ldx, leaf,
+    const int2* blk = c->d_blk + li.fwd_off;
+    if (li.fwd_n == 0) continue;
+    if (li.fwd_rows == 8)
+      hipLaunchKernelGGL((k_fwd_rows<P, 8, 1>), dim3(li.fwd_n), dim3(512), lds, st, blk, c->N, ldx, leaf,
                          c->d_fs2, c->d_fm, c->d_foff, c->d_fnode_ptr, c->d_fnodes, c->d_cinv0, c->d_cinv1, c->d_front,
                          c->d_delta, rhs, c->d_fvec, c->d_fvec2);
-    else if (li.count <= DOT_FORM_MAX_FRONTS)
-      hipLaunchKernelGGL((k_fwd_rows<P, 8, 2>), dim3((li.max_m + 15) / 16, li.count), dim3(512), lds, st, li.first, c->N, ldx, leaf,
+    else if (li.fwd_rows == 16)
+      hipLaunchKernelGGL((k_fwd_rows<P, 8, 2>), dim3(li.fwd_n), dim3(512), lds, st, blk, c->N, ldx, leaf,
                          c->d_fs2, c->d_fm, c->d_foff, c->d_fnode_ptr, c->d_fnodes, c->d_cinv0, c->d_cinv1, c->d_front,
                          c->d_delta, rhs, c->d_fvec, c->d_fvec2);
     else {
@@ -944,7 +948,7 @@ static void launch_solve_p(plfem_ctx* c, const double* rhs, double* x, int64_t l
         c->prof_ev.push_back(e);
       }
       if (timed) (void)hipEventRecord(c->prof_ev[2 * c->prof_n], st);
-      hipLaunchKernelGGL((k_fwd<P, 4>), dim3((li.max_m + 63) / 64, li.count), dim3(256), lds, st, li.first, c->N, ldx, leaf,
+      hipLaunchKernelGGL((k_fwd<P, 4>), dim3(li.fwd_n), dim3(256), lds, st, blk, c->N, ldx, leaf,
                          c->d_fs2, c->d_fm, c->d_foff, c->d_fnode_ptr, c->d_fnodes, c->d_cinv0, c->d_cinv1, c->d_front,
                          c->d_delta, rhs, c->d_fvec, c->d_fvec2);
       if (timed) {
@@ -956,18 +960,17 @@ static void launch_solve_p(plfem_ctx* c, const double* rhs, double* x, int64_t l
   }
   for (int lev = 0; lev <= c->L; ++lev) {
     const LevelInfo& li = c->levels[lev];
-    if (li.max_s2 <= 0) continue;
+    if (li.bwd_n == 0) continue;
     const size_t lds = sizeof(double) * P * (li.max_m + 1);
-    // measured at C1 (P = 4): 8 waves per block in every backward form, 2 rows per wave at the mid levels;
-    // the forward tile kernel is best with 4 waves (scripts/gpu_trace_levels.sh prints the per-level table)
-    if (lev == c->L)          // leaf fronts (about as many owned rows as boundary columns): tile form
-      hipLaunchKernelGGL((k_bwd<P, 8>), dim3((li.max_s2 + 63) / 64, li.count), dim3(512), lds, st, li.first, c->N, ldx,
+    const int2* blk = c->d_blk + li.bwd_off;
+    if (li.bwd_rows == 64)    // leaf fronts (about as many owned rows as boundary columns): tile form
+      hipLaunchKernelGGL((k_bwd<P, 8>), dim3(li.bwd_n), dim3(512), lds, st, blk, c->N, ldx,
                          c->d_fs2, c->d_fm, c->d_foff, c->d_fnode_ptr, c->d_fnodes, c->d_front, c->d_fvec2, x);
-    else if (li.count <= DOT_FORM_MAX_FRONTS)   // few large fronts: one row per wave, most blocks
-      hipLaunchKernelGGL((k_bwd_rows<P, 8, 1>), dim3((li.max_s2 + 7) / 8, li.count), dim3(512), lds, st, li.first, c->N, ldx,
+    else if (li.bwd_rows == 8)   // few large fronts: one row per wave, most blocks
+      hipLaunchKernelGGL((k_bwd_rows<P, 8, 1>), dim3(li.bwd_n), dim3(512), lds, st, blk, c->N, ldx,
                          c->d_fs2, c->d_fm, c->d_foff, c->d_fnode_ptr, c->d_fnodes, c->d_front, c->d_fvec2, x);
     else
-      hipLaunchKernelGGL((k_bwd_rows<P, 8, 2>), dim3((li.max_s2 + 15) / 16, li.count), dim3(512), lds, st, li.first, c->N, ldx,
+      hipLaunchKernelGGL((k_bwd_rows<P, 8, 2>), dim3(li.bwd_n), dim3(512), lds, st, blk, c->N, ldx,
                          c->d_fs2, c->d_fm, c->d_foff, c->d_fnode_ptr, c->d_fnodes, c->d_front, c->d_fvec2, x);
   }
 }

@@ -31,6 +31,15 @@ for L in range(nlev):
     vec[L] = 8.0 * (m + s).sum()
     cnt[L] = (lev == L).sum()
 
+# workgroups per level of each sweep (the compact launch lists of the context; rules of csrc/device.h)
+def fwd_rows(count): return 8 if count <= 8 else 16 if count <= 32 else 64
+def bwd_rows(count, leaf): return 64 if leaf else 8 if count <= 32 else 16
+nblk = {}
+for L in range(nlev):
+    s_, m_ = fs[lev == L], fs[lev == L] + fb[lev == L]
+    nblk[("fwd", int(np.ceil(m_ / fwd_rows(cnt[L])).sum()))] = L
+    nblk[("bwd", int(np.ceil(s_ / bwd_rows(cnt[L], L == nlev - 1)).sum()))] = L
+
 rows = list(csv.DictReader(open(sys.argv[1])))
 agg = {}
 for r in rows:
@@ -38,19 +47,17 @@ for r in rows:
     if not m:
         continue
     name, P = m.group(1), int(m.group(2))
-    wg = (int(r["Workgroup_Size_X"]), int(r["Workgroup_Size_Y"]), int(r["Workgroup_Size_Z"]))
-    g = (int(r["Grid_Size_X"]) // wg[0], int(r["Grid_Size_Y"]) // wg[1], int(r["Grid_Size_Z"]) // wg[2])
+    g = int(r["Grid_Size_X"]) // int(r["Workgroup_Size_X"])
     agg.setdefault((name, P, g), []).append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
 
 out = []
-for (name, P, g), d in sorted(agg.items(), key=lambda kv: (kv[0][0][:5], kv[0][1], -kv[0][2][1])):
-    cands = [L for L in range(nlev) if cnt[L] == g[1]]             # grid.y = fronts of the level
-    L = cands[0] if cands else -1
+for (name, P, g), d in sorted(agg.items(), key=lambda kv: (kv[0][0][:5], kv[0][1], -nblk.get((kv[0][0][2:5], kv[0][2]), -1))):
+    L = nblk.get((name[2:5], g), -1)
     us = np.mean(d) / 1e3
     byt = mat[L] + P * vec[L] if L >= 0 else float("nan")
-    out.append({"kernel": name, "P": P, "grid": g, "level": L, "fronts": int(cnt[L]) if L >= 0 else None, "launches": len(d),
+    out.append({"kernel": name, "P": P, "workgroups": g, "level": L, "fronts": int(cnt[L]) if L >= 0 else None, "launches": len(d),
                 "avg_us": round(us, 2), "MB": round(byt / 1e6, 2), "GBps": round(byt / us / 1e3, 1)})
-    print(f"{name:10s} P={P} grid={str(g):18s} level={L:2d} fronts={cnt[L] if L >= 0 else 0:5d} n={len(d):5d} "
+    print(f"{name:10s} P={P} workgroups={g:6d} level={L:2d} fronts={cnt[L] if L >= 0 else 0:5d} n={len(d):5d} "
           f"avg={us:7.2f} us  {byt / 1e6:7.2f} MB  {byt / us / 1e3:8.1f} GB/s")
 for name in ("k_fwd", "k_bwd"):
     for P in (1, 4):
