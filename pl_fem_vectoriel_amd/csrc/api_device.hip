@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
 #include <numeric>
 
 #include "device.h"
@@ -75,6 +76,8 @@ void free_all(plfem_ctx* c) {
     if (e) (void)hipEventDestroy(e);
 }
 
+static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
 int create_impl(plfem_ctx* c, const plfem_symbolic* sym, int device, void* stream, int max_ncv, void* workspace,
                 int64_t workspace_bytes, bool size_only) {
   const Symbolic& S = sym->S;
@@ -108,33 +111,49 @@ int create_impl(plfem_ctx* c, const plfem_symbolic* sym, int device, void* strea
       li.sweep_vec_doubles += fm[f] + fs2[f];
     }
   }
-  // launch lists of the sweep kernels
+  const bool ctx_trace = getenv("PLFEM_CTX_TRACE") != nullptr;
+  const double tt0 = now_ms();
+  // Launch order of the fronts of a level: decreasing s2 (counting sort on s2 / 16, stable).  The fronts still
+  // active at a block step of the factorisation are then a prefix, and in every batched launch the long fronts
+  // start first.  blk: compact launch lists of the sweep kernels, (front, row block) per useful workgroup.
+  std::vector<int32_t> forder(S.nfronts);
+  c->forder_s2.assign(S.nfronts, 0);
+  c->forder_maxm.assign(S.nfronts, 0);
   std::vector<int2> blk;
   {
-    std::vector<int> order;
+    std::vector<int32_t> bucket;
     for (int lev = 0; lev <= S.L; ++lev) {
       LevelInfo& li = c->levels[lev];
-      order.resize(li.count);
-      std::iota(order.begin(), order.end(), 0);
-      std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
-        return (int64_t)fs2[li.first + a] * fm[li.first + a] > (int64_t)fs2[li.first + b] * fm[li.first + b];
-      });
+      int32_t* o = forder.data() + li.first;
+      const int nb = li.max_s2 / 16 + 2;
+      bucket.assign(nb, 0);
+      for (int f = li.first; f < li.first + li.count; ++f) bucket[nb - 2 - fs2[f] / 16 + 1]++;
+      for (int b = 1; b < nb; ++b) bucket[b] += bucket[b - 1];
+      for (int f = li.first; f < li.first + li.count; ++f) o[bucket[nb - 2 - fs2[f] / 16]++] = f;
+      int mx = 0;
+      for (int q = 0; q < li.count; ++q) {
+        mx = std::max(mx, fm[o[q]]);
+        c->forder_s2[li.first + q] = fs2[o[q]];
+        c->forder_maxm[li.first + q] = mx;
+      }
       li.fwd_rows = plfem::fwd_block_rows(li.count);
       li.bwd_rows = plfem::bwd_block_rows(li.count, lev == S.L);
       li.fwd_off = (int64_t)blk.size();
-      for (int q : order)
-        for (int t = 0; t * li.fwd_rows < fm[li.first + q]; ++t) blk.push_back(make_int2(li.first + q, t));
+      for (int q = 0; q < li.count; ++q)
+        for (int t = 0; t * li.fwd_rows < fm[o[q]]; ++t) blk.push_back(make_int2(o[q], t));
       li.fwd_n = (int)(blk.size() - li.fwd_off);
       li.bwd_off = (int64_t)blk.size();
-      for (int q : order)
-        for (int t = 0; t * li.bwd_rows < fs2[li.first + q]; ++t) blk.push_back(make_int2(li.first + q, t));
+      for (int q = 0; q < li.count; ++q)
+        for (int t = 0; t * li.bwd_rows < fs2[o[q]]; ++t) blk.push_back(make_int2(o[q], t));
       li.bwd_n = (int)(blk.size() - li.bwd_off);
     }
   }
+  const double tt1 = now_ms();
   auto place = [&]() -> int {
   c->slab_off = 0;
   TRY(upload(c, &c->d_tsorted, S.tsorted));
   TRY(upload(c, &c->d_blk, blk));
+  TRY(upload(c, &c->d_forder, forder));
   TRY(upload(c, &c->d_edof, S.edof));
   TRY(upload(c, &c->d_rowptr, S.rowptr));
   TRY(dalloc(c, &c->d_colind, (size_t)c->nnz));      // filled on the device by launch_pattern_fill below
@@ -206,7 +225,9 @@ int create_impl(plfem_ctx* c, const plfem_symbolic* sym, int device, void* strea
     c->own_slab = true;
   }
   c->slab_bytes = need;
+  const double tt2 = now_ms();
   TRY(place());                      // pass 1: place + upload
+  const double tt3 = now_ms();
   HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, 4 * sizeof(int32_t), c->stream));
   plfem::launch_pattern_fill(c);
   TRY(check_launch(c, "pattern fill"));
@@ -217,7 +238,9 @@ int create_impl(plfem_ctx* c, const plfem_symbolic* sym, int device, void* strea
     c->h_slots = c->h_pinned + 8192 + nc1p * nc1p;
   }
   HIP_TRY(c, hipEventRecord(c->ev[4][1], c->stream));
+  const double tt4 = now_ms();
   HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (ctx_trace) fprintf(stderr, "[ctx] lists %.3f  size pass %.3f  upload pass %.3f  pinned+launch %.3f  sync %.3f ms\n", tt1 - tt0, tt2 - tt1, tt3 - tt2, tt4 - tt3, now_ms() - tt4);
   c->ev_used[4] = true;
   return PLFEM_OK;
 }

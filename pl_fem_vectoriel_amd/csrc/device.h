@@ -50,6 +50,8 @@ struct plfem_ctx {
   int64_t n2 = 0;   // 2N
   std::vector<plfem::LevelInfo> levels;
   // ---- index structures on the device
+  int32_t* d_forder = nullptr;    // [nfronts] per level: front ids in order of decreasing s2 (factorisation launches)
+  std::vector<int> forder_s2, forder_maxm;   // host: s2 in that order, running max of m in that order
   int2* d_blk = nullptr;          // (front, row block) of every sweep workgroup, level by level
   int32_t *d_tsorted = nullptr, *d_edof = nullptr, *d_rowptr = nullptr, *d_colind = nullptr;
   int32_t *d_slot_row = nullptr, *d_nptr = nullptr, *d_nadj = nullptr, *d_interior = nullptr;

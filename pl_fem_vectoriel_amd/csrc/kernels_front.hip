@@ -115,13 +115,13 @@ __device__ __forceinline__ double readlane_f64(double v, int src) {
   return __hiloint2double(hi, lo);
 }
 
-__global__ __launch_bounds__(64) void k_ldl_diag(int first_front, int kb, const int32_t* __restrict__ fs2,
+__global__ __launch_bounds__(64) void k_ldl_diag(const int32_t* __restrict__ forder, int kb, const int32_t* __restrict__ fs2,
                                                  const int32_t* __restrict__ fm, const int64_t* __restrict__ foff,
                                                  const int64_t* __restrict__ fnode_ptr, double* __restrict__ front,
                                                  double* __restrict__ dinv, double* __restrict__ delta,
                                                  double* __restrict__ tbuf, int32_t* __restrict__ counters) {
   static_assert(NB == 32, "lane map of k_ldl_diag");
-  const int f = first_front + blockIdx.x;
+  const int f = forder[blockIdx.x];
   const int s2 = fs2[f];
   const int k0 = kb * NB;
   if (k0 >= s2) return;
@@ -218,11 +218,11 @@ __global__ __launch_bounds__(64) void k_ldl_diag(int first_front, int kb, const 
 //   T (32 x 16) = L[k, j>=c0] (A: tbuf, contiguous in q) * X<k[j, c] (B: upper mirror, contiguous in c);
 //   the accumulator register r of lane (lr, lk) holds T[lk + 4 r][lr], which is exactly the B operand
 //   of k-step r of the second product  Xnew = -X[k,k] * T  -- no cross-lane movement.
-__device__ __forceinline__ void ldl_invrow_block(int bx, int first_front, int kb, const int32_t* __restrict__ fs2,
+__device__ __forceinline__ void ldl_invrow_block(int bx, const int32_t* __restrict__ forder, int kb, const int32_t* __restrict__ fs2,
                                                  const int32_t* __restrict__ fm, const int64_t* __restrict__ foff,
                                                  const int64_t* __restrict__ fnode_ptr, double* __restrict__ front,
                                                  const double* __restrict__ dinv, const double* __restrict__ tbuf) {
-  const int f = first_front + blockIdx.y;
+  const int f = forder[blockIdx.y];
   const int s2 = fs2[f];
   const int k0 = kb * NB;
   if (k0 >= s2 || k0 == 0) return;
@@ -279,12 +279,12 @@ __device__ __forceinline__ void ldl_invrow_block(int bx, int first_front, int kb
 
 // Panel below the pivot block: Y = R X^T (= R L^-T), W = Y D^-1 (= the L panel).  Saves W, Y for the
 // update kernel and writes W into F (columns of the pivot block) and mirrored (rows).
-__device__ __forceinline__ void ldl_panel_block(int bx, int first_front, int kb, const int32_t* __restrict__ fs2,
+__device__ __forceinline__ void ldl_panel_block(int bx, const int32_t* __restrict__ forder, int kb, const int32_t* __restrict__ fs2,
                                                 const int32_t* __restrict__ fm, const int64_t* __restrict__ foff,
                                                 const int64_t* __restrict__ fnode_ptr, double* __restrict__ front,
                                                 const double* __restrict__ dinv, const double* __restrict__ delta,
                                                 double* __restrict__ wbuf, double* __restrict__ rbuf) {
-  const int f = first_front + blockIdx.y;
+  const int f = forder[blockIdx.y];
   const int s2 = fs2[f];
   const int k0 = kb * NB;
   if (k0 >= s2) return;
@@ -331,14 +331,14 @@ __device__ __forceinline__ void ldl_panel_block(int bx, int first_front, int kb,
 
 // The triangular-inverse update and the panel only depend on the pivot kernel, so one launch runs both:
 // blocks [0, n_inv) of x are invrow blocks, the rest panel blocks.
-__global__ __launch_bounds__(256) void k_ldl_invrow_panel(int n_inv, int first_front, int kb, const int32_t* __restrict__ fs2,
+__global__ __launch_bounds__(256) void k_ldl_invrow_panel(int n_inv, const int32_t* __restrict__ forder, int kb, const int32_t* __restrict__ fs2,
                                                           const int32_t* __restrict__ fm, const int64_t* __restrict__ foff,
                                                           const int64_t* __restrict__ fnode_ptr, double* __restrict__ front,
                                                           const double* __restrict__ dinv, const double* __restrict__ delta,
                                                           const double* __restrict__ tbuf, double* __restrict__ wbuf,
                                                           double* __restrict__ rbuf) {
-  if ((int)blockIdx.x < n_inv) ldl_invrow_block(blockIdx.x, first_front, kb, fs2, fm, foff, fnode_ptr, front, dinv, tbuf);
-  else ldl_panel_block(blockIdx.x - n_inv, first_front, kb, fs2, fm, foff, fnode_ptr, front, dinv, delta, wbuf, rbuf);
+  if ((int)blockIdx.x < n_inv) ldl_invrow_block(blockIdx.x, forder, kb, fs2, fm, foff, fnode_ptr, front, dinv, tbuf);
+  else ldl_panel_block(blockIdx.x - n_inv, forder, kb, fs2, fm, foff, fnode_ptr, front, dinv, delta, wbuf, rbuf);
 }
 
 // Trailing update: F[i,j] -= sum_c W[i,c] Y[j,c] for i, j >= k0 + nbk, one 32x32 tile per wave as 2x2
@@ -354,12 +354,12 @@ __global__ __launch_bounds__(256) void k_ldl_invrow_panel(int n_inv, int first_f
 // The panel kernel stores all NB columns of W and Y (zeros past nbk): fixed trip counts, and every operand
 // of a rank-32 batch (32 loads) plus the 16 loads of the tile itself are requested before the first MFMA.
 template <int MODE>
-__global__ __launch_bounds__(256) void k_ldl_update(int first_front, int kb, const int32_t* __restrict__ fs2,
+__global__ __launch_bounds__(256) void k_ldl_update(const int32_t* __restrict__ forder, int kb, const int32_t* __restrict__ fs2,
                                                     const int32_t* __restrict__ fm, const int64_t* __restrict__ foff,
                                                     const int64_t* __restrict__ fnode_ptr, double* __restrict__ front,
                                                     const double* __restrict__ wbuf, const double* __restrict__ rbuf,
                                                     const double* __restrict__ wbuf_prev, const double* __restrict__ rbuf_prev) {
-  const int f = first_front + blockIdx.z;
+  const int f = forder[blockIdx.z];
   const int s2 = fs2[f];
   const int k0 = kb * NB;
   if (k0 >= s2) return;
@@ -873,12 +873,24 @@ void launch_factor(plfem_ctx* c, double sigma, int stop_level, int stop_step, in
                          c->d_fnode_ptr, c->d_fnodes, c->d_cinv0, c->d_cinv1, c->d_front);
     }
     if (lev == stop_level && stop_stage == 0) return;
+    // Fronts of the level in order of decreasing s2 (c->forder): the fronts still active at block step kb are a
+    // prefix of that order, so every launch only covers them and is sized by the largest ACTIVE front.
     const int steps = (li.max_s2 + NB - 1) / NB;
+    const int32_t* ford = c->d_forder + li.first;
+    const int* hs2 = c->forder_s2.data() + li.first;          // s2 in that order (descending)
+    const int* hpm = c->forder_maxm.data() + li.first;        // running maximum of m in that order
     for (int kb = 0; kb < steps; ++kb) {
       const bool stop_here = (lev == stop_level && kb == stop_step);
       const int k0 = kb * NB;
-      const int max_trail = li.max_m - k0 - 16;   // upper bound of the trailing order after this step
-      hipLaunchKernelGGL(k_ldl_diag, dim3(li.count, 1 + (k0 + 63) / 64), dim3(64), 0, st, li.first, kb, c->d_fs2, c->d_fm, c->d_foff,
+      int nact = 0;                                            // fronts with s2 > k0
+      {
+        int lo = 0, hi = li.count;
+        while (lo < hi) { int mid = (lo + hi) / 2; if (hs2[mid] > k0) lo = mid + 1; else hi = mid; }
+        nact = lo;
+      }
+      if (nact == 0) break;
+      const int max_trail = hpm[nact - 1] - k0 - 16;   // upper bound of the trailing order after this step
+      hipLaunchKernelGGL(k_ldl_diag, dim3(nact, 1 + (k0 + 63) / 64), dim3(64), 0, st, ford, kb, c->d_fs2, c->d_fm, c->d_foff,
                          c->d_fnode_ptr, c->d_front, c->d_dinv, c->d_delta, c->d_tbuf, c->d_counters);
       if (stop_here && stop_stage == 1) return;
       // W / Y of even and odd steps live in separate halves of wbuf / rbuf (see k_ldl_update)
@@ -889,18 +901,18 @@ void launch_factor(plfem_ctx* c, double sigma, int stop_level, int stop_step, in
         const int n_inv = kb > 0 ? (k0 + 63) / 64 : 0;
         const int n_pan = max_trail > 0 ? (max_trail + 63) / 64 : 0;
         if (n_inv + n_pan > 0)
-          hipLaunchKernelGGL(k_ldl_invrow_panel, dim3(n_inv + n_pan, li.count), dim3(256), 0, st, n_inv, li.first, kb,
+          hipLaunchKernelGGL(k_ldl_invrow_panel, dim3(n_inv + n_pan, nact), dim3(256), 0, st, n_inv, ford, kb,
                              c->d_fs2, c->d_fm, c->d_foff, c->d_fnode_ptr, c->d_front, c->d_dinv, c->d_delta, c->d_tbuf,
                              wb, rb);
       }
       if (stop_here && (stop_stage == 2 || stop_stage == 3)) return;
       if (max_trail > 0) {
-        dim3 ug((max_trail + 63) / 64, (max_trail + 63) / 64, li.count);
+        dim3 ug((max_trail + 63) / 64, (max_trail + 63) / 64, nact);
         if ((kb & 1) == 0)
-          hipLaunchKernelGGL(k_ldl_update<0>, ug, dim3(256), 0, st, li.first, kb, c->d_fs2, c->d_fm, c->d_foff,
+          hipLaunchKernelGGL(k_ldl_update<0>, ug, dim3(256), 0, st, ford, kb, c->d_fs2, c->d_fm, c->d_foff,
                              c->d_fnode_ptr, c->d_front, wb, rb, wb, rb);
         else
-          hipLaunchKernelGGL(k_ldl_update<1>, ug, dim3(256), 0, st, li.first, kb, c->d_fs2, c->d_fm, c->d_foff,
+          hipLaunchKernelGGL(k_ldl_update<1>, ug, dim3(256), 0, st, ford, kb, c->d_fs2, c->d_fm, c->d_foff,
                              c->d_fnode_ptr, c->d_front, wb, rb, c->d_wbuf, c->d_rbuf);
       }
       if (stop_here && stop_stage == 4) return;
