@@ -148,11 +148,69 @@ int create_impl(plfem_ctx* c, const plfem_symbolic* sym, int device, void* strea
       li.bwd_n = (int)(blk.size() - li.bwd_off);
     }
   }
+  // 64 x 64 tile lists of the factorisation kernels: only workgroups with work are launched (a dense
+  // (tiles of the largest front)^2 x fronts grid is 85-90 % empty workgroups, which cost ~3 ns each)
+  std::vector<int2> tiles;
+  c->upd_off.clear();
+  c->upd_n.clear();
+  {
+    auto cdiv = [](int a, int b) { return (a + b - 1) / b; };
+    // pass 0 counts (also all the size-only call needs), pass 1 fills
+    int64_t ntiles = 0;
+    for (int pass = 0; pass < (size_only ? 1 : 2); ++pass) {
+      int2* out = nullptr;
+      if (pass == 1) {
+        tiles.resize((size_t)ntiles);
+        out = tiles.data();
+        c->upd_off.clear();
+        c->upd_n.clear();
+      }
+      int64_t pos = 0;
+      auto rect = [&](int f, int ntx, int nty) {         // ntx x nty blocks of front f, x fastest
+        if (out)
+          for (int ty = 0; ty < nty; ++ty)
+            for (int tx = 0; tx < ntx; ++tx) out[pos++] = make_int2(f, tx | (ty << 16));
+        else
+          pos += (int64_t)ntx * nty;
+      };
+      for (int lev = 0; lev <= S.L; ++lev) {
+        LevelInfo& li = c->levels[lev];
+        const int32_t* o = forder.data() + li.first;
+        li.gather_off = pos;
+        if (lev < S.L)
+          for (int q = 0; q < li.count; ++q) {
+            const int nt = cdiv(fm[o[q]], 64);
+            rect(o[q], nt, nt);
+          }
+        li.gather_n = (int)(pos - li.gather_off);
+        li.step0 = (int)c->upd_n.size();
+        const int steps = (li.max_s2 + plfem::NB - 1) / plfem::NB;
+        for (int kb = 0; kb < steps; ++kb) {
+          const int k0 = kb * plfem::NB;
+          c->upd_off.push_back(pos);
+          for (int q = 0; q < li.count && fs2[o[q]] > k0; ++q) {     // active fronts: a prefix of the order
+            const int f = o[q];
+            const int t0 = k0 + std::min(plfem::NB, fs2[f] - k0);
+            const int nt = cdiv(fm[f] - t0, 64);
+            // even step of a front that has a next one: only the block column of its next pivot block (k_ldl_update<0>)
+            rect(f, nt, ((kb & 1) == 0 && t0 < fs2[f]) ? std::min(nt, 1) : nt);
+          }
+          c->upd_n.push_back((int)(pos - c->upd_off.back()));
+        }
+        li.formz_off = pos;
+        for (int q = 0; q < li.count; ++q) rect(o[q], cdiv(fm[o[q]] - fs2[o[q]], 64), cdiv(fs2[o[q]], 64));
+        li.formz_n = (int)(pos - li.formz_off);
+      }
+      ntiles = pos;
+    }
+    if (size_only) tiles.resize((size_t)ntiles);          // only its size matters to the placement pass
+  }
   const double tt1 = now_ms();
   auto place = [&]() -> int {
   c->slab_off = 0;
   TRY(upload(c, &c->d_tsorted, S.tsorted));
   TRY(upload(c, &c->d_blk, blk));
+  TRY(upload(c, &c->d_tiles, tiles));
   TRY(upload(c, &c->d_forder, forder));
   TRY(upload(c, &c->d_edof, S.edof));
   TRY(upload(c, &c->d_rowptr, S.rowptr));

@@ -29,6 +29,10 @@ struct LevelInfo {
   int max_b2 = 0;
   // compact launch lists of the sweep kernels (d_blk): one entry per useful workgroup = (front, row block),
   // fronts in order of decreasing work so that the long ones start first
+  // factorisation: 64 x 64 tile lists (d_tiles) of the extend-add, of Z, and (per block step: upd_off / upd_n of
+  // the context, index step0 + kb) of the trailing updates
+  int64_t gather_off = 0, formz_off = 0;
+  int gather_n = 0, formz_n = 0, step0 = 0;
   int fwd_rows = 0, bwd_rows = 0;      // rows per workgroup of the forward / backward kernel of this level
   int64_t fwd_off = 0, bwd_off = 0;    // first entry in d_blk
   int fwd_n = 0, bwd_n = 0;            // entries = workgroups
@@ -52,6 +56,9 @@ struct plfem_ctx {
   // ---- index structures on the device
   int32_t* d_forder = nullptr;    // [nfronts] per level: front ids in order of decreasing s2 (factorisation launches)
   std::vector<int> forder_s2, forder_maxm;   // host: s2 in that order, running max of m in that order
+  int2* d_tiles = nullptr;        // (front, tx | ty << 16) of every useful 64 x 64 workgroup of the factorisation
+  std::vector<int64_t> upd_off;   // per (level, block step): first entry / entries of the trailing-update list
+  std::vector<int> upd_n;
   int2* d_blk = nullptr;          // (front, row block) of every sweep workgroup, level by level
   int32_t *d_tsorted = nullptr, *d_edof = nullptr, *d_rowptr = nullptr, *d_colind = nullptr;
   int32_t *d_slot_row = nullptr, *d_nptr = nullptr, *d_nadj = nullptr, *d_interior = nullptr;

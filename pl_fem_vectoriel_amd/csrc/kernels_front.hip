@@ -70,13 +70,14 @@ __global__ __launch_bounds__(256) void k_leaf_assemble(
 // Internal fronts: gather formulation of the extend-add.  F[i,j] = S_child0[.,.] + S_child1[.,.]
 // through the inverse index maps; every entry written exactly once (no zero fill, no atomics).
 __global__ __launch_bounds__(256) void k_front_gather(
-    int first_front, const int32_t* __restrict__ fs2, const int32_t* __restrict__ fm,
+    const int2* __restrict__ tiles, const int32_t* __restrict__ fs2, const int32_t* __restrict__ fm,
     const int64_t* __restrict__ foff, const int64_t* __restrict__ fnode_ptr, const int32_t* __restrict__ fnodes,
     const int32_t* __restrict__ cinv0, const int32_t* __restrict__ cinv1, double* __restrict__ front) {
-  const int f = first_front + blockIdx.z;
+  const int2 job = tiles[blockIdx.x];                    // (front, tx | ty << 16): 64 x 64 entries
+  const int f = job.x;
   const int m = fm[f];
-  const int i = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int j0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * 16;
+  const int i = (job.y & 0xffff) * 64 + (threadIdx.x & 63);
+  const int j0 = ((job.y >> 16) * 4 + (threadIdx.x >> 6)) * 16;
   if (i >= m || j0 >= m) return;
   const int64_t np = fnode_ptr[f];
   const int qi = i >> 1, ci = i & 1;
@@ -354,12 +355,13 @@ __global__ __launch_bounds__(256) void k_ldl_invrow_panel(int n_inv, const int32
 // The panel kernel stores all NB columns of W and Y (zeros past nbk): fixed trip counts, and every operand
 // of a rank-32 batch (32 loads) plus the 16 loads of the tile itself are requested before the first MFMA.
 template <int MODE>
-__global__ __launch_bounds__(256) void k_ldl_update(const int32_t* __restrict__ forder, int kb, const int32_t* __restrict__ fs2,
+__global__ __launch_bounds__(256) void k_ldl_update(const int2* __restrict__ tiles, int kb, const int32_t* __restrict__ fs2,
                                                     const int32_t* __restrict__ fm, const int64_t* __restrict__ foff,
                                                     const int64_t* __restrict__ fnode_ptr, double* __restrict__ front,
                                                     const double* __restrict__ wbuf, const double* __restrict__ rbuf,
                                                     const double* __restrict__ wbuf_prev, const double* __restrict__ rbuf_prev) {
-  const int f = forder[blockIdx.z];
+  const int2 job = tiles[blockIdx.x];                    // (front, tx | ty << 16): a 64 x 64 block of the trailing matrix
+  const int f = job.x;
   const int s2 = fs2[f];
   const int k0 = kb * NB;
   if (k0 >= s2) return;
@@ -367,8 +369,8 @@ __global__ __launch_bounds__(256) void k_ldl_update(const int32_t* __restrict__ 
   const int nbk = min(NB, s2 - k0);
   const int t0 = k0 + nbk;                 // first trailing index (multiple of 16)
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int i0 = t0 + (blockIdx.x * 2 + (wave & 1)) * 32;
-  const int j0 = t0 + (blockIdx.y * 2 + (wave >> 1)) * 32;
+  const int i0 = t0 + ((job.y & 0xffff) * 2 + (wave & 1)) * 32;
+  const int j0 = t0 + ((job.y >> 16) * 2 + (wave >> 1)) * 32;
   if (i0 >= m || j0 >= m) return;
   // MODE 0 and a next step exists: only the columns of its pivot block now (32, or 16 if it is the front's
   // last, partial block) -- everything to their right is updated once, by the rank-64 pass after that step
@@ -430,15 +432,16 @@ __global__ __launch_bounds__(256) void k_ldl_update(const int32_t* __restrict__ 
 // sweep of a front is ONE product [L11^-1; Z] r and the backward sweep ONE product [L11^-1; -Z]^T [D^-1 y; x_b].
 // Z^T (s2 x b2) is written into the F12 mirror region (F21 = L21 and the upper mirror of L11^-1 are
 // only read), 32x32 tile per wave on v_mfma_f64_16x16x4_f64; k_mirror_z then copies it back into F21.
-__global__ __launch_bounds__(256) void k_form_z(int first_front, const int32_t* __restrict__ fs2,
+__global__ __launch_bounds__(256) void k_form_z(const int2* __restrict__ tiles, const int32_t* __restrict__ fs2,
                                                 const int32_t* __restrict__ fm, const int64_t* __restrict__ foff,
                                                 double* __restrict__ front) {
-  const int f = first_front + blockIdx.z;
+  const int2 job = tiles[blockIdx.x];                    // (front, tx | ty << 16): 64 x 64 entries of Z
+  const int f = job.x;
   const int m = fm[f], s2 = fs2[f];
   const int b2 = m - s2;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int b0 = (blockIdx.x * 2 + (wave & 1)) * 32;     // rows of Z (boundary DOFs)
-  const int c0 = (blockIdx.y * 2 + (wave >> 1)) * 32;     // columns of Z (owned DOFs)
+  const int b0 = ((job.y & 0xffff) * 2 + (wave & 1)) * 32;     // rows of Z (boundary DOFs)
+  const int c0 = ((job.y >> 16) * 2 + (wave >> 1)) * 32;       // columns of Z (owned DOFs)
   if (b0 >= b2 || c0 >= s2) return;
   double* F = front + foff[f];
   const int lr = lane & 15, lk = lane >> 4;
@@ -472,13 +475,15 @@ __global__ __launch_bounds__(256) void k_form_z(int first_front, const int32_t* 
 }
 
 // F21[b, c] = F12[c, b] through a 32x32 LDS tile
-__global__ __launch_bounds__(256) void k_mirror_z(int first_front, const int32_t* __restrict__ fs2,
+__global__ __launch_bounds__(256) void k_mirror_z(const int2* __restrict__ tiles, const int32_t* __restrict__ fs2,
                                                   const int32_t* __restrict__ fm, const int64_t* __restrict__ foff,
                                                   double* __restrict__ front) {
-  const int f = first_front + blockIdx.z;
+  // one 64 x 64 entry of the k_form_z list = four 32 x 32 tiles, blockIdx.y picks one
+  const int2 job = tiles[blockIdx.x];
+  const int f = job.x;
   const int m = fm[f], s2 = fs2[f];
   const int b2 = m - s2;
-  const int b0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+  const int b0 = ((job.y & 0xffff) * 2 + (blockIdx.y & 1)) * 32, c0 = ((job.y >> 16) * 2 + (blockIdx.y >> 1)) * 32;
   if (b0 >= b2 || c0 >= s2) return;
   __shared__ double tile[32][33];
   double* F = front + foff[f];
@@ -868,9 +873,9 @@ void launch_factor(plfem_ctx* c, double sigma, int stop_level, int stop_step, in
                          c->d_fnode_ptr, c->d_fnodes, c->d_leaf_elem_ptr, c->d_leaf_elems, c->d_epos, c->d_elem,
                          c->d_front);
     } else {
-      dim3 grid((li.max_m + 63) / 64, (li.max_m + 63) / 64, li.count);
-      hipLaunchKernelGGL(k_front_gather, grid, dim3(256), 0, st, li.first, c->d_fs2, c->d_fm, c->d_foff,
-                         c->d_fnode_ptr, c->d_fnodes, c->d_cinv0, c->d_cinv1, c->d_front);
+      if (li.gather_n > 0)
+        hipLaunchKernelGGL(k_front_gather, dim3(li.gather_n), dim3(256), 0, st, c->d_tiles + li.gather_off, c->d_fs2, c->d_fm,
+                           c->d_foff, c->d_fnode_ptr, c->d_fnodes, c->d_cinv0, c->d_cinv1, c->d_front);
     }
     if (lev == stop_level && stop_stage == 0) return;
     // Fronts of the level in order of decreasing s2 (c->forder): the fronts still active at block step kb are a
@@ -906,22 +911,22 @@ void launch_factor(plfem_ctx* c, double sigma, int stop_level, int stop_step, in
                              wb, rb);
       }
       if (stop_here && (stop_stage == 2 || stop_stage == 3)) return;
-      if (max_trail > 0) {
-        dim3 ug((max_trail + 63) / 64, (max_trail + 63) / 64, nact);
+      const int un = c->upd_n[li.step0 + kb];                  // 64 x 64 blocks of this step's trailing updates
+      if (un > 0) {
+        const int2* ut = c->d_tiles + c->upd_off[li.step0 + kb];
         if ((kb & 1) == 0)
-          hipLaunchKernelGGL(k_ldl_update<0>, ug, dim3(256), 0, st, ford, kb, c->d_fs2, c->d_fm, c->d_foff,
+          hipLaunchKernelGGL(k_ldl_update<0>, dim3(un), dim3(256), 0, st, ut, kb, c->d_fs2, c->d_fm, c->d_foff,
                              c->d_fnode_ptr, c->d_front, wb, rb, wb, rb);
         else
-          hipLaunchKernelGGL(k_ldl_update<1>, ug, dim3(256), 0, st, ford, kb, c->d_fs2, c->d_fm, c->d_foff,
+          hipLaunchKernelGGL(k_ldl_update<1>, dim3(un), dim3(256), 0, st, ut, kb, c->d_fs2, c->d_fm, c->d_foff,
                              c->d_fnode_ptr, c->d_front, wb, rb, c->d_wbuf, c->d_rbuf);
       }
       if (stop_here && stop_stage == 4) return;
     }
-    if (li.max_b2 > 0 && li.max_s2 > 0) {
-      dim3 zg((li.max_b2 + 63) / 64, (li.max_s2 + 63) / 64, li.count);
-      hipLaunchKernelGGL(k_form_z, zg, dim3(256), 0, st, li.first, c->d_fs2, c->d_fm, c->d_foff, c->d_front);
-      dim3 mg((li.max_b2 + 31) / 32, (li.max_s2 + 31) / 32, li.count);
-      hipLaunchKernelGGL(k_mirror_z, mg, dim3(256), 0, st, li.first, c->d_fs2, c->d_fm, c->d_foff, c->d_front);
+    if (li.formz_n > 0) {
+      const int2* zt = c->d_tiles + li.formz_off;
+      hipLaunchKernelGGL(k_form_z, dim3(li.formz_n), dim3(256), 0, st, zt, c->d_fs2, c->d_fm, c->d_foff, c->d_front);
+      hipLaunchKernelGGL(k_mirror_z, dim3(li.formz_n, 4), dim3(256), 0, st, zt, c->d_fs2, c->d_fm, c->d_foff, c->d_front);
     }
     if (lev == stop_level && stop_stage == 5) return;
   }
