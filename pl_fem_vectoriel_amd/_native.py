@@ -64,6 +64,10 @@ def load_library() -> ctypes.CDLL:
             f"libplfem_hip.so requis: {LIB_PATH} not found — build it with "
             "`python -c 'import __graft_entry__ as g; g.build()'` (hipcc --offload-arch=gfx950). "
             "There is no CPU fallback for the eigenmode path.")
+    # torch first: the wheel bundles its own libamdhip64 and the context's device memory comes from torch.  If this
+    # library were loaded before torch, the process would hold TWO HIP runtimes (the system one bound here, torch's
+    # own) and plfem_create would see no device in the one it is bound to.
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     c_void_pp = ctypes.POINTER(ctypes.c_void_p)
     lib.plfem_symbolic_create.argtypes = [ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p,

@@ -409,3 +409,19 @@ def test_every_arrangement_matches_oracle(arrangement, gpu_device, built_library
                 assert abs(a[key] - b[key]) <= 1e-5 * max(1.0, abs(b[key])), key
     if modes:
         assert mode_field_errors(modes, ref, rel_gap=1e-5).max() < FIELD_TOL
+
+
+def test_package_first_import_order_in_a_fresh_process(built_library):
+    """Importing the package (and loading libplfem_hip.so) before torch must still end with ONE HIP runtime in the
+    process: the loader pulls torch in first (the wheel bundles its own libamdhip64)."""
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r)\\n"
+            "from pl_fem_vectoriel_amd import MCFGeometry, generate_mesh, _native\\n"
+            "g = MCFGeometry(2, 8.0, 1.5, 1.535, 1.0)\\n"
+            "m = generate_mesh(g, 0.3, 0)\\n"
+            "s = _native.Symbolic(m.p, m.t)\\n"
+            "c = _native.Context(s, 0)\\n"
+            "print('ok', s.N)\\n") % root
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.strip().startswith("ok"), out.stderr[-2000:]
