@@ -416,12 +416,13 @@ def test_package_first_import_order_in_a_fresh_process(built_library):
     process: the loader pulls torch in first (the wheel bundles its own libamdhip64)."""
     import subprocess, sys, os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = ("import sys; sys.path.insert(0, %r)\\n"
-            "from pl_fem_vectoriel_amd import MCFGeometry, generate_mesh, _native\\n"
-            "g = MCFGeometry(2, 8.0, 1.5, 1.535, 1.0)\\n"
-            "m = generate_mesh(g, 0.3, 0)\\n"
-            "s = _native.Symbolic(m.p, m.t)\\n"
-            "c = _native.Context(s, 0)\\n"
-            "print('ok', s.N)\\n") % root
+    code = "\n".join([
+        "import sys; sys.path.insert(0, %r)" % root,
+        "from pl_fem_vectoriel_amd import MCFGeometry, generate_mesh, _native",
+        "g = MCFGeometry(2, 8.0, 1.5, 1.535, 1.0)",
+        "m = generate_mesh(g, 0.3, 0)",
+        "s = _native.Symbolic(m.p, m.t)",
+        "c = _native.Context(s, 0)",
+        "print('ok', s.N)"])
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and out.stdout.strip().startswith("ok"), out.stderr[-2000:]
