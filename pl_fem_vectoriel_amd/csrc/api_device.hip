@@ -23,6 +23,13 @@ using plfem::Symbolic;
     }                                                                                        \
   } while (0)
 
+namespace plfem {
+std::vector<hipEvent_t>& profile_event_pool() {
+  static std::vector<hipEvent_t>* pool = new std::vector<hipEvent_t>();   // never destroyed: outlives every context
+  return *pool;
+}
+}  // namespace plfem
+
 namespace {
 
 // Every device buffer of a context is carved out of ONE slab (caller-provided, e.g. a torch tensor
@@ -71,7 +78,6 @@ void free_all(plfem_ctx* c) {
   for (auto& pr : c->ev)
     for (auto& e : pr)
       if (e) (void)hipEventDestroy(e);
-  for (auto& e : c->prof_ev) (void)hipEventDestroy(e);
   for (auto& e : c->ev_step)
     if (e) (void)hipEventDestroy(e);
 }
@@ -868,6 +874,7 @@ extern "C" int plfem_profile_begin(plfem_ctx* c, int32_t max_launches) {
   if (!c || max_launches < 1) return PLFEM_EINVAL;
   HIP_TRY(c, hipSetDevice(c->device));
   c->prof_max = max_launches;                        // event pairs are created on demand at the launch site
+  c->prof_ev = &plfem::profile_event_pool();
   c->prof_n = 0;
   c->prof_bytes = 0;
   c->prof_on = true;
@@ -881,7 +888,7 @@ extern "C" int plfem_profile_end(plfem_ctx* c, double* out_host) {
   double total_us = 0;
   for (int q = 0; q < c->prof_n; ++q) {
     float ms = 0;
-    HIP_TRY(c, hipEventElapsedTime(&ms, c->prof_ev[2 * q], c->prof_ev[2 * q + 1]));
+    HIP_TRY(c, hipEventElapsedTime(&ms, (*c->prof_ev)[2 * q], (*c->prof_ev)[2 * q + 1]));
     total_us += ms * 1e3;
   }
   out_host[0] = c->prof_n;

@@ -103,7 +103,7 @@ struct plfem_ctx {
   bool prof_on = false;
   int prof_n = 0, prof_max = 0;
   double prof_bytes = 0;
-  std::vector<hipEvent_t> prof_ev;
+  std::vector<hipEvent_t>* prof_ev = nullptr;   // process-wide pool (profile_event_pool), reused by successive contexts
   double sigma = 0.0, k0 = 0.0;
   hipEvent_t ev[5][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
   bool ev_used[5] = {false, false, false, false, false};
@@ -118,6 +118,9 @@ void launch_csr_gather(plfem_ctx* c);
 void launch_pattern_fill(plfem_ctx* c);   // colind / slot_row from the node -> element adjacency (once per context)
 void launch_spmv(plfem_ctx* c, int which, const double* x, double* y);
 void launch_spmv_b_block(plfem_ctx* c, const double* x, double* y, int64_t ld);   // y_q = B x_q, BLOCK_P vectors
+// process-wide pool of timing events for plfem_profile_*: contexts come and go in a cold-solve loop, the events
+// (a few hundred, ~10 us each to create) stay
+std::vector<hipEvent_t>& profile_event_pool();
 // kernels_front.hip
 void launch_factor(plfem_ctx* c, double sigma, int stop_level = -1, int stop_step = 0, int stop_stage = 0);
 void launch_solve(plfem_ctx* c, const double* rhs, double* x);

@@ -959,17 +959,17 @@ static void launch_solve_p(plfem_ctx* c, const double* rhs, double* x, int64_t l
     else {
       // optional live timing of this kernel (bench.py roofline): HIP events on the launch stream
       bool timed = c->prof_on && c->prof_n < c->prof_max;
-      while (timed && (int)c->prof_ev.size() < 2 * (c->prof_n + 1)) {
+      while (timed && (int)c->prof_ev->size() < 2 * (c->prof_n + 1)) {
         hipEvent_t e;
         if (hipEventCreate(&e) != hipSuccess) { timed = false; break; }
-        c->prof_ev.push_back(e);
+        c->prof_ev->push_back(e);
       }
-      if (timed) (void)hipEventRecord(c->prof_ev[2 * c->prof_n], st);
+      if (timed) (void)hipEventRecord((*c->prof_ev)[2 * c->prof_n], st);
       hipLaunchKernelGGL((k_fwd<P, 4>), dim3(li.fwd_n), dim3(256), lds, st, blk, c->N, ldx, leaf,
                          c->d_fs2, c->d_fm, c->d_foff, c->d_fnode_ptr, c->d_fnodes, c->d_cinv0, c->d_cinv1, c->d_front,
                          c->d_delta, rhs, c->d_fvec, c->d_fvec2);
       if (timed) {
-        (void)hipEventRecord(c->prof_ev[2 * c->prof_n + 1], st);
+        (void)hipEventRecord((*c->prof_ev)[2 * c->prof_n + 1], st);
         c->prof_bytes += li.sweep_bytes + 8.0 * (P - 1) * li.sweep_vec_doubles;
         ++c->prof_n;
       }

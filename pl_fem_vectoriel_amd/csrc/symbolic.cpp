@@ -104,6 +104,7 @@ struct Trace {
 // P2 numbering, scikit-fem compatible (MeshTri sort_t + build_entities + ElementTriP2 dof layout)
 // ------------------------------------------------------------------------------------------------
 std::string p2_numbering(int nv, int ne, const double* p, const int32_t* t, Symbolic& S) {
+  Trace tr;
   S.nv = nv;
   S.ne = ne;
   S.tsorted.resize((size_t)3 * ne);
@@ -124,6 +125,7 @@ std::string p2_numbering(int nv, int ne, const double* p, const int32_t* t, Symb
   });
   if (bad_t.load() == 1) return "mesh.t refers to a vertex outside mesh.p";
   if (bad_t.load() == 2) return "degenerate element (repeated vertex)";
+  tr.lap("num: sort columns");
   // edges bucketed by their smaller vertex: local edges (0,1),(1,2),(0,2) -> (t0,t1),(t1,t2),(t0,t2)
   std::vector<int32_t> cnt((size_t)nv + 1, 0);
   for (int e = 0; e < ne; ++e) { cnt[t0[e] + 1] += 2; cnt[t1[e] + 1] += 1; }
@@ -137,6 +139,7 @@ std::string p2_numbering(int nv, int ne, const double* p, const int32_t* t, Symb
       nb[fill[t0[e]]++] = t2[e];
     }
   }
+  tr.lap("num: bucket edges");
   // sort + unique each bucket; edge id = running count => lexicographic (min, max) rank
   // (two passes so that the per-vertex work runs on the worker pool: sort + count, prefix, write)
   std::vector<int32_t> eoff((size_t)nv + 1, 0);
@@ -179,6 +182,7 @@ std::string p2_numbering(int nv, int ne, const double* p, const int32_t* t, Symb
       }
     }
   });
+  tr.lap("num: unique edges");
   S.nedges = nedges_total;
   S.edges.resize((size_t)2 * S.nedges);
   std::copy(ea.begin(), ea.end(), S.edges.begin());
@@ -202,6 +206,7 @@ std::string p2_numbering(int nv, int ne, const double* p, const int32_t* t, Symb
       d[(size_t)5 * ne + e] = nv + edge_id(t0[e], t2[e]);
     }
   });
+  tr.lap("num: edof");
   S.doflocs.resize((size_t)2 * N);
   std::memcpy(S.doflocs.data(), p, sizeof(double) * nv);
   std::memcpy(S.doflocs.data() + N, p + nv, sizeof(double) * nv);
@@ -211,6 +216,7 @@ std::string p2_numbering(int nv, int ne, const double* p, const int32_t* t, Symb
       S.doflocs[(size_t)N + nv + k] = 0.5 * (p[nv + ea[k]] + p[nv + eb[k]]);
     }
   });
+  tr.lap("num: doflocs");
   S.bmask.assign(N, 0);
   for (int k = 0; k < S.nedges; ++k)
     if (mult[k] == 1) { S.bmask[ea[k]] = 1; S.bmask[eb[k]] = 1; S.bmask[nv + k] = 1; }
@@ -220,6 +226,7 @@ std::string p2_numbering(int nv, int ne, const double* p, const int32_t* t, Symb
   for (int i = 0; i < N; ++i)
     if (!S.bmask[i]) { S.int_index[i] = (int32_t)S.interior.size(); S.interior.push_back(i); }
   S.nsolve = (int)S.interior.size();
+  tr.lap("num: boundary + interior");
   return "";
 }
 
