@@ -217,14 +217,36 @@ std::string p2_numbering(int nv, int ne, const double* p, const int32_t* t, Symb
     }
   });
   tr.lap("num: doflocs");
+  // boundary = vertices and mid-edge node of every edge with a single adjacent element; every byte of bmask has
+  // one writer value (1), so the edge loop can run on the pool
   S.bmask.assign(N, 0);
-  for (int k = 0; k < S.nedges; ++k)
-    if (mult[k] == 1) { S.bmask[ea[k]] = 1; S.bmask[eb[k]] = 1; S.bmask[nv + k] = 1; }
-  S.int_index.assign(N, -1);
-  S.interior.clear();
-  S.interior.reserve(N);
-  for (int i = 0; i < N; ++i)
-    if (!S.bmask[i]) { S.int_index[i] = (int32_t)S.interior.size(); S.interior.push_back(i); }
+  uint8_t* bm = S.bmask.data();
+  parallel_for(S.nedges, nth, [&](int64_t k0, int64_t k1, int) {
+    for (int64_t k = k0; k < k1; ++k)
+      if (mult[k] == 1) { bm[ea[k]] = 1; bm[eb[k]] = 1; bm[nv + k] = 1; }
+  });
+  // interior list / inverse map: per-chunk counts, prefix, fill
+  S.int_index.resize(N);
+  {
+    const int nt = nth > 1 && N >= 4096 && g_pool ? g_pool->nt : 1;
+    const int64_t chunk = ((int64_t)N + nt - 1) / nt;
+    std::vector<int32_t> cnt((size_t)nt + 1, 0);
+    parallel_for(N, nt, [&](int64_t b, int64_t e_, int tid) {
+      int32_t c = 0;
+      for (int64_t i = b; i < e_; ++i) c += bm[i] == 0;
+      cnt[tid + 1] = c;
+    }, 1);
+    for (int t2 = 0; t2 < nt; ++t2) cnt[t2 + 1] += cnt[t2];
+    S.interior.resize(cnt[nt]);
+    parallel_for(N, nt, [&](int64_t b, int64_t e_, int tid) {
+      int32_t pos = cnt[tid];
+      for (int64_t i = b; i < e_; ++i) {
+        if (bm[i]) S.int_index[i] = -1;
+        else { S.int_index[i] = pos; S.interior[pos++] = (int32_t)i; }
+      }
+    }, 1);
+    (void)chunk;
+  }
   S.nsolve = (int)S.interior.size();
   tr.lap("num: boundary + interior");
   return "";
