@@ -223,7 +223,7 @@ __device__ __forceinline__ void ldl_invrow_block(int bx, const int32_t* __restri
                                                  const int32_t* __restrict__ fm, const int64_t* __restrict__ foff,
                                                  const int64_t* __restrict__ fnode_ptr, double* __restrict__ front,
                                                  const double* __restrict__ dinv, const double* __restrict__ tbuf) {
-  const int f = forder[blockIdx.y];
+  const int f = forder[blockIdx.x];      // fronts along x (no 65535 limit), block index within the front along y
   const int s2 = fs2[f];
   const int k0 = kb * NB;
   if (k0 >= s2 || k0 == 0) return;
@@ -285,7 +285,7 @@ __device__ __forceinline__ void ldl_panel_block(int bx, const int32_t* __restric
                                                 const int64_t* __restrict__ fnode_ptr, double* __restrict__ front,
                                                 const double* __restrict__ dinv, const double* __restrict__ delta,
                                                 double* __restrict__ wbuf, double* __restrict__ rbuf) {
-  const int f = forder[blockIdx.y];
+  const int f = forder[blockIdx.x];      // fronts along x (no 65535 limit), block index within the front along y
   const int s2 = fs2[f];
   const int k0 = kb * NB;
   if (k0 >= s2) return;
@@ -331,15 +331,15 @@ __device__ __forceinline__ void ldl_panel_block(int bx, const int32_t* __restric
 }
 
 // The triangular-inverse update and the panel only depend on the pivot kernel, so one launch runs both:
-// blocks [0, n_inv) of x are invrow blocks, the rest panel blocks.
+// blocks [0, n_inv) of y are invrow blocks, the rest panel blocks.
 __global__ __launch_bounds__(256) void k_ldl_invrow_panel(int n_inv, const int32_t* __restrict__ forder, int kb, const int32_t* __restrict__ fs2,
                                                           const int32_t* __restrict__ fm, const int64_t* __restrict__ foff,
                                                           const int64_t* __restrict__ fnode_ptr, double* __restrict__ front,
                                                           const double* __restrict__ dinv, const double* __restrict__ delta,
                                                           const double* __restrict__ tbuf, double* __restrict__ wbuf,
                                                           double* __restrict__ rbuf) {
-  if ((int)blockIdx.x < n_inv) ldl_invrow_block(blockIdx.x, forder, kb, fs2, fm, foff, fnode_ptr, front, dinv, tbuf);
-  else ldl_panel_block(blockIdx.x - n_inv, forder, kb, fs2, fm, foff, fnode_ptr, front, dinv, delta, wbuf, rbuf);
+  if ((int)blockIdx.y < n_inv) ldl_invrow_block(blockIdx.y, forder, kb, fs2, fm, foff, fnode_ptr, front, dinv, tbuf);
+  else ldl_panel_block(blockIdx.y - n_inv, forder, kb, fs2, fm, foff, fnode_ptr, front, dinv, delta, wbuf, rbuf);
 }
 
 // Trailing update: F[i,j] -= sum_c W[i,c] Y[j,c] for i, j >= k0 + nbk, one 32x32 tile per wave as 2x2
@@ -906,7 +906,7 @@ void launch_factor(plfem_ctx* c, double sigma, int stop_level, int stop_step, in
         const int n_inv = kb > 0 ? (k0 + 63) / 64 : 0;
         const int n_pan = max_trail > 0 ? (max_trail + 63) / 64 : 0;
         if (n_inv + n_pan > 0)
-          hipLaunchKernelGGL(k_ldl_invrow_panel, dim3(n_inv + n_pan, nact), dim3(256), 0, st, n_inv, ford, kb,
+          hipLaunchKernelGGL(k_ldl_invrow_panel, dim3(nact, n_inv + n_pan), dim3(256), 0, st, n_inv, ford, kb,
                              c->d_fs2, c->d_fm, c->d_foff, c->d_fnode_ptr, c->d_front, c->d_dinv, c->d_delta, c->d_tbuf,
                              wb, rb);
       }
