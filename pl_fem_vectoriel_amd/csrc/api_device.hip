@@ -566,14 +566,21 @@ static int lanczos_block(plfem_ctx* c, int k, int ncv, double tol, int maxiter, 
     count_converged(mm_, [&](int id, int b) { return Svec[(size_t)id * mm_ + (mm_ - P + b)]; });
   };
   // Pipeline: while the GPU runs block step j + 1, the host tests convergence on the projected matrix of
-  // step j; the extra step in flight when the test succeeds is simply not used.
+  // step j; the extra step in flight when the test succeeds is simply not used.  The largest residual of the
+  // wanted pairs decays geometrically (x 0.15-0.25 per block step), so when the last two tests predict that the
+  // pending step converges, step j + 1 is held back until its test is in: a correct prediction saves the wasted
+  // step, a wrong one idles the GPU for one host test.
+  double res_prev = 0.0, res_last = 0.0;         // largest relative residual at the last two tests (0 = none yet)
   while (true) {
     int pend_c0 = -1, pend_slot = 0, slot = 0;
-    bool converged = false;
+    bool converged = false, inflight = false, force_launch = false, have_full = false;
     mm = c0;
     while (true) {
+      const bool predicted = !force_launch && pend_c0 >= 0 && res_prev > 0.0 && res_last > 0.0 &&
+                             res_last * (res_last / res_prev) <= tol;
+      force_launch = false;
       int new_c0 = -1, new_slot = 0;
-      if (c0 + P <= m) {
+      if (c0 + P <= m && !predicted) {
         TRY(launch_step(c0, slot));
         nop += P; ++nblock;
         new_c0 = c0; new_slot = slot;
@@ -582,19 +589,31 @@ static int lanczos_block(plfem_ctx* c, int k, int ncv, double tol, int maxiter, 
       if (pend_c0 >= 0) {
         TRY(absorb_step(pend_c0, pend_slot));
         mm = pend_c0 + P;
-        if (mm >= k + P && new_c0 >= 0) {          // (the last step of a cycle gets the full test below)
-          quick_check(mm);
-          if (nconv >= k) { converged = true; break; }
+        if (mm >= k + P && (new_c0 >= 0 || predicted)) {     // (the last step of a cycle gets the full test below)
+          // a held step is expected to converge: go straight to the full decomposition the rotation needs
+          if (predicted) { full_check(mm); have_full = true; } else { quick_check(mm); have_full = false; }
+          res_prev = res_last;
+          res_last = max_rel_res;
+          if (getenv("PLFEM_LANCZOS_TRACE"))
+            fprintf(stderr, "[lanczos] cols %d nconv %d max_rel_res %.3e%s\n", mm, nconv, max_rel_res, predicted ? " (held)" : "");
+          if (nconv >= k) { converged = true; inflight = new_c0 >= 0; break; }
+        }
+        if (predicted) {                            // not converged after all: resume with the step that was held
+          pend_c0 = -1;
+          force_launch = true;
+          if (c0 + P <= m) continue;
+          break;
         }
       }
       pend_c0 = new_c0; pend_slot = new_slot;
       if (pend_c0 < 0) break;                       // basis full and every step absorbed
     }
     if (converged) {
-      full_check(mm);
+      if (!have_full) full_check(mm);
       if (nconv < k) {                              // the two eigensolvers disagree at the threshold: resume
         converged = false;
-        TRY(absorb_step(c0 - P, slot ^ 1));         // the step in flight
+        if (inflight) { TRY(absorb_step(c0 - P, slot ^ 1)); }
+        res_prev = res_last = 0.0;
         if (c0 + P <= m) continue;
         mm = c0;
         full_check(mm);
@@ -603,6 +622,7 @@ static int lanczos_block(plfem_ctx* c, int k, int ncv, double tol, int maxiter, 
       mm = c0;
       full_check(mm);
     }
+    res_prev = res_last = 0.0;                      // a restart changes the decay
     if (nconv >= k || restarts >= maxiter) { done = nconv >= k; break; }
     int pk = k + std::min(nconv, (mm - k) / 2);
     pk = std::max(pk, k + (mm - k) / 4);
