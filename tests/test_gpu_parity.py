@@ -426,3 +426,19 @@ def test_package_first_import_order_in_a_fresh_process(built_library):
         "print('ok', s.N)"])
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and out.stdout.strip().startswith("ok"), out.stderr[-2000:]
+
+
+def test_readme_form_builds_its_own_mesh(gpu_device, built_library):
+    """The documented convenience form (reference README.md:141-160): keyword geometry, `n_modes`, `.solve()` with no
+    mesh argument, attribute access on the mode records — same result as the explicit call chain."""
+    from pl_fem_vectoriel_amd import PhotonicLanternGeometry
+    geom = PhotonicLanternGeometry(arrangement="triangular_3", core_radius_um=1.5, pitch_um=8.0, n_core=1.535,
+                                   n_clad=1.0, wavelength_nm=1550.0)
+    solver = TrueVectorialMaxwellSolver(geom, n_modes=4, device=gpu_device, mesh_refinement=0.35, mesh_levels=0)
+    modes = solver.solve()
+    assert len(modes) > 0 and solver.last_stats["n_req"] == 16
+    direct = TrueVectorialMaxwellSolver(geom, device=gpu_device).solve_vectorial_modes(generate_mesh(geom, 0.35, 0), 4)
+    assert len(direct) == len(modes)
+    for a, b in zip(modes, direct):
+        assert a.n_eff == a["n_eff"] and a.is_vectorial is True
+        assert abs(a.n_eff - b["n_eff"]) < 1e-12
