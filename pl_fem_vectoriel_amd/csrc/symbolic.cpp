@@ -223,7 +223,11 @@ std::string p2_numbering(int nv, int ne, const double* p, const int32_t* t, Symb
   uint8_t* bm = S.bmask.data();
   parallel_for(S.nedges, nth, [&](int64_t k0, int64_t k1, int) {
     for (int64_t k = k0; k < k1; ++k)
-      if (mult[k] == 1) { bm[ea[k]] = 1; bm[eb[k]] = 1; bm[nv + k] = 1; }
+      if (mult[k] == 1) {   // several edges may mark the same vertex: relaxed atomic stores of the same value
+        __atomic_store_n(&bm[ea[k]], (uint8_t)1, __ATOMIC_RELAXED);
+        __atomic_store_n(&bm[eb[k]], (uint8_t)1, __ATOMIC_RELAXED);
+        bm[nv + k] = 1;
+      }
   });
   // interior list / inverse map: per-chunk counts, prefix, fill
   S.int_index.resize(N);
@@ -544,10 +548,10 @@ std::string build_fronts(Symbolic& S, int nthreads) {
   // owner front of every non-Dirichlet node = deepest tree node containing all its elements
   Trace tr;
   S.owner.assign(N, -1);
-  bool orphan = false;
+  std::atomic<bool> orphan{false};
   parallel_for(N, nthreads, [&](int64_t b, int64_t e_, int) {
     for (int64_t i = b; i < e_; ++i) {
-      if (nptr[i] == nptr[i + 1]) { orphan = true; continue; }
+      if (nptr[i] == nptr[i + 1]) { orphan.store(true, std::memory_order_relaxed); continue; }
       if (S.bmask[i]) continue;
       uint32_t lo = 0xffffffffu, hi = 0;
       for (int32_t q = nptr[i]; q < nptr[i + 1]; ++q) {
@@ -559,7 +563,7 @@ std::string build_fronts(Symbolic& S, int nthreads) {
       S.owner[i] = (1 << level) - 1 + (int)(lo >> (L - level));
     }
   }, 8192);
-  if (orphan) return "mesh has a vertex that belongs to no element";
+  if (orphan.load()) return "mesh has a vertex that belongs to no element";
   tr.lap("fronts: owner");
   // Per-front node lists, bottom-up, level by level (fronts of one level are independent):
   // own (ascending ids) and boundary (ascending ids).  One flat buffer per level and list, front q of the
