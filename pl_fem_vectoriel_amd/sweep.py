@@ -120,41 +120,95 @@ def default_solve(device: Optional[int] = None) -> Callable[[SweepItem, dict], n
     return solve
 
 
+def _run_lane(entries, solve, rank: int, rec: np.ndarray, device, own_stream: bool) -> None:
+    """One lane = a sequential pass over ``entries`` [(row in rec, item), ...] with its own solver cache (and, on
+    a GPU, its own stream so that lanes overlap on the device); the next different mesh is prepared on a host
+    thread while the current one is being solved."""
+    import contextlib
+    import threading
+
+    ctx = contextlib.nullcontext()
+    if own_stream:
+        import torch
+        ctx = torch.cuda.stream(torch.cuda.Stream(device))
+    cache: dict = {}
+    prefetch = None
+    with ctx:
+        for pos, (q, it) in enumerate(entries):
+            new_group = pos == 0 or entries[pos - 1][1].mesh_key != it.mesh_key
+            if new_group:
+                if prefetch is not None:
+                    prefetch.join()             # the mesh prepared in the background is this item's
+                    prefetch = None
+                if hasattr(solve, "prepare"):
+                    # while the GPU works on this mesh, prepare the next DIFFERENT mesh on a host thread
+                    nxt = next((x for _, x in entries[pos + 1:] if x.mesh_key != it.mesh_key), None)
+                    if nxt is not None:
+                        prefetch = threading.Thread(target=solve.prepare, args=(nxt, cache), daemon=True)
+                        prefetch.start()
+            ne = np.asarray(solve(it, cache), dtype=np.float64)[:K_MAX]
+            rec[q, 0], rec[q, 1], rec[q, 2], rec[q, 3] = it.index, len(ne), rank, 0
+            rec[q, 4:4 + len(ne)] = ne
+        if prefetch is not None:
+            prefetch.join()
+        ent = cache.get("cur")
+        if ent is not None and "solver" in ent:
+            ent["solver"].clear_cache()
+
+
 def run_sweep(items: Sequence[SweepItem], rank: int = 0, world_size: int = 1,
               solve: Optional[Callable[[SweepItem, dict], np.ndarray]] = None, device=None,
-              gather: bool = True):
+              gather: bool = True, lanes: int = 1):
     """Solve this rank's share and gather fixed-size records on every rank.
 
     Returns ``(table, local_count)``; ``table[i]`` is the descending n_eff list of item ``i``
     (available on all ranks after the gather).  Records are ``[index, count, rank, 0, n_eff...]``
     padded with NaN to ``REC_WIDTH`` doubles — the only inter-GPU traffic of the whole sweep.
+
+    ``lanes`` > 1: that many solves in flight on this rank's GPU, each lane a host thread with its own context and
+    stream (whole cross-sections are dealt to the lanes, so a lane still reuses its analysis across wavelengths).
+    A 1e5-DOF solve leaves most of an MI355X idle (host analysis, latency-bound tree levels); two lanes fill it.
     """
     import torch
 
     mine = partition(items, world_size)[rank]
     if solve is None:
         solve = default_solve(device)
-    cache: dict = {}
     per_rank = max(len(p) for p in partition(items, world_size))
     rec = np.full((per_rank, REC_WIDTH), np.nan)
     rec[:, 0] = -1
-    prefetch = None
-    for q, it in enumerate(mine):
-        new_group = q == 0 or mine[q - 1].mesh_key != it.mesh_key
-        if new_group:
-            if prefetch is not None:
-                prefetch.join()             # the mesh prepared in the background is this item's
-                prefetch = None
-            if hasattr(solve, "prepare"):
-                # while the GPU works on this mesh, prepare the next DIFFERENT mesh on a host thread
-                nxt = next((x for x in mine[q + 1:] if x.mesh_key != it.mesh_key), None)
-                if nxt is not None:
-                    import threading
-                    prefetch = threading.Thread(target=solve.prepare, args=(nxt, cache), daemon=True)
-                    prefetch.start()
-        ne = np.asarray(solve(it, cache), dtype=np.float64)[:K_MAX]
-        rec[q, 0], rec[q, 1], rec[q, 2], rec[q, 3] = it.index, len(ne), rank, 0
-        rec[q, 4:4 + len(ne)] = ne
+    lanes = max(1, int(lanes))
+    if lanes == 1:
+        _run_lane(list(enumerate(mine)), solve, rank, rec, device, own_stream=False)
+    else:
+        import threading
+        # deal whole mesh groups to the lanes, heaviest first, always to the lane with the least work so far
+        groups: Dict[tuple, list] = {}
+        for q, it in enumerate(mine):
+            groups.setdefault(it.mesh_key, []).append((q, it))
+        order = sorted(groups.values(), key=lambda g: -sum(it.cost() for _, it in g))
+        lane_items = [[] for _ in range(lanes)]
+        load = [0.0] * lanes
+        for g in order:
+            k = int(np.argmin(load))
+            lane_items[k].extend(g)
+            load[k] += sum(it.cost() for _, it in g)
+        on_gpu = device is not None and torch.cuda.is_available()
+        errors: list = []
+
+        def work(entries):
+            try:
+                _run_lane(entries, solve, rank, rec, device, own_stream=on_gpu)
+            except BaseException as exc:       # surfaced on the caller's thread below
+                errors.append(exc)
+
+        threads = [threading.Thread(target=work, args=(e,)) for e in lane_items if e]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        if errors:
+            raise errors[0]
     table: Dict[int, np.ndarray] = {}
     if world_size > 1 and gather:
         import torch.distributed as dist

@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--levels", type=int, default=1)
     ap.add_argument("--refinement", type=float, default=1.0)
     ap.add_argument("--modes", type=int, default=10)
+    ap.add_argument("--lanes", type=int, default=1, help="solves in flight per GPU")
     args = ap.parse_args()
     import torch
     import torch.distributed as dist
@@ -39,7 +40,7 @@ def main():
     if world > 1:
         dist.barrier()
     t0 = time.perf_counter()
-    table, n_local = run_sweep(items, rank, world, device=local_rank)
+    table, n_local = run_sweep(items, rank, world, device=local_rank, lanes=args.lanes)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

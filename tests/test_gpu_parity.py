@@ -442,3 +442,18 @@ def test_readme_form_builds_its_own_mesh(gpu_device, built_library):
     for a, b in zip(modes, direct):
         assert a.n_eff == a["n_eff"] and a.is_vectorial is True
         assert abs(a.n_eff - b["n_eff"]) < 1e-12
+
+
+def test_sweep_lanes_give_identical_results(gpu_device, built_library):
+    """Two solves in flight per GPU (one host thread + context + stream each) = the same table as one lane."""
+    from pl_fem_vectoriel_amd.sweep import SweepItem, run_sweep
+    items = []
+    for arr in ("linear_2", "triangular_3", "square_2x2_4"):
+        for lam in (1.55, 1.60):
+            items.append(SweepItem(len(items), arr, 8.0, lam, n_modes=4, mesh_refinement=0.35, mesh_levels=0))
+    one, n1 = run_sweep(items, 0, 1, device=gpu_device, lanes=1)
+    two, n2 = run_sweep(items, 0, 1, device=gpu_device, lanes=2)
+    assert n1 == n2 == 6 and sorted(one) == sorted(two) == list(range(6))
+    for i in one:
+        np.testing.assert_array_equal(one[i], two[i])
+
