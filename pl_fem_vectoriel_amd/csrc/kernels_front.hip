@@ -294,39 +294,64 @@ __device__ __forceinline__ void ldl_panel_block(int bx, const int32_t* __restric
   const int i0 = k0 + nbk + bx * 64;
   if (i0 >= m) return;
   double* F = front + foff[f];
-  const double* D = dinv + (int64_t)f * NB * NB;
+  const double* D = dinv + (int64_t)f * NB * NB;       // D[r + c*NB] = X[r][c]
   const double* dl = delta + 2 * fnode_ptr[f] + k0;
   double* W = wbuf + 2 * fnode_ptr[f] * NB;
   double* Y = rbuf + 2 * fnode_ptr[f] * NB;
-  __shared__ double sXT[NB][NB + 1];   // sXT[j][c] = X[c][j]
-  __shared__ double sR[64][NB + 1];
-  __shared__ double sdi[NB];
-  const int tid = threadIdx.x;
-  for (int k = tid; k < NB * NB; k += 256) sXT[k / NB][k % NB] = D[k];   // D[r + c*NB] = X[r][c] -> sXT[c][r]
-  if (tid < NB) sdi[tid] = (tid < nbk) ? 1.0 / dl[tid] : 0.0;
-  const int r = tid & 63, cq = tid >> 6;
-  const int i = i0 + r;
-  const bool valid = i < m;
-  for (int cc = 0; cc < 8; ++cc) {
-    int c = cq * 8 + cc;
-    sR[r][c] = (valid && c < nbk) ? F[(int64_t)(k0 + c) * m + i] : 0.0;
+  // Y^T[c][i] = sum_j X[c][j] R[i][j] on v_mfma_f64_16x16x4_f64: A <- X (row c, k = j: contiguous in c in dinv),
+  // B <- R^T (k = j, col i: the panel columns of F, contiguous in i); the accumulator register r of lane l is
+  // Y[i = ibase + (l & 15)][c = 16 tc + (l >> 4) + 4 r]: 128-B runs of W, Y and of the panel columns of F.
+  // One wave = 16 rows i x all 32 columns; every operand (24 loads) is requested before the first MFMA.
+  __shared__ double tr[4][NB][17];                     // per-wave transpose for the mirrored (row) copy of W
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int lr = lane & 15, lk = lane >> 4;
+  const int ibase = i0 + 16 * wave;
+  if (ibase >= m) return;                              // m is a multiple of 16: the wave's 16 rows are all valid
+  const int i = ibase + lr;
+  double a0[NB / 4], a1[NB / 4], b[NB / 4];
+#pragma unroll
+  for (int kk = 0; kk < NB / 4; ++kk) {
+    const int jx = 4 * kk + lk;
+    a0[kk] = D[lr + (int64_t)jx * NB];
+    a1[kk] = D[16 + lr + (int64_t)jx * NB];
+    b[kk] = (jx < nbk) ? F[(int64_t)(k0 + jx) * m + i] : 0.0;
   }
-  __syncthreads();
-  if (!valid) return;
-  for (int cc = 0; cc < 8; ++cc) {
-    int c = cq * 8 + cc;
-    double y = 0.0;
-    if (c < nbk) {
-#pragma unroll 8
-      for (int j = 0; j < NB; ++j) y += sR[r][j] * sXT[j][c];
+  double di[2][4];
+#pragma unroll
+  for (int tc = 0; tc < 2; ++tc)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int c = 16 * tc + lk + 4 * r;
+      di[tc][r] = (c < nbk) ? 1.0 / dl[c] : 0.0;
     }
-    double w = y * sdi[c];
-    W[(int64_t)c * m + i] = w;
-    Y[(int64_t)c * m + i] = y;
-    if (c < nbk) {
-      F[(int64_t)(k0 + c) * m + i] = w;
-      F[(int64_t)i * m + (k0 + c)] = w;
+  v4d y0 = (v4d){0.0, 0.0, 0.0, 0.0}, y1 = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int kk = 0; kk < NB / 4; ++kk) {
+    y0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[kk], b[kk], y0, 0, 0, 0);
+    y1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[kk], b[kk], y1, 0, 0, 0);
+  }
+#pragma unroll
+  for (int tc = 0; tc < 2; ++tc)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int c = 16 * tc + lk + 4 * r;
+      const double y = tc == 0 ? y0[r] : y1[r];
+      const double w = y * di[tc][r];
+      W[(int64_t)c * m + i] = w;
+      Y[(int64_t)c * m + i] = y;
+      if (c < nbk) F[(int64_t)(k0 + c) * m + i] = w;
+      tr[wave][c][lr] = w;
     }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  // mirrored copy F[i][k0 + c]: lane = (row i = lane >> 2, 8 consecutive columns) -> 256-B runs per row
+  {
+    const int ri = lane >> 2, c0 = (lane & 3) * 8;
+    double* dst = F + (int64_t)(ibase + ri) * m + k0 + c0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+      if (c0 + q < nbk) dst[q] = tr[wave][c0 + q][ri];
   }
 }
 
