@@ -88,15 +88,26 @@ __global__ __launch_bounds__(256) void k_front_gather(
   const double* F0 = front + foff[ch0];
   const double* F1 = front + foff[ch1];
   double* F = front + foff[f];
+  // the 8 column-node index pairs first, then all 32 child entries: two memory round trips for 16 columns
+  int c0j[8], c1j[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    c0j[q] = cinv0[np + (j0 >> 1) + q];
+    c1j[q] = cinv1[np + (j0 >> 1) + q];
+  }
+  double v[16];
+#pragma unroll
   for (int jj = 0; jj < 16; ++jj) {
-    int j = j0 + jj;
-    int qj = j >> 1, cj = j & 1;
-    int c0j = cinv0[np + qj], c1j = cinv1[np + qj];
-    double v = 0.0;
-    if (c0i >= 0 && c0j >= 0) v += F0[(int64_t)(s0 + 2 * c0j + cj) * m0 + (s0 + 2 * c0i + ci)];
-    if (c1i >= 0 && c1j >= 0) v += F1[(int64_t)(s1 + 2 * c1j + cj) * m1 + (s1 + 2 * c1i + ci)];
-    if (dummy_i && i == j) v = 1.0;
-    F[(int64_t)j * m + i] = v;
+    const int cj = jj & 1, q = jj >> 1;
+    double a = 0.0, b = 0.0;
+    if (c0i >= 0 && c0j[q] >= 0) a = F0[(int64_t)(s0 + 2 * c0j[q] + cj) * m0 + (s0 + 2 * c0i + ci)];
+    if (c1i >= 0 && c1j[q] >= 0) b = F1[(int64_t)(s1 + 2 * c1j[q] + cj) * m1 + (s1 + 2 * c1i + ci)];
+    v[jj] = a + b;
+  }
+#pragma unroll
+  for (int jj = 0; jj < 16; ++jj) {
+    const int j = j0 + jj;
+    F[(int64_t)j * m + i] = (dummy_i && i == j) ? 1.0 : v[jj];
   }
 }
 
@@ -475,17 +486,25 @@ __global__ __launch_bounds__(256) void k_form_z(const int2* __restrict__ tiles, 
   for (int tb = 0; tb < 2; ++tb)
     for (int tc = 0; tc < 2; ++tc) acc[tb][tc] = (v4d){0.0, 0.0, 0.0, 0.0};
   // Z[b, c] = sum_{j >= c} L21[b, j] Linv[j, c];  A <- L21 rows (contiguous in b), B <- Linv via the upper mirror
-  for (int j0 = c0; j0 < s2; j0 += 4) {
-    const int j = j0 + lk;
-    const double a0 = F[(int64_t)j * m + s2 + b0 + lr];
-    const double a1 = bv1 ? F[(int64_t)j * m + s2 + b0 + 16 + lr] : 0.0;
-    const int cA = c0 + lr, cB = c0 + 16 + lr;
-    const double x0 = (j >= cA) ? F[(int64_t)j * m + cA] : 0.0;
-    const double x1 = (cv1 && j >= cB) ? F[(int64_t)j * m + cB] : 0.0;
-    acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, x0, acc[0][0], 0, 0, 0);
-    acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, x1, acc[0][1], 0, 0, 0);
-    acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, x0, acc[1][0], 0, 0, 0);
-    acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, x1, acc[1][1], 0, 0, 0);
+  // s2 - c0 is a multiple of 16: four k-steps (16 loads) are requested before their MFMAs
+  const int cA = c0 + lr, cB = c0 + 16 + lr;
+  for (int j0 = c0; j0 < s2; j0 += 16) {
+    double a0[4], a1[4], x0[4], x1[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int j = j0 + 4 * t + lk;
+      a0[t] = F[(int64_t)j * m + s2 + b0 + lr];
+      a1[t] = bv1 ? F[(int64_t)j * m + s2 + b0 + 16 + lr] : 0.0;
+      x0[t] = (j >= cA) ? F[(int64_t)j * m + cA] : 0.0;
+      x1[t] = (cv1 && j >= cB) ? F[(int64_t)j * m + cB] : 0.0;
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[t], x0[t], acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[t], x1[t], acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[t], x0[t], acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[t], x1[t], acc[1][1], 0, 0, 0);
+    }
   }
   // D[row = b (lk + 4r)][col = c (lr)] -> Z^T[c, b] at F[c + (s2 + b) m]: lanes lr contiguous
   for (int tb = 0; tb < 2; ++tb) {
