@@ -37,9 +37,7 @@ __global__ __launch_bounds__(256) void k_leaf_assemble(
   const int m = fm[f];
   double* F = front + foff[f];
   const int tid = threadIdx.x;
-  const int64_t mm = (int64_t)m * m;
-  for (int64_t k = tid; k < mm; k += 256) F[k] = 0.0;
-  __syncthreads();
+  // (the leaf fronts are contiguous in memory and were zeroed by one memset before this launch)
   const int32_t* fn = fnodes + fnode_ptr[f];
   for (int q = tid; q < m / 2; q += 256)
     if (fn[q] < 0) {   // padding node: unit pivot, no coupling
@@ -49,21 +47,36 @@ __global__ __launch_bounds__(256) void k_leaf_assemble(
   __syncthreads();
   const int adof = tid / 12, bdof = tid % 12;
   const int a = adof >> 1, ca = adof & 1, b = bdof >> 1, cb = bdof & 1;
-  for (int q = leaf_elem_ptr[lf]; q < leaf_elem_ptr[lf + 1]; ++q) {
-    const int e = leaf_elems[q];
-    if (tid < 144) {
-      int pa = epos[(size_t)a * ne + e], pb = epos[(size_t)b * ne + e];
-      if (pa >= 0 && pb >= 0) {
+  const bool worker = tid < 144;
+  const int blk_a = (ca == 0 && cb == 0) ? PLFEM_BLK_AXX : (ca == 0) ? PLFEM_BLK_AXY : (cb == 0) ? PLFEM_BLK_AYX : PLFEM_BLK_AYY;
+  const bool diag_blk = ca == cb;
+  // positions and values of EB elements are fetched together (they do not depend on F); only the additions into
+  // F stay ordered element by element (two elements of a leaf may hit the same entry)
+  constexpr int EB = 8;
+  for (int q0 = leaf_elem_ptr[lf]; q0 < leaf_elem_ptr[lf + 1]; q0 += EB) {
+    const int nb = min(EB, leaf_elem_ptr[lf + 1] - q0);
+    int64_t dst[EB];
+    double val[EB];
+#pragma unroll
+    for (int t = 0; t < EB; ++t) {
+      dst[t] = -1;
+      val[t] = 0.0;
+      if (worker && t < nb) {
+        const int e = leaf_elems[q0 + t];
+        const int pa = epos[(size_t)a * ne + e], pb = epos[(size_t)b * ne + e];
         const double* em = elem + (size_t)e * ELEM_STRIDE + a * 6 + b;
-        double v;
-        if (ca == 0 && cb == 0) v = em[PLFEM_BLK_AXX * 36] - sigma * em[PLFEM_BLK_MINV * 36];
-        else if (ca == 0 && cb == 1) v = em[PLFEM_BLK_AXY * 36];
-        else if (ca == 1 && cb == 0) v = em[PLFEM_BLK_AYX * 36];
-        else v = em[PLFEM_BLK_AYY * 36] - sigma * em[PLFEM_BLK_MINV * 36];
-        F[(int64_t)(2 * pb + cb) * m + (2 * pa + ca)] += v;
+        double v = em[blk_a * 36];
+        if (diag_blk) v -= sigma * em[PLFEM_BLK_MINV * 36];
+        if (pa >= 0 && pb >= 0) { dst[t] = (int64_t)(2 * pb + cb) * m + (2 * pa + ca); val[t] = v; }
       }
     }
-    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < EB; ++t) {
+      if (t < nb) {
+        if (dst[t] >= 0) F[dst[t]] += val[t];
+        __syncthreads();
+      }
+    }
   }
 }
 
@@ -913,6 +926,8 @@ void launch_factor(plfem_ctx* c, double sigma, int stop_level, int stop_step, in
   for (int lev = c->L; lev >= 0; --lev) {
     const LevelInfo& li = c->levels[lev];
     if (lev == c->L) {
+      const int64_t lo = c->S->foff[li.first], hi = c->S->foff[li.first + li.count];
+      (void)hipMemsetAsync(c->d_front + lo, 0, sizeof(double) * (size_t)(hi - lo), st);
       hipLaunchKernelGGL(k_leaf_assemble, dim3(li.count), dim3(256), 0, st, li.first, c->ne, sigma, c->d_fm, c->d_foff,
                          c->d_fnode_ptr, c->d_fnodes, c->d_leaf_elem_ptr, c->d_leaf_elems, c->d_epos, c->d_elem,
                          c->d_front);
