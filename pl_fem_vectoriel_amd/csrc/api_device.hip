@@ -495,9 +495,8 @@ static int lanczos_block(plfem_ctx* c, int k, int ncv, double tol, int maxiter, 
     double* Hblk = c->d_Hcols + (size_t)c0_ * ld;                             // T[0:nc, c0:c0+P]
     plfem::launch_panel_dot_block(c, c->d_BV, nc, c->d_w, n, Hblk, ld);
     plfem::launch_panel_axpy_block(c, c->d_V, nc, Hblk, ld, c->d_w, n);
-    plfem::launch_panel_dot_block(c, c->d_BV, nc, c->d_w, n, c->d_hblk, ld);  // CGS2 second pass
+    plfem::launch_panel_dot_block(c, c->d_BV, nc, c->d_w, n, c->d_hblk, ld, Hblk, ld);  // CGS2 second pass, T += h2
     plfem::launch_panel_axpy_block(c, c->d_V, nc, c->d_hblk, ld, c->d_w, n);
-    plfem::launch_mat_add(c, nc, Hblk, ld, c->d_hblk, ld);
     plfem::launch_spmv_b_block(c, c->d_w, c->d_bw, n);
     plfem::launch_panel_dot_block(c, c->d_w, P, c->d_bw, n, c->d_G, P);       // Gram matrix W^T B W
     plfem::launch_chol_block(c, c->d_G, P, Hblk + nc, ld, c->d_Rinv);         // R -> T[nc:nc+P, c0:c0+P]

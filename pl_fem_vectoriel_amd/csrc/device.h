@@ -135,7 +135,9 @@ void launch_scale_store(plfem_ctx* c, const double* w, const double* bw, const d
 void launch_axpby(plfem_ctx* c, double a, const double* x, double b, const double* y, double* z);  // z = a x + b y
 void launch_rotate(plfem_ctx* c, const double* V, int m, const double* Smat, int ldS, int p, double* out);  // out = V[:, :m] S
 // block (BLOCK_P vectors) variants; H matrices are column major with leading dimension ldh
-void launch_panel_dot_block(plfem_ctx* c, const double* Pm, int ncols, const double* W, int64_t ldw, double* h, int ldh);
+// h = Pm^T W (ncols x BLOCK_P); hacc (optional) += the same coefficients
+void launch_panel_dot_block(plfem_ctx* c, const double* Pm, int ncols, const double* W, int64_t ldw, double* h, int ldh,
+                            double* hacc = nullptr, int ldacc = 0);
 void launch_panel_axpy_block(plfem_ctx* c, const double* Pm, int ncols, const double* H, int ldh, double* W, int64_t ldw);
 void launch_mat_add(plfem_ctx* c, int ncols, double* acc, int lda, const double* h, int ldh);
 void launch_chol_block(plfem_ctx* c, const double* G, int ldg, double* Tblk, int ldT, double* Rinv);

@@ -141,13 +141,17 @@ __global__ __launch_bounds__(256) void k_panel_dot_p(int64_t n, int ncols, int n
 
 // h[c + q*ldh] = sum over chunks (one wave per (c, q), fixed order)
 __global__ __launch_bounds__(64) void k_panel_dot_finish_p(int P, int nchunks, const double* __restrict__ partial,
-                                                           double* __restrict__ h, int ldh) {
+                                                           double* __restrict__ h, int ldh, double* __restrict__ hacc,
+                                                           int ldacc) {
   const int cq = blockIdx.x;          // c*P + q
   const int c = cq / P, q = cq % P;
   double acc = 0.0;
   for (int t = threadIdx.x; t < nchunks; t += 64) acc += partial[(int64_t)cq * nchunks + t];
   for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
-  if (threadIdx.x == 0) h[c + (int64_t)q * ldh] = acc;
+  if (threadIdx.x == 0) {
+    h[c + (int64_t)q * ldh] = acc;
+    if (hacc) hacc[c + (int64_t)q * ldacc] += acc;     // CGS2: the second-pass coefficients also go into T
+  }
 }
 
 // W[i, q] -= sum_c Pm[i, c] H[c + q*ldh]
@@ -340,13 +344,15 @@ __global__ __launch_bounds__(256) void k_post_sums(int N, int nblocks, const int
         red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
 
-__global__ void k_post_finish(int k, int nblocks, const double* __restrict__ partial, double* __restrict__ out) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= k * 5) return;
+// one wave per (mode, quantity): lane l adds blocks l, l + 64, ... in order, then a fixed-order lane reduction
+__global__ __launch_bounds__(64) void k_post_finish(int k, int nblocks, const double* __restrict__ partial,
+                                                    double* __restrict__ out) {
+  const int t = blockIdx.x;             // mode * 5 + q
   const int mode = t / 5, q = t % 5;
   double acc = 0.0;
-  for (int b = 0; b < nblocks; ++b) acc += partial[((int64_t)mode * nblocks + b) * 5 + q];
-  out[t] = acc;
+  for (int b = threadIdx.x; b < nblocks; b += 64) acc += partial[((int64_t)mode * nblocks + b) * 5 + q];
+  for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
+  if (threadIdx.x == 0) out[t] = acc;
 }
 
 // normalise each mode in place (solver_fem.py:213)
@@ -400,12 +406,14 @@ void launch_axpby(plfem_ctx* c, double a, const double* x, double b, const doubl
   hipLaunchKernelGGL(k_axpby, dim3((unsigned)((c->n2 + 255) / 256)), dim3(256), 0, c->stream, c->n2, a, x, b, y, z);
 }
 
-void launch_panel_dot_block(plfem_ctx* c, const double* Pm, int ncols, const double* W, int64_t ldw, double* h, int ldh) {
+void launch_panel_dot_block(plfem_ctx* c, const double* Pm, int ncols, const double* W, int64_t ldw, double* h, int ldh,
+                            double* hacc, int ldacc) {
   constexpr int P = BLOCK_P;
   const int nchunks = c->npartial;
   hipLaunchKernelGGL(k_panel_dot_p<P>, dim3(nchunks, (ncols + 15) / 16), dim3(256), 0, c->stream, c->n2, ncols, nchunks,
                      Pm, W, ldw, c->d_partial);
-  hipLaunchKernelGGL(k_panel_dot_finish_p, dim3(ncols * P), dim3(64), 0, c->stream, P, nchunks, c->d_partial, h, ldh);
+  hipLaunchKernelGGL(k_panel_dot_finish_p, dim3(ncols * P), dim3(64), 0, c->stream, P, nchunks, c->d_partial, h, ldh,
+                     hacc, ldacc);
 }
 
 void launch_panel_axpy_block(plfem_ctx* c, const double* Pm, int ncols, const double* H, int ldh, double* W, int64_t ldw) {
@@ -449,7 +457,7 @@ void launch_post(plfem_ctx* c, int k, double* evecs, int ncore, double* out_host
   hipLaunchKernelGGL(k_post_sums, dim3(nblocks, k), dim3(256), 0, st, N, nblocks, c->d_rowptr, c->d_colind,
                      c->d_vals[PLFEM_BLK_DXX], c->d_vals[PLFEM_BLK_DXY], c->d_vals[PLFEM_BLK_DYY], c->d_coremask, evecs,
                      partial);
-  hipLaunchKernelGGL(k_post_finish, dim3((k * 5 + 63) / 64), dim3(64), 0, st, k, nblocks, partial, sums);
+  hipLaunchKernelGGL(k_post_finish, dim3(k * 5), dim3(64), 0, st, k, nblocks, partial, sums);
   hipLaunchKernelGGL(k_post_scale, dim3((unsigned)((2 * (int64_t)N + 255) / 256), k), dim3(256), 0, st, N, sums, evecs);
   if (modes_int)
     hipLaunchKernelGGL(k_gather_interior, dim3((unsigned)((2 * (int64_t)c->nsolve + 255) / 256), k), dim3(256), 0, st,
