@@ -498,8 +498,7 @@ static int lanczos_block(plfem_ctx* c, int k, int ncv, double tol, int maxiter, 
     plfem::launch_panel_dot_block(c, c->d_BV, nc, c->d_w, n, c->d_hblk, ld, Hblk, ld);  // CGS2 second pass, T += h2
     plfem::launch_panel_axpy_block(c, c->d_V, nc, c->d_hblk, ld, c->d_w, n);
     plfem::launch_spmv_b_block(c, c->d_w, c->d_bw, n);
-    plfem::launch_panel_dot_block(c, c->d_w, P, c->d_bw, n, c->d_G, P);       // Gram matrix W^T B W
-    plfem::launch_chol_block(c, c->d_G, P, Hblk + nc, ld, c->d_Rinv);         // R -> T[nc:nc+P, c0:c0+P]
+    plfem::launch_gram_chol_block(c, c->d_w, c->d_bw, n, Hblk + nc, ld, c->d_Rinv);   // W^T B W = R^T R, R -> T[nc:nc+P, c0:c0+P]
     plfem::launch_block_scale(c, c->d_w, c->d_bw, n, c->d_Rinv, c->d_V + (size_t)nc * n, c->d_BV + (size_t)nc * n, n);
     int rc = check_launch(c, "block lanczos step");
     if (rc != PLFEM_OK) return rc;

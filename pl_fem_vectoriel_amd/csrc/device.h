@@ -140,6 +140,7 @@ void launch_panel_dot_block(plfem_ctx* c, const double* Pm, int ncols, const dou
                             double* hacc = nullptr, int ldacc = 0);
 void launch_panel_axpy_block(plfem_ctx* c, const double* Pm, int ncols, const double* H, int ldh, double* W, int64_t ldw);
 void launch_mat_add(plfem_ctx* c, int ncols, double* acc, int lda, const double* h, int ldh);
+void launch_gram_chol_block(plfem_ctx* c, const double* W, const double* BW, int64_t ldw, double* Tblk, int ldT, double* Rinv);
 void launch_chol_block(plfem_ctx* c, const double* G, int ldg, double* Tblk, int ldT, double* Rinv);
 void launch_block_scale(plfem_ctx* c, const double* W, const double* BW, int64_t ldw, const double* Rinv, double* Vn,
                         double* BVn, int64_t ldv);

@@ -187,10 +187,27 @@ __global__ void k_mat_add(int ncols, int P, double* __restrict__ acc, int lda, c
 // Cholesky G = R^T R of the P x P Gram matrix of the new block (one lane), R into the projected matrix
 // (rows nc.., columns c0..), R^-1 for the block scaling.  A non-positive pivot (rank-deficient block:
 // the Krylov space is exhausted) raises counters[2].
+// G comes either ready-made (G != nullptr) or as the chunk partials of k_panel_dot_p (partial[((c P + q) nchunks +
+// chunk)], summed here in the same fixed order as k_panel_dot_finish_p: one launch less per block step)
 template <int P>
-__global__ void k_chol_small(const double* __restrict__ G, int ldg, double* __restrict__ Tblk, int ldT,
-                             double* __restrict__ Rinv, int32_t* __restrict__ counters) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__global__ __launch_bounds__(64) void k_chol_small(const double* __restrict__ G, int ldg, const double* __restrict__ partial,
+                                                   int nchunks, double* __restrict__ Tblk, int ldT,
+                                                   double* __restrict__ Rinv, int32_t* __restrict__ counters) {
+  __shared__ double sG[P * P];
+  if (G) {
+    if (threadIdx.x < P * P) sG[threadIdx.x] = G[(threadIdx.x % P) + (int64_t)(threadIdx.x / P) * ldg];
+  } else {
+    for (int cq = 0; cq < P * P; ++cq) {             // cq = c P + q  ->  G[c + q ldg]
+      double acc = 0.0;
+      for (int t = threadIdx.x; t < nchunks; t += 64) acc += partial[(int64_t)cq * nchunks + t];
+      for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
+      if (threadIdx.x == 0) sG[(cq / P) + (cq % P) * P] = acc;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  ldg = P;
+  G = sG;
   double R[P][P], X[P][P];
   for (int i = 0; i < P; ++i)
     for (int j = 0; j < P; ++j) { R[i][j] = 0.0; X[i][j] = 0.0; }
@@ -428,7 +445,17 @@ void launch_mat_add(plfem_ctx* c, int ncols, double* acc, int lda, const double*
 }
 
 void launch_chol_block(plfem_ctx* c, const double* G, int ldg, double* Tblk, int ldT, double* Rinv) {
-  hipLaunchKernelGGL(k_chol_small<BLOCK_P>, dim3(1), dim3(64), 0, c->stream, G, ldg, Tblk, ldT, Rinv, c->d_counters);
+  hipLaunchKernelGGL(k_chol_small<BLOCK_P>, dim3(1), dim3(64), 0, c->stream, G, ldg, (const double*)nullptr, 0, Tblk, ldT,
+                     Rinv, c->d_counters);
+}
+
+// Gram matrix W^T BW (chunk partials only) + its Cholesky factor in two launches
+void launch_gram_chol_block(plfem_ctx* c, const double* W, const double* BW, int64_t ldw, double* Tblk, int ldT, double* Rinv) {
+  constexpr int P = BLOCK_P;
+  const int nchunks = c->npartial;
+  hipLaunchKernelGGL(k_panel_dot_p<P>, dim3(nchunks, 1), dim3(256), 0, c->stream, c->n2, P, nchunks, W, BW, ldw, c->d_partial);
+  hipLaunchKernelGGL(k_chol_small<P>, dim3(1), dim3(64), 0, c->stream, (const double*)nullptr, 0, c->d_partial, nchunks, Tblk,
+                     ldT, Rinv, c->d_counters);
 }
 
 void launch_block_scale(plfem_ctx* c, const double* W, const double* BW, int64_t ldw, const double* Rinv, double* Vn,
