@@ -19,6 +19,14 @@ inline double secs(clk::time_point a, clk::time_point b) {
   return std::chrono::duration<double>(b - a).count();
 }
 
+// The pool's waits are short (the regions are 10-500 us apart): spin on the cache line with a pause instruction
+// first -- a yield costs a system call and several microseconds of wake-up latency per region, ~100 regions per
+// analysis -- and only fall back to yielding when the wait drags on (oversubscribed host).
+inline void cpu_relax(int spins) {
+  if (spins < 4096) __builtin_ia32_pause();
+  else std::this_thread::yield();
+}
+
 // Small spin-waiting worker pool, alive for the duration of one build_symbolic() call: the parallel
 // regions of the analysis are ~0.1-3 ms each, far too short to pay a thread creation per region.
 struct Pool {
@@ -32,9 +40,9 @@ struct Pool {
       th.emplace_back([this, t] {
         int seen = 0;
         while (true) {
-          while (gen.load(std::memory_order_acquire) == seen) {
+          for (int spins = 0; gen.load(std::memory_order_acquire) == seen; ++spins) {
             if (stop.load(std::memory_order_acquire)) return;
-            std::this_thread::yield();
+            cpu_relax(spins);
           }
           seen = gen.load(std::memory_order_acquire);
           job(t);
@@ -47,7 +55,7 @@ struct Pool {
     done.store(0, std::memory_order_release);
     gen.fetch_add(1, std::memory_order_release);
     f(0);
-    while (done.load(std::memory_order_acquire) < nt - 1) std::this_thread::yield();
+    for (int spins = 0; done.load(std::memory_order_acquire) < nt - 1; ++spins) cpu_relax(spins);
   }
   ~Pool() {
     stop.store(true, std::memory_order_release);
@@ -348,6 +356,15 @@ namespace {
 // ------------------------------------------------------------------------------------------------
 // element-based geometric nested dissection: complete binary tree of depth L over the elements
 // ------------------------------------------------------------------------------------------------
+// One record per element, moved around by the bisection (sort the data, not an index: every pass over a
+// subdomain is then a sequential stream; at 64 B the records of C1 fit the L2 cache).
+struct alignas(64) ElemGeo {
+  double c[2];        // centroid x, y
+  double lo[2];       // extent along x, y
+  double hi[2];
+  int32_t id;
+};
+
 void nd_tree(Symbolic& S, int leaf_elems, int nthreads) {
   const int ne = S.ne, N = S.N;
   int L = 0;
@@ -356,45 +373,45 @@ void nd_tree(Symbolic& S, int leaf_elems, int nthreads) {
   S.L = L;
   S.nfronts = (1 << (L + 1)) - 1;
   Trace tr;
-  // element centroids and extents along both axes (for counting elements a cut line would straddle)
-  std::vector<double> cx(ne), cy(ne), exlo(ne), exhi(ne), eylo(ne), eyhi(ne);
-  std::vector<int32_t> perm(ne), scratch(ne);
+  std::vector<ElemGeo> G(ne), scratch(nthreads > 1 ? ne : 0);
   const double* X = S.doflocs.data();
   const double* Y = X + N;
   parallel_for(ne, nthreads, [&](int64_t b_, int64_t e_, int) {
     for (int64_t e = b_; e < e_; ++e) {
       int32_t a = S.tsorted[e], b = S.tsorted[(size_t)ne + e], c = S.tsorted[(size_t)2 * ne + e];
-      cx[e] = (X[a] + X[b] + X[c]) / 3.0;
-      cy[e] = (Y[a] + Y[b] + Y[c]) / 3.0;
-      exlo[e] = std::min(X[a], std::min(X[b], X[c])); exhi[e] = std::max(X[a], std::max(X[b], X[c]));
-      eylo[e] = std::min(Y[a], std::min(Y[b], Y[c])); eyhi[e] = std::max(Y[a], std::max(Y[b], Y[c]));
-      perm[e] = (int32_t)e;
+      ElemGeo& g = G[e];
+      g.c[0] = (X[a] + X[b] + X[c]) / 3.0;
+      g.c[1] = (Y[a] + Y[b] + Y[c]) / 3.0;
+      g.lo[0] = std::min(X[a], std::min(X[b], X[c])); g.hi[0] = std::max(X[a], std::max(X[b], X[c]));
+      g.lo[1] = std::min(Y[a], std::min(Y[b], Y[c])); g.hi[1] = std::max(Y[a], std::max(Y[b], Y[c]));
+      g.id = (int32_t)e;
     }
   });
   tr.lap("tree: centroids");
   S.leaf_of_elem.resize(ne);
   S.leaf_elem_ptr.assign((size_t)(1 << L) + 1, 0);
+  S.leaf_elems.resize(ne);
   constexpr int NBIN = 512;
   struct Hist {
     double x0 = 1e300, x1 = -1e300, y0 = 1e300, y1 = -1e300;
     int32_t cnt[2][NBIN + 1];
     int32_t diff[2][NBIN + 2];
   };
-  // Bisection of perm[lo, hi).  Large subdomains: the cut is an axis-parallel line chosen among NBIN-1
+  // Bisection of G[lo, hi).  Large subdomains: the cut is an axis-parallel line chosen among NBIN-1
   // candidates per axis to minimise the number of straddled elements (~ separator size) subject to
   // a balance window; small subdomains: plain median split along the longer extent.  par: the passes
   // over the elements run on the pool (top of the tree, where there are fewer nodes than threads).
-  // The result does not depend on par or on the order of perm inside [lo, hi).
+  // The result (which elements go left) does not depend on par or on the order inside [lo, hi).
   auto bisect = [&](int lo, int hi, int level, bool par) -> int {
     const int n = hi - lo;
     const int nt = (par && g_pool) ? g_pool->nt : 1;
     std::vector<Hist> hs(nt);
+    const ElemGeo* Gl = G.data() + lo;
     auto bbox = [&](int64_t b, int64_t e_, int tid) {
       Hist& h = hs[tid];
-      for (int64_t q = lo + b; q < lo + e_; ++q) {
-        int e = perm[q];
-        h.x0 = std::min(h.x0, cx[e]); h.x1 = std::max(h.x1, cx[e]);
-        h.y0 = std::min(h.y0, cy[e]); h.y1 = std::max(h.y1, cy[e]);
+      for (int64_t q = b; q < e_; ++q) {
+        h.x0 = std::min(h.x0, Gl[q].c[0]); h.x1 = std::max(h.x1, Gl[q].c[0]);
+        h.y0 = std::min(h.y0, Gl[q].c[1]); h.y1 = std::max(h.y1, Gl[q].c[1]);
       }
     };
     if (nt > 1) parallel_for(n, nt, bbox, 1); else bbox(0, n, 0);
@@ -418,24 +435,23 @@ void nd_tree(Symbolic& S, int leaf_elems, int nthreads) {
         Hist& h = hs[tid];
         std::memset(h.cnt, 0, sizeof(h.cnt));
         std::memset(h.diff, 0, sizeof(h.diff));
-        for (int axis = 0; axis < 2; ++axis) {
-          const double a0 = a0s[axis], scale = scales[axis];
-          if (!(scale > 0.0)) continue;
-          const double* c = axis ? cy.data() : cx.data();
-          const double* elo = axis ? eylo.data() : exlo.data();
-          const double* ehi = axis ? eyhi.data() : exhi.data();
-          int32_t* cnt = h.cnt[axis];
-          int32_t* diff = h.diff[axis];
-          for (int64_t q = lo + b; q < lo + e_; ++q) {
-            int e = perm[q];
-            int bc = std::min(NBIN - 1, std::max(0, (int)((c[e] - a0) * scale)));
-            cnt[bc]++;
+        for (int64_t q = b; q < e_; ++q) {
+          const ElemGeo& g = Gl[q];
+          for (int axis = 0; axis < 2; ++axis) {
+            const double a0 = a0s[axis], scale = scales[axis];
+            if (!(scale > 0.0)) continue;
+            int bc = std::min(NBIN - 1, std::max(0, (int)((g.c[axis] - a0) * scale)));
+            h.cnt[axis][bc]++;
             // thresholds t_j = a0 + j/scale, j = 1..NBIN-1; the element touches the cut line iff
             // elo <= t_j <= ehi (closed: a line running along mesh edges still costs its nodes)
-            int j0 = (int)std::ceil((elo[e] - a0) * scale - 1e-9);
-            int j1 = (int)std::floor((ehi[e] - a0) * scale + 1e-9);
+            // ceil / floor by truncation + correction (the baseline x86-64 target has no rounding instruction,
+            // std::ceil / std::floor would be libm calls in the innermost loop of the analysis)
+            const double v0 = (g.lo[axis] - a0) * scale - 1e-9, v1 = (g.hi[axis] - a0) * scale + 1e-9;
+            const int t0 = (int)v0, t1 = (int)v1;
+            int j0 = t0 + (v0 > (double)t0);
+            int j1 = t1 - (v1 < (double)t1);
             j0 = std::max(j0, 1); j1 = std::min(j1, NBIN - 1);
-            if (j0 <= j1) { diff[j0]++; diff[j1 + 1]--; }
+            if (j0 <= j1) { h.diff[axis][j0]++; h.diff[axis][j1 + 1]--; }
           }
         }
       };
@@ -459,51 +475,51 @@ void nd_tree(Symbolic& S, int leaf_elems, int nthreads) {
         }
       }
       if (best_axis >= 0) {
-        const double* c = best_axis ? cy.data() : cx.data();
+        const int ax = best_axis;
         if (nt > 1) {
           // stable two-pass partition through scratch
           std::vector<int64_t> nl(nt + 1, 0);
-          const int64_t chunk = (n + nt - 1) / nt;
           parallel_for(n, nt, [&](int64_t b, int64_t e_, int tid) {
             int64_t k = 0;
-            for (int64_t q = lo + b; q < lo + e_; ++q) k += c[perm[q]] < best_thr;
+            for (int64_t q = b; q < e_; ++q) k += Gl[q].c[ax] < best_thr;
             nl[tid + 1] = k;
           }, 1);
           for (int t = 0; t < nt; ++t) nl[t + 1] += nl[t];
           const int64_t nleft = nl[nt];
+          ElemGeo* Sc = scratch.data() + lo;
           parallel_for(n, nt, [&](int64_t b, int64_t e_, int tid) {
-            int64_t wl = lo + nl[tid], wr = lo + nleft + (b - nl[tid]);
-            for (int64_t q = lo + b; q < lo + e_; ++q) {
-              int32_t e = perm[q];
-              if (c[e] < best_thr) scratch[wl++] = e; else scratch[wr++] = e;
+            int64_t wl = nl[tid], wr = nleft + (b - nl[tid]);
+            for (int64_t q = b; q < e_; ++q) {
+              if (Gl[q].c[ax] < best_thr) Sc[wl++] = Gl[q]; else Sc[wr++] = Gl[q];
             }
           }, 1);
-          (void)chunk;
           parallel_for(n, nt, [&](int64_t b, int64_t e_, int) {
-            std::memcpy(perm.data() + lo + b, scratch.data() + lo + b, sizeof(int32_t) * (size_t)(e_ - b));
+            std::memcpy((void*)(G.data() + lo + b), (const void*)(Sc + b), sizeof(ElemGeo) * (size_t)(e_ - b));
           }, 1);
           mid = lo + (int)nleft;
         } else {
-          auto it = std::partition(perm.begin() + lo, perm.begin() + hi, [&](int32_t e) { return c[e] < best_thr; });
-          mid = (int)(it - perm.begin());
+          auto it = std::partition(G.begin() + lo, G.begin() + hi, [&](const ElemGeo& g) { return g.c[ax] < best_thr; });
+          mid = (int)(it - G.begin());
         }
         if (mid - lo < min_side || hi - mid < min_side) mid = -1;
       }
     }
     if (mid < 0) {
-      const std::vector<double>& key = (x1 - x0 >= y1 - y0) ? cx : cy;
+      const int ax = (x1 - x0 >= y1 - y0) ? 0 : 1;
       mid = lo + n / 2;
-      std::nth_element(perm.begin() + lo, perm.begin() + mid, perm.begin() + hi,
-                       [&](int32_t a, int32_t b) { return key[a] < key[b] || (key[a] == key[b] && a < b); });
+      std::nth_element(G.begin() + lo, G.begin() + mid, G.begin() + hi, [&](const ElemGeo& a, const ElemGeo& b) {
+        return a.c[ax] < b.c[ax] || (a.c[ax] == b.c[ax] && a.id < b.id);
+      });
     }
     return mid;
   };
   std::function<void(int, int, int, int)> subtree = [&](int lo, int hi, int level, int idx) {
     if (level == L) {
       S.leaf_elem_ptr[idx] = lo;
-      // keep element ids ascending inside every leaf (deterministic assembly order)
-      std::sort(perm.begin() + lo, perm.begin() + hi);
-      for (int q = lo; q < hi; ++q) S.leaf_of_elem[perm[q]] = idx;
+      // element ids ascending inside every leaf (deterministic assembly order)
+      for (int q = lo; q < hi; ++q) S.leaf_elems[q] = G[q].id;
+      std::sort(S.leaf_elems.begin() + lo, S.leaf_elems.begin() + hi);
+      for (int q = lo; q < hi; ++q) S.leaf_of_elem[S.leaf_elems[q]] = idx;
       return;
     }
     const int mid = bisect(lo, hi, level, false);
@@ -532,7 +548,6 @@ void nd_tree(Symbolic& S, int leaf_elems, int nthreads) {
   parallel_tasks((int)cur.size(), nthreads, [&](int q) { subtree(cur[q].lo, cur[q].hi, level, cur[q].idx); });
   tr.lap("tree: subtrees");
   S.leaf_elem_ptr[(size_t)1 << L] = ne;
-  S.leaf_elems = std::move(perm);
 }
 
 inline int bitlen(uint32_t x) {
@@ -576,36 +591,81 @@ std::string build_fronts(Symbolic& S, int nthreads) {
   std::vector<LevelBuf> lv(L + 1);
   S.fs.resize(nf); S.fb.resize(nf); S.fs_true.resize(nf); S.fb_true.resize(nf);
   const int leaf0 = (1 << L) - 1, nleaf = 1 << L;
+  S.epos.resize((size_t)6 * ne);                 // uninitialised: every (element, local node) entry is written below
   {
+    // Leaf fronts from the NODE side: node i belongs to the leaves of its adjacent elements.  Visiting the nodes
+    // in ascending order (chunk t of the pool takes an ascending range, with per-chunk cursors inside every leaf
+    // list) yields ascending lists without sorting, and the position of node i in a leaf list is known when it is
+    // written -- which is exactly epos for every (element, local node) pair of that node in that leaf.
     LevelBuf& lb = lv[L];
     lb.off.assign((size_t)nleaf + 1, 0);
     for (int lf = 0; lf < nleaf; ++lf) lb.off[lf + 1] = lb.off[lf] + 6 * (int64_t)(S.leaf_elem_ptr[lf + 1] - S.leaf_elem_ptr[lf]);
     lb.own.resize(lb.off[nleaf]);
     lb.bnd.resize(lb.off[nleaf]);
-    parallel_for(nleaf, nthreads, [&](int64_t b, int64_t e_, int) {
-      std::vector<int32_t> tmp;
-      for (int64_t lf = b; lf < e_; ++lf) {
-        const int f = leaf0 + (int)lf;
-        tmp.clear();
-        for (int32_t q = S.leaf_elem_ptr[lf]; q < S.leaf_elem_ptr[lf + 1]; ++q) {
-          int32_t e = S.leaf_elems[q];
-          for (int a = 0; a < 6; ++a) {
-            int32_t i = S.edof[(size_t)a * ne + e];
-            if (!S.bmask[i]) tmp.push_back(i);
+    const int nt = (nthreads > 1 && g_pool && N >= 8192) ? g_pool->nt : 1;
+    // cnt[(t * nleaf + lf) * 2 + {0: own, 1: boundary}]: first counts, then start cursors of chunk t in leaf lf
+    std::vector<int32_t> cnt((size_t)nt * nleaf * 2, 0);
+    auto leaves_of = [&](int64_t i, int32_t* lfs) {      // distinct leaves of node i, in order of first appearance
+      int n = 0;
+      for (int32_t q = nptr[i]; q < nptr[i + 1]; ++q) {
+        const int32_t lf = S.leaf_of_elem[nadj[q]];
+        bool seen = false;
+        for (int k = 0; k < n; ++k) seen = seen || lfs[k] == lf;
+        if (!seen) lfs[n++] = lf;
+      }
+      return n;
+    };
+    int maxdeg = 0;
+    for (int i = 0; i < N; ++i) maxdeg = std::max(maxdeg, nptr[i + 1] - nptr[i]);
+    parallel_for(N, nt, [&](int64_t b, int64_t e_, int tid) {
+      std::vector<int32_t> lfs((size_t)maxdeg + 1);
+      int32_t* c = cnt.data() + (size_t)tid * nleaf * 2;
+      for (int64_t i = b; i < e_; ++i) {
+        if (S.bmask[i]) continue;
+        const int n = leaves_of(i, lfs.data());
+        for (int k = 0; k < n; ++k) c[2 * lfs[k] + (S.owner[i] == leaf0 + lfs[k] ? 0 : 1)]++;
+      }
+    }, 1);
+    for (int lf = 0; lf < nleaf; ++lf) {
+      int32_t no = 0, nb = 0;
+      for (int t = 0; t < nt; ++t) {
+        int32_t* c = cnt.data() + ((size_t)t * nleaf + lf) * 2;
+        const int32_t a = c[0], b2 = c[1];
+        c[0] = no; c[1] = nb;
+        no += a; nb += b2;
+      }
+      S.fs_true[leaf0 + lf] = no;
+      S.fb_true[leaf0 + lf] = nb;
+    }
+    parallel_for(N, nt, [&](int64_t b, int64_t e_, int tid) {
+      std::vector<int32_t> lfs((size_t)maxdeg + 1), pos((size_t)maxdeg + 1);
+      int32_t* c = cnt.data() + (size_t)tid * nleaf * 2;
+      for (int64_t i = b; i < e_; ++i) {
+        if (S.bmask[i]) {
+          for (int32_t q = nptr[i]; q < nptr[i + 1]; ++q) S.epos[(size_t)S.nloc[q] * ne + nadj[q]] = -1;
+          continue;
+        }
+        const int n = leaves_of(i, lfs.data());
+        for (int k = 0; k < n; ++k) {
+          const int32_t lf = lfs[k];
+          if (S.owner[i] == leaf0 + lf) {
+            const int32_t p = c[2 * lf]++;
+            lb.own[lb.off[lf] + p] = (int32_t)i;
+            pos[k] = p;
+          } else {
+            const int32_t p = c[2 * lf + 1]++;
+            lb.bnd[lb.off[lf] + p] = (int32_t)i;
+            pos[k] = pad8(S.fs_true[leaf0 + lf]) + p;
           }
         }
-        std::sort(tmp.begin(), tmp.end());
-        tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
-        int32_t* ow = lb.own.data() + lb.off[lf];
-        int32_t* bd = lb.bnd.data() + lb.off[lf];
-        int no = 0, nb = 0;
-        for (int32_t i : tmp) {
-          if (S.owner[i] == f) ow[no++] = i; else bd[nb++] = i;
+        for (int32_t q = nptr[i]; q < nptr[i + 1]; ++q) {
+          const int32_t lf = S.leaf_of_elem[nadj[q]];
+          int k = 0;
+          while (lfs[k] != lf) ++k;
+          S.epos[(size_t)S.nloc[q] * ne + nadj[q]] = pos[k];
         }
-        S.fs_true[f] = no;
-        S.fb_true[f] = nb;
       }
-    }, 64);
+    }, 1);
   }
   tr.lap("fronts: leaves");
   for (int lev = L - 1; lev >= 0; --lev) {
@@ -668,7 +728,6 @@ std::string build_fronts(Symbolic& S, int nthreads) {
   S.fnodes.resize(tot);                  // uninitialised: every entry (padding included) is written below
   S.cinv0.resize(tot);
   S.cinv1.resize(tot);
-  S.epos.resize((size_t)6 * ne);
   auto put = [](int32_t* dst, const int32_t* src, int count, int padded) {
     if (src) std::copy(src, src + count, dst);
     else std::fill(dst, dst + count, -1);
@@ -692,24 +751,6 @@ std::string build_fronts(Symbolic& S, int nthreads) {
       put(c0 + fs, leaf ? nullptr : b.c0.data() + o, nb, fb);
       put(c1, leaf ? nullptr : b.o1.data() + o, no, fs);
       put(c1 + fs, leaf ? nullptr : b.c1.data() + o, nb, fb);
-      if (leaf) {
-        // element node positions inside their leaf front (binary search in the two ascending lists)
-        const int lf = f - leaf0;
-        const int32_t* ow = b.own.data() + o;
-        const int32_t* bd = b.bnd.data() + o;
-        for (int32_t qe = S.leaf_elem_ptr[lf]; qe < S.leaf_elem_ptr[lf + 1]; ++qe) {
-          int32_t e = S.leaf_elems[qe];
-          for (int a = 0; a < 6; ++a) {
-            int32_t i = S.edof[(size_t)a * ne + e];
-            int32_t pos = -1;
-            if (!S.bmask[i]) {
-              if (S.owner[i] == f) pos = (int32_t)(std::lower_bound(ow, ow + no, i) - ow);
-              else pos = fs + (int32_t)(std::lower_bound(bd, bd + nb, i) - bd);
-            }
-            S.epos[(size_t)a * ne + e] = pos;
-          }
-        }
-      }
     }
   });
   tr.lap("fronts: flatten");
