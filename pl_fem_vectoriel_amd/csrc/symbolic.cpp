@@ -373,7 +373,8 @@ void nd_tree(Symbolic& S, int leaf_elems, int nthreads) {
   S.L = L;
   S.nfronts = (1 << (L + 1)) - 1;
   Trace tr;
-  std::vector<ElemGeo> G(ne), scratch(nthreads > 1 ? ne : 0);
+  // (default-initialised storage: a value-initialising vector would zero 2 x 64 B x ne on one thread first)
+  std::vector<ElemGeo, default_init_allocator<ElemGeo>> G(ne), scratch(nthreads > 1 ? ne : 0);
   const double* X = S.doflocs.data();
   const double* Y = X + N;
   parallel_for(ne, nthreads, [&](int64_t b_, int64_t e_, int) {
