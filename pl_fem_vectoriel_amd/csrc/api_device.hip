@@ -298,7 +298,7 @@ int create_impl(plfem_ctx* c, const plfem_symbolic* sym, int device, void* strea
   {
     const size_t nc1p = (size_t)max_ncv + 2 + plfem::BLOCK_P;
     // [0, 8192): scalars / counters / core table; then the projected matrix (nc1p^2); then two block-step slots
-    HIP_TRY(c, hipHostMalloc((void**)&c->h_pinned, sizeof(double) * (8192 + nc1p * nc1p + 2 * nc1p * plfem::BLOCK_P), hipHostMallocDefault));
+    HIP_TRY(c, hipHostMalloc((void**)&c->h_pinned, sizeof(double) * (8192 + nc1p * nc1p + 2 * nc1p * plfem::BLOCK_P), hipHostMallocMapped | hipHostMallocCoherent));
     c->h_slots = c->h_pinned + 8192 + nc1p * nc1p;
   }
   HIP_TRY(c, hipEventRecord(c->ev[4][1], c->stream));
@@ -461,17 +461,7 @@ static int lanczos_block(plfem_ctx* c, int k, int ncv, double tol, int maxiter, 
   double* hH = c->h_pinned + 8192;
   int nop = 0, nblock = 0, restarts = 0;
   {
-    std::vector<double> v0((size_t)n * P, 0.0);
-    uint64_t s = 0x9E3779B97F4A7C15ull;
-    const Symbolic& S = *c->S;
-    for (int q = 0; q < P; ++q)
-      for (int comp = 0; comp < 2; ++comp)
-        for (int i = 0; i < S.nsolve; ++i) {
-          s = s * 6364136223846793005ull + 1442695040888963407ull;
-          v0[(size_t)q * n + (size_t)comp * S.N + S.interior[i]] = ((double)(s >> 11) / 9007199254740992.0) * 2.0 - 1.0;
-        }
-    HIP_TRY(c, hipMemcpyAsync(c->d_V2, v0.data(), sizeof(double) * n * P, hipMemcpyHostToDevice, st));
-    HIP_TRY(c, hipStreamSynchronize(st));
+    plfem::launch_start_field(c, P, c->d_V2);       // fixed pseudo-random interior block, generated on the device
     plfem::launch_spmv_b_block(c, c->d_V2, c->d_bw, n);
     plfem::launch_solve_block(c, c->d_bw, c->d_w, n);
     nop += P; ++nblock;
@@ -489,21 +479,31 @@ static int lanczos_block(plfem_ctx* c, int k, int ncv, double tol, int maxiter, 
   // One block step = one pass over the factors for P vectors + CGS2 + CholQR, all asynchronous.  The
   // P new columns of the projected matrix and the rank flag follow it into a pinned slot, then an event.
   int32_t* hcnt = reinterpret_cast<int32_t*>(c->h_pinned + 4096);
+  double* slots_dev = nullptr;                   // device view of the pinned slots and counters
+  int32_t* hcnt_dev = nullptr;
+  HIP_TRY(c, hipHostGetDevicePointer((void**)&slots_dev, c->h_slots, 0));
+  HIP_TRY(c, hipHostGetDevicePointer((void**)&hcnt_dev, hcnt, 0));
+  // Orthogonalisation: in exact arithmetic OP V_j only has components along V_j and V_{j-1}, so the first
+  // Gram-Schmidt pass runs over those two blocks (where the cancellation is) and the second over the whole basis
+  // (full reorthogonalisation of what rounding left, no cancellation any more).  The first step after a thick
+  // restart couples with every kept Ritz vector: both passes full.
+  int cycle_start = -1;                          // first column of the current cycle when it follows a restart
   auto launch_step = [&](int c0_, int slot) -> int {
     const int nc = c0_ + P;
+    const int lo = (c0_ == cycle_start) ? 0 : std::max(0, nc - 2 * P);
     plfem::launch_solve_block(c, c->d_BV + (size_t)c0_ * n, c->d_w, n);      // W = OP V_j
-    double* Hblk = c->d_Hcols + (size_t)c0_ * ld;                             // T[0:nc, c0:c0+P]
-    plfem::launch_panel_dot_block(c, c->d_BV, nc, c->d_w, n, Hblk, ld);
-    plfem::launch_panel_axpy_block(c, c->d_V, nc, Hblk, ld, c->d_w, n);
-    plfem::launch_panel_dot_block(c, c->d_BV, nc, c->d_w, n, c->d_hblk, ld, Hblk, ld);  // CGS2 second pass, T += h2
+    double* Hblk = c->d_Hcols + (size_t)c0_ * ld;                             // T[0:nc, c0:c0+P] (zero before the step)
+    plfem::launch_panel_dot_block(c, c->d_BV + (size_t)lo * n, nc - lo, c->d_w, n, Hblk + lo, ld);
+    plfem::launch_panel_axpy_block(c, c->d_V + (size_t)lo * n, nc - lo, Hblk + lo, ld, c->d_w, n);
+    plfem::launch_panel_dot_block(c, c->d_BV, nc, c->d_w, n, c->d_hblk, ld, Hblk, ld);  // second pass, T += h2
     plfem::launch_panel_axpy_block(c, c->d_V, nc, c->d_hblk, ld, c->d_w, n);
     plfem::launch_spmv_b_block(c, c->d_w, c->d_bw, n);
     plfem::launch_gram_chol_block(c, c->d_w, c->d_bw, n, Hblk + nc, ld, c->d_Rinv);   // W^T B W = R^T R, R -> T[nc:nc+P, c0:c0+P]
-    plfem::launch_block_scale(c, c->d_w, c->d_bw, n, c->d_Rinv, c->d_V + (size_t)nc * n, c->d_BV + (size_t)nc * n, n);
+    // the last kernel of the step also stores the new columns and the counters into the pinned slot (no copies)
+    plfem::launch_block_scale(c, c->d_w, c->d_bw, n, c->d_Rinv, c->d_V + (size_t)nc * n, c->d_BV + (size_t)nc * n, n,
+                              Hblk, ld * P, slots_dev + (size_t)slot * ld * P, hcnt_dev + 4 * slot);
     int rc = check_launch(c, "block lanczos step");
     if (rc != PLFEM_OK) return rc;
-    HIP_TRY(c, hipMemcpyAsync(c->h_slots + (size_t)slot * ld * P, Hblk, sizeof(double) * ld * P, hipMemcpyDeviceToHost, st));
-    HIP_TRY(c, hipMemcpyAsync(hcnt + 4 * slot, c->d_counters, sizeof(int32_t) * 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(c, hipEventRecord(c->ev_step[slot], st));
     return PLFEM_OK;
   };
@@ -640,6 +640,7 @@ static int lanczos_block(plfem_ctx* c, int k, int ncv, double tol, int maxiter, 
     for (int q = 0; q < pk; ++q) T[(size_t)q * ld + q] = theta[order[q]];
     HIP_TRY(c, hipMemsetAsync(c->d_Hcols, 0, sizeof(double) * ld * ld, st));
     c0 = pk;
+    cycle_start = pk;
     ++restarts;
   }
   std::vector<int> want(order.begin(), order.begin() + k);
@@ -703,16 +704,7 @@ extern "C" int plfem_lanczos_shift_invert(plfem_ctx* c, int32_t k, int32_t ncv, 
 
   // start vector: fixed pseudo-random interior field pushed through OP once (as ARPACK does for mode 3)
   {
-    std::vector<double> v0((size_t)n, 0.0);
-    uint64_t s = 0x9E3779B97F4A7C15ull;
-    const Symbolic& S = *c->S;
-    for (int comp = 0; comp < 2; ++comp)
-      for (int q = 0; q < S.nsolve; ++q) {
-        s = s * 6364136223846793005ull + 1442695040888963407ull;
-        v0[(size_t)comp * S.N + S.interior[q]] = ((double)(s >> 11) / 9007199254740992.0) * 2.0 - 1.0;
-      }
-    HIP_TRY(c, hipMemcpyAsync(c->d_t1, v0.data(), sizeof(double) * n, hipMemcpyHostToDevice, st));
-    HIP_TRY(c, hipStreamSynchronize(st));
+    plfem::launch_start_field(c, 1, c->d_t1);
     plfem::launch_spmv(c, 1, c->d_t1, c->d_bw);
     plfem::launch_solve(c, c->d_bw, c->d_w);
     ++nop;

@@ -143,7 +143,9 @@ void launch_mat_add(plfem_ctx* c, int ncols, double* acc, int lda, const double*
 void launch_gram_chol_block(plfem_ctx* c, const double* W, const double* BW, int64_t ldw, double* Tblk, int ldT, double* Rinv);
 void launch_chol_block(plfem_ctx* c, const double* G, int ldg, double* Tblk, int ldT, double* Rinv);
 void launch_block_scale(plfem_ctx* c, const double* W, const double* BW, int64_t ldw, const double* Rinv, double* Vn,
-                        double* BVn, int64_t ldv);
+                        double* BVn, int64_t ldv, const double* exp_src = nullptr, int exp_n = 0, double* exp_dst = nullptr,
+                        int32_t* cnt_dst = nullptr);
+void launch_start_field(plfem_ctx* c, int nvec, double* out);
 void launch_post(plfem_ctx* c, int k, double* evecs, int ncore, double* out_host, double* frac_core, double* modes_int);
 
 }  // namespace plfem

@@ -907,13 +907,16 @@ __global__ __launch_bounds__(256) void k_interleave(int64_t n, const double* __r
   for (int u = 0; u < P; ++u) il[i * P + u] = cols[(int64_t)u * ld + i];
 }
 
+// the sweeps never write the Dirichlet DOFs of the interleaved result: they are set to zero here (bmask), so the
+// result buffer needs no memset per solve
 template <int P>
-__global__ __launch_bounds__(256) void k_deinterleave(int64_t n, const double* __restrict__ il, double* __restrict__ cols,
-                                                      int64_t ld) {
+__global__ __launch_bounds__(256) void k_deinterleave(int64_t n, int N, const uint8_t* __restrict__ bmask,
+                                                      const double* __restrict__ il, double* __restrict__ cols, int64_t ld) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
+  const bool fixed = bmask[i < N ? i : i - N] != 0;
 #pragma unroll
-  for (int u = 0; u < P; ++u) cols[(int64_t)u * ld + i] = il[i * P + u];
+  for (int u = 0; u < P; ++u) cols[(int64_t)u * ld + i] = fixed ? 0.0 : il[i * P + u];
 }
 
 }  // namespace
@@ -994,9 +997,8 @@ void launch_factor(plfem_ctx* c, double sigma, int stop_level, int stop_step, in
 template <int P>
 static void launch_solve_p(plfem_ctx* c, const double* rhs, double* x, int64_t ldx) {
   hipStream_t st = c->stream;
-  if (ldx == 0) (void)hipMemsetAsync(x, 0, sizeof(double) * c->n2 * P, st);
-  else
-    for (int u = 0; u < P; ++u) (void)hipMemsetAsync(x + (int64_t)u * ldx, 0, sizeof(double) * c->n2, st);
+  // (interleaved results, ldx == 0, get their Dirichlet entries zeroed by k_deinterleave)
+  for (int u = 0; u < P && ldx != 0; ++u) (void)hipMemsetAsync(x + (int64_t)u * ldx, 0, sizeof(double) * c->n2, st);
   // Kernel form by level: fwd_block_rows / bwd_block_rows (device.h); workgroups come from the compact launch
   // lists of the context (no empty workgroups, large fronts first).  Measured at C1 (P = 4): 4 waves per block in
   // the forward tile kernel, 8 in every backward form, 2 rows per wave at the mid levels
@@ -1059,7 +1061,7 @@ void launch_solve_block(plfem_ctx* c, const double* rhs, double* x, int64_t ldx)
   const unsigned grid = (unsigned)((c->n2 + 255) / 256);
   hipLaunchKernelGGL(k_interleave<BLOCK_P>, dim3(grid), dim3(256), 0, c->stream, c->n2, rhs, ldx, c->d_t1);
   launch_solve_p<BLOCK_P>(c, c->d_t1, c->d_t2, 0);
-  hipLaunchKernelGGL(k_deinterleave<BLOCK_P>, dim3(grid), dim3(256), 0, c->stream, c->n2, c->d_t2, x, ldx);
+  hipLaunchKernelGGL(k_deinterleave<BLOCK_P>, dim3(grid), dim3(256), 0, c->stream, c->n2, c->N, c->d_bmask, c->d_t2, x, ldx);
 }
 
 }  // namespace plfem

@@ -190,18 +190,19 @@ __global__ void k_mat_add(int ncols, int P, double* __restrict__ acc, int lda, c
 // G comes either ready-made (G != nullptr) or as the chunk partials of k_panel_dot_p (partial[((c P + q) nchunks +
 // chunk)], summed here in the same fixed order as k_panel_dot_finish_p: one launch less per block step)
 template <int P>
-__global__ __launch_bounds__(64) void k_chol_small(const double* __restrict__ G, int ldg, const double* __restrict__ partial,
-                                                   int nchunks, double* __restrict__ Tblk, int ldT,
-                                                   double* __restrict__ Rinv, int32_t* __restrict__ counters) {
+__global__ __launch_bounds__(64 * P * P) void k_chol_small(const double* __restrict__ G, int ldg, const double* __restrict__ partial,
+                                                           int nchunks, double* __restrict__ Tblk, int ldT,
+                                                           double* __restrict__ Rinv, int32_t* __restrict__ counters) {
   __shared__ double sG[P * P];
   if (G) {
     if (threadIdx.x < P * P) sG[threadIdx.x] = G[(threadIdx.x % P) + (int64_t)(threadIdx.x / P) * ldg];
   } else {
-    for (int cq = 0; cq < P * P; ++cq) {             // cq = c P + q  ->  G[c + q ldg]
+    const int lane = threadIdx.x & 63;
+    for (int cq = threadIdx.x >> 6; cq < P * P; cq += blockDim.x >> 6) {   // one wave per entry; cq = c P + q  ->  G[c + q ldg]
       double acc = 0.0;
-      for (int t = threadIdx.x; t < nchunks; t += 64) acc += partial[(int64_t)cq * nchunks + t];
+      for (int t = lane; t < nchunks; t += 64) acc += partial[(int64_t)cq * nchunks + t];
       for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
-      if (threadIdx.x == 0) sG[(cq / P) + (cq % P) * P] = acc;
+      if (lane == 0) sG[(cq / P) + (cq % P) * P] = acc;
     }
   }
   __syncthreads();
@@ -239,12 +240,21 @@ __global__ __launch_bounds__(64) void k_chol_small(const double* __restrict__ G,
 }
 
 // Vn = W R^-1, BVn = BW R^-1 (R^-1 upper triangular)
+// exp_*: workgroup 0 also stores the step's new projected-matrix columns and the counters into the pinned slot of
+// the host (a store over the host link from the last kernel of the step costs nothing; two blit copies behind it
+// cost ~25 us of stream time per block step)
 template <int P>
 __global__ __launch_bounds__(256) void k_block_scale(int64_t n, const double* __restrict__ W, const double* __restrict__ BW,
                                                      int64_t ldw, const double* __restrict__ Rinv,
-                                                     double* __restrict__ Vn, double* __restrict__ BVn, int64_t ldv) {
+                                                     double* __restrict__ Vn, double* __restrict__ BVn, int64_t ldv,
+                                                     const double* __restrict__ exp_src, int exp_n, double* __restrict__ exp_dst,
+                                                     const int32_t* __restrict__ cnt_src, int32_t* __restrict__ cnt_dst) {
   __shared__ double X[P * P];
   if (threadIdx.x < P * P) X[threadIdx.x] = Rinv[threadIdx.x];
+  if (blockIdx.x == 0 && exp_dst) {
+    for (int t = threadIdx.x; t < exp_n; t += 256) exp_dst[t] = exp_src[t];
+    if (threadIdx.x < 4) cnt_dst[threadIdx.x] = cnt_src[threadIdx.x];
+  }
   __syncthreads();
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
@@ -454,14 +464,43 @@ void launch_gram_chol_block(plfem_ctx* c, const double* W, const double* BW, int
   constexpr int P = BLOCK_P;
   const int nchunks = c->npartial;
   hipLaunchKernelGGL(k_panel_dot_p<P>, dim3(nchunks, 1), dim3(256), 0, c->stream, c->n2, P, nchunks, W, BW, ldw, c->d_partial);
-  hipLaunchKernelGGL(k_chol_small<P>, dim3(1), dim3(64), 0, c->stream, (const double*)nullptr, 0, c->d_partial, nchunks, Tblk,
-                     ldT, Rinv, c->d_counters);
+  hipLaunchKernelGGL(k_chol_small<P>, dim3(1), dim3(64 * P * P), 0, c->stream, (const double*)nullptr, 0, c->d_partial, nchunks,
+                     Tblk, ldT, Rinv, c->d_counters);
 }
 
 void launch_block_scale(plfem_ctx* c, const double* W, const double* BW, int64_t ldw, const double* Rinv, double* Vn,
-                        double* BVn, int64_t ldv) {
+                        double* BVn, int64_t ldv, const double* exp_src, int exp_n, double* exp_dst, int32_t* cnt_dst) {
   hipLaunchKernelGGL(k_block_scale<BLOCK_P>, dim3((unsigned)((c->n2 + 255) / 256)), dim3(256), 0, c->stream, c->n2, W,
-                     BW, ldw, Rinv, Vn, BVn, ldv);
+                     BW, ldw, Rinv, Vn, BVn, ldv, exp_src, exp_n, exp_dst, c->d_counters, cnt_dst);
+}
+
+// Start block of the Lanczos drivers: the fixed pseudo-random interior field (a 64-bit LCG stream, element e of the
+// stream = state after e + 1 updates, values in [-1, 1)), written straight into the padded vectors.  Every thread
+// jumps the generator to its own element (a^k and the matching increment by binary powering), so the field is the
+// same as a sequential host loop over (vector, component, interior DOF) and costs no host time or upload.
+__global__ __launch_bounds__(256) void k_start_field(int nsolve, int N, int64_t ld, int nvec,
+                                                     const int32_t* __restrict__ interior, double* __restrict__ out) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (int64_t)nvec * 2 * nsolve) return;
+  uint64_t k = (uint64_t)e + 1, am = 1, ap = 0, cm = 6364136223846793005ull, cp = 1442695040888963407ull;
+  while (k) {
+    if (k & 1) { am *= cm; ap = ap * cm + cp; }
+    cp = (cm + 1) * cp;
+    cm *= cm;
+    k >>= 1;
+  }
+  const uint64_t s = am * 0x9E3779B97F4A7C15ull + ap;
+  const int q = (int)(e / (2 * (int64_t)nsolve));
+  const int r = (int)(e - (int64_t)q * 2 * nsolve);
+  const int comp = r >= nsolve, i = r - comp * nsolve;
+  out[(int64_t)q * ld + (int64_t)comp * N + interior[i]] = ((double)(s >> 11) / 9007199254740992.0) * 2.0 - 1.0;
+}
+
+void launch_start_field(plfem_ctx* c, int nvec, double* out) {
+  (void)hipMemsetAsync(out, 0, sizeof(double) * c->n2 * nvec, c->stream);
+  const int64_t total = (int64_t)nvec * 2 * c->nsolve;
+  hipLaunchKernelGGL(k_start_field, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, c->nsolve, c->N,
+                     c->n2, nvec, c->d_interior, out);
 }
 
 void launch_rotate(plfem_ctx* c, const double* V, int m, const double* Smat, int ldS, int p, double* out) {

@@ -1,0 +1,8 @@
+#!/bin/bash
+# kernel trace of a short bench run, summarised as the timeline of one block Lanczos step (run through gpurun)
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+rm -rf gpurun_out/prof_step
+rocprofv3 --kernel-trace -d gpurun_out/prof_step -o st --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/bench_st.log 2>&1 || exit 1
+python3 scripts/step_timeline.py gpurun_out/prof_step/st_kernel_trace.csv 70 > gpurun_out/step_timeline.txt
+rm -rf gpurun_out/prof_step
+cat gpurun_out/step_timeline.txt
