@@ -468,7 +468,7 @@ static int lanczos_block(plfem_ctx* c, int k, int ncv, double tol, int maxiter, 
     plfem::launch_spmv_b_block(c, c->d_w, c->d_bw, n);
     plfem::launch_panel_dot_block(c, c->d_w, P, c->d_bw, n, c->d_G, P);
     plfem::launch_chol_block(c, c->d_G, P, c->d_hblk, P, c->d_Rinv);      // R itself is not needed for the start block
-    plfem::launch_block_scale(c, c->d_w, c->d_bw, n, c->d_Rinv, c->d_V, c->d_BV, n);
+    plfem::launch_block_scale(c, c->d_w, c->d_bw, n, c->d_Rinv, c->d_V, c->d_BV, n, nullptr, 0, nullptr, nullptr, c->d_t1);
   }
   HIP_TRY(c, hipMemsetAsync(c->d_Hcols, 0, sizeof(double) * ld * ld, st));
   int c0 = 0, mm = 0, nconv = 0;
@@ -488,10 +488,11 @@ static int lanczos_block(plfem_ctx* c, int k, int ncv, double tol, int maxiter, 
   // (full reorthogonalisation of what rounding left, no cancellation any more).  The first step after a thick
   // restart couples with every kept Ritz vector: both passes full.
   int cycle_start = -1;                          // first column of the current cycle when it follows a restart
+  int il_ready = 0;                              // basis column whose B V block d_t1 holds interleaved (k_block_scale)
   auto launch_step = [&](int c0_, int slot) -> int {
     const int nc = c0_ + P;
     const int lo = (c0_ == cycle_start) ? 0 : std::max(0, nc - 2 * P);
-    plfem::launch_solve_block(c, c->d_BV + (size_t)c0_ * n, c->d_w, n);      // W = OP V_j
+    plfem::launch_solve_block(c, c->d_BV + (size_t)c0_ * n, c->d_w, n, il_ready == c0_);      // W = OP V_j
     double* Hblk = c->d_Hcols + (size_t)c0_ * ld;                             // T[0:nc, c0:c0+P] (zero before the step)
     plfem::launch_panel_dot_block(c, c->d_BV + (size_t)lo * n, nc - lo, c->d_w, n, Hblk + lo, ld);
     plfem::launch_panel_axpy_block(c, c->d_V + (size_t)lo * n, nc - lo, Hblk + lo, ld, c->d_w, n);
@@ -501,7 +502,8 @@ static int lanczos_block(plfem_ctx* c, int k, int ncv, double tol, int maxiter, 
     plfem::launch_gram_chol_block(c, c->d_w, c->d_bw, n, Hblk + nc, ld, c->d_Rinv);   // W^T B W = R^T R, R -> T[nc:nc+P, c0:c0+P]
     // the last kernel of the step also stores the new columns and the counters into the pinned slot (no copies)
     plfem::launch_block_scale(c, c->d_w, c->d_bw, n, c->d_Rinv, c->d_V + (size_t)nc * n, c->d_BV + (size_t)nc * n, n,
-                              Hblk, ld * P, slots_dev + (size_t)slot * ld * P, hcnt_dev + 4 * slot);
+                              Hblk, ld * P, slots_dev + (size_t)slot * ld * P, hcnt_dev + 4 * slot, c->d_t1);
+    il_ready = nc;
     int rc = check_launch(c, "block lanczos step");
     if (rc != PLFEM_OK) return rc;
     HIP_TRY(c, hipEventRecord(c->ev_step[slot], st));
@@ -641,6 +643,7 @@ static int lanczos_block(plfem_ctx* c, int k, int ncv, double tol, int maxiter, 
     HIP_TRY(c, hipMemsetAsync(c->d_Hcols, 0, sizeof(double) * ld * ld, st));
     c0 = pk;
     cycle_start = pk;
+    il_ready = -1;
     ++restarts;
   }
   std::vector<int> want(order.begin(), order.begin() + k);

@@ -124,7 +124,7 @@ std::vector<hipEvent_t>& profile_event_pool();
 // kernels_front.hip
 void launch_factor(plfem_ctx* c, double sigma, int stop_level = -1, int stop_step = 0, int stop_stage = 0);
 void launch_solve(plfem_ctx* c, const double* rhs, double* x);
-void launch_solve_block(plfem_ctx* c, const double* rhs, double* x, int64_t ldx);   // BLOCK_P right-hand sides
+void launch_solve_block(plfem_ctx* c, const double* rhs, double* x, int64_t ldx, bool rhs_interleaved_in_t1 = false);   // BLOCK_P right-hand sides
 // kernels_lanczos.hip
 void launch_panel_dot(plfem_ctx* c, const double* P, int ncols, const double* w, double* h);   // h = P^T w
 void launch_panel_axpy(plfem_ctx* c, const double* P, int ncols, const double* h, double* w);  // w -= P h
@@ -144,7 +144,7 @@ void launch_gram_chol_block(plfem_ctx* c, const double* W, const double* BW, int
 void launch_chol_block(plfem_ctx* c, const double* G, int ldg, double* Tblk, int ldT, double* Rinv);
 void launch_block_scale(plfem_ctx* c, const double* W, const double* BW, int64_t ldw, const double* Rinv, double* Vn,
                         double* BVn, int64_t ldv, const double* exp_src = nullptr, int exp_n = 0, double* exp_dst = nullptr,
-                        int32_t* cnt_dst = nullptr);
+                        int32_t* cnt_dst = nullptr, double* bv_il = nullptr);
 void launch_start_field(plfem_ctx* c, int nvec, double* out);
 void launch_post(plfem_ctx* c, int k, double* evecs, int ncore, double* out_host, double* frac_core, double* modes_int);
 

@@ -1057,9 +1057,11 @@ void launch_solve(plfem_ctx* c, const double* rhs, double* x) { launch_solve_p<1
 
 // BLOCK_P right-hand sides given as columns (ldx apart): interleaved inside the sweeps so that the P
 // values of a DOF are one 32-byte access (t1/t2 scratch: n2 x BLOCK_P each)
-void launch_solve_block(plfem_ctx* c, const double* rhs, double* x, int64_t ldx) {
+// rhs_interleaved_in_t1: the caller's previous kernel already left the interleaved right-hand side in d_t1
+void launch_solve_block(plfem_ctx* c, const double* rhs, double* x, int64_t ldx, bool rhs_interleaved_in_t1) {
   const unsigned grid = (unsigned)((c->n2 + 255) / 256);
-  hipLaunchKernelGGL(k_interleave<BLOCK_P>, dim3(grid), dim3(256), 0, c->stream, c->n2, rhs, ldx, c->d_t1);
+  if (!rhs_interleaved_in_t1)
+    hipLaunchKernelGGL(k_interleave<BLOCK_P>, dim3(grid), dim3(256), 0, c->stream, c->n2, rhs, ldx, c->d_t1);
   launch_solve_p<BLOCK_P>(c, c->d_t1, c->d_t2, 0);
   hipLaunchKernelGGL(k_deinterleave<BLOCK_P>, dim3(grid), dim3(256), 0, c->stream, c->n2, c->N, c->d_bmask, c->d_t2, x, ldx);
 }

@@ -248,7 +248,8 @@ __global__ __launch_bounds__(256) void k_block_scale(int64_t n, const double* __
                                                      int64_t ldw, const double* __restrict__ Rinv,
                                                      double* __restrict__ Vn, double* __restrict__ BVn, int64_t ldv,
                                                      const double* __restrict__ exp_src, int exp_n, double* __restrict__ exp_dst,
-                                                     const int32_t* __restrict__ cnt_src, int32_t* __restrict__ cnt_dst) {
+                                                     const int32_t* __restrict__ cnt_src, int32_t* __restrict__ cnt_dst,
+                                                     double* __restrict__ bv_il) {
   __shared__ double X[P * P];
   if (threadIdx.x < P * P) X[threadIdx.x] = Rinv[threadIdx.x];
   if (blockIdx.x == 0 && exp_dst) {
@@ -268,6 +269,7 @@ __global__ __launch_bounds__(256) void k_block_scale(int64_t n, const double* __
     for (int k = 0; k <= q; ++k) { a += w[k] * X[k + q * P]; b += bw[k] * X[k + q * P]; }
     Vn[(int64_t)q * ldv + i] = a;
     BVn[(int64_t)q * ldv + i] = b;
+    if (bv_il) bv_il[i * P + q] = b;     // the next solve's right-hand side, already in the sweeps' interleaved layout
   }
 }
 
@@ -469,9 +471,10 @@ void launch_gram_chol_block(plfem_ctx* c, const double* W, const double* BW, int
 }
 
 void launch_block_scale(plfem_ctx* c, const double* W, const double* BW, int64_t ldw, const double* Rinv, double* Vn,
-                        double* BVn, int64_t ldv, const double* exp_src, int exp_n, double* exp_dst, int32_t* cnt_dst) {
+                        double* BVn, int64_t ldv, const double* exp_src, int exp_n, double* exp_dst, int32_t* cnt_dst,
+                        double* bv_il) {
   hipLaunchKernelGGL(k_block_scale<BLOCK_P>, dim3((unsigned)((c->n2 + 255) / 256)), dim3(256), 0, c->stream, c->n2, W,
-                     BW, ldw, Rinv, Vn, BVn, ldv, exp_src, exp_n, exp_dst, c->d_counters, cnt_dst);
+                     BW, ldw, Rinv, Vn, BVn, ldv, exp_src, exp_n, exp_dst, c->d_counters, cnt_dst, bv_il);
 }
 
 // Start block of the Lanczos drivers: the fixed pseudo-random interior field (a 64-bit LCG stream, element e of the
