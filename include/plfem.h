@@ -201,10 +201,14 @@ int plfem_profile_end(plfem_ctx* ctx, double* out_host /* [3] */);
  * <= ~200; needs no GPU).  a_host: n x n symmetric.  last_rows < 0: v_out[i*n + k] = component k of
  * eigenvector i; last_rows = p >= 0: v_out[i*p + a] = component n-p+a of eigenvector i only (the
  * cheap form used by the per-step convergence test).  w_out[n]: eigenvalues, same (arbitrary) order.
+ * plfem_debug_symeig_band: the band path used for the final Ritz vectors of a run without restart
+ * (half bandwidth b; entries further from the diagonal are ignored): w_out[n] ascending, v_out[i*n + k] =
+ * component k of the eigenvector of w_out[i] for the nsel eigenvalues of largest magnitude, zero rows elsewhere.
  * ------------------------------------------------------------------------------------------- */
 int plfem_debug_factor_until(plfem_ctx* ctx, double sigma, int32_t level, int32_t step, int32_t stage);
 int plfem_debug_copy(plfem_ctx* ctx, const char* name, int64_t offset, int64_t count, double* out_host);
 int plfem_debug_symeig(int32_t n, const double* a_host, int32_t last_rows, double* w_out, double* v_out);
+int plfem_debug_symeig_band(int32_t n, int32_t b, const double* a_host, int32_t nsel, double* w_out, double* v_out);
 
 #ifdef __cplusplus
 }

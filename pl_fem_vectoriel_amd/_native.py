@@ -30,7 +30,7 @@ EXPORTS = (
     "plfem_assemble_hfield", "plfem_block_values_dev", "plfem_block_values_host", "plfem_spmv", "plfem_factor",
     "plfem_solve", "plfem_lanczos_shift_invert", "plfem_postprocess", "plfem_timings",
     "plfem_debug_factor_until", "plfem_debug_copy", "plfem_profile_begin", "plfem_profile_end",
-    "plfem_mesh_edge_count", "plfem_mesh_refine", "plfem_debug_symeig",
+    "plfem_mesh_edge_count", "plfem_mesh_refine", "plfem_debug_symeig", "plfem_debug_symeig_band",
 )
 
 _ARRAY_DTYPES = {
@@ -152,6 +152,25 @@ def debug_symeig(a, last_rows: int = -1):
     rc = lib.plfem_debug_symeig(n, _ptr(a), int(last_rows), _ptr(w), _ptr(v))
     if rc != PLFEM_OK:
         raise ValueError(f"plfem_debug_symeig failed ({rc})")
+    return w, v
+
+
+def debug_symeig_band(a, b: int, nsel: int):
+    """Band path of the host eigensolver (``plfem_debug_symeig_band``): ``(w, V)`` with w ascending and the
+    eigenvector of ``w[i]`` in row i of V for the ``nsel`` eigenvalues of largest magnitude (zero rows elsewhere)."""
+    lib = load_library()
+    a = np.ascontiguousarray(np.asarray(a, dtype=np.float64))
+    n = a.shape[0]
+    if a.shape != (n, n):
+        raise ValueError("square matrix expected")
+    w = np.empty(n, dtype=np.float64)
+    v = np.empty((n, n), dtype=np.float64)
+    lib.plfem_debug_symeig_band.argtypes = [ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32,
+                                            ctypes.c_void_p, ctypes.c_void_p]
+    lib.plfem_debug_symeig_band.restype = ctypes.c_int
+    rc = lib.plfem_debug_symeig_band(n, int(b), _ptr(a), int(nsel), _ptr(w), _ptr(v))
+    if rc != PLFEM_OK:
+        raise ValueError(f"plfem_debug_symeig_band failed ({rc})")
     return w, v
 
 

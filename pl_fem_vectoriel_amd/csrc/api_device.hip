@@ -559,10 +559,24 @@ static int lanczos_block(plfem_ctx* c, int k, int ncv, double tol, int maxiter, 
     plfem::sym_eig_last_rows(mm_, P, Tm, Ylast, theta);
     count_converged(mm_, [&](int id, int b) { return Ylast[(size_t)id * P + b]; });
   };
-  // full Ritz decomposition (theta, Svec, order): before a restart and for the final rotation
-  auto full_check = [&](int mm_) {
+  // Ritz decomposition (theta, Svec, order) for the final rotation, or (need_all) for a restart.  Before the first
+  // restart the projected matrix is block tridiagonal (half bandwidth P; what full reorthogonalisation leaves outside
+  // the band is rounding) and the final rotation only needs the k wanted vectors: band path of host_eig.h, Svec
+  // then holds the rows of order[0 .. k) only.
+  const bool band_path = !(getenv("PLFEM_RITZ_BAND") && atoi(getenv("PLFEM_RITZ_BAND")) == 0);
+  auto full_check = [&](int mm_, bool need_all) {
     fill_tm(mm_);
-    plfem::sym_eig(mm_, Tm, Svec, theta);
+    if (band_path && restarts == 0 && !need_all) {
+      plfem::sym_band_eigenvalues(mm_, P, Tm.data(), mm_, theta);
+      std::vector<int> ids(mm_);
+      std::iota(ids.begin(), ids.end(), 0);
+      std::sort(ids.begin(), ids.end(), [&](int a, int b) { return std::fabs(theta[a]) > std::fabs(theta[b]); });
+      ids.resize(std::min(k, mm_));
+      Svec.resize((size_t)mm_ * mm_);
+      plfem::sym_band_eigenvectors(mm_, P, Tm.data(), mm_, theta, ids, Svec.data(), mm_);
+    } else {
+      plfem::sym_eig(mm_, Tm, Svec, theta);
+    }
     count_converged(mm_, [&](int id, int b) { return Svec[(size_t)id * mm_ + (mm_ - P + b)]; });
   };
   // Pipeline: while the GPU runs block step j + 1, the host tests convergence on the projected matrix of
@@ -591,7 +605,7 @@ static int lanczos_block(plfem_ctx* c, int k, int ncv, double tol, int maxiter, 
         mm = pend_c0 + P;
         if (mm >= k + P && (new_c0 >= 0 || predicted)) {     // (the last step of a cycle gets the full test below)
           // a held step is expected to converge: go straight to the full decomposition the rotation needs
-          if (predicted) { full_check(mm); have_full = true; } else { quick_check(mm); have_full = false; }
+          if (predicted) { full_check(mm, false); have_full = true; } else { quick_check(mm); have_full = false; }
           res_prev = res_last;
           res_last = max_rel_res;
           if (getenv("PLFEM_LANCZOS_TRACE"))
@@ -609,18 +623,18 @@ static int lanczos_block(plfem_ctx* c, int k, int ncv, double tol, int maxiter, 
       if (pend_c0 < 0) break;                       // basis full and every step absorbed
     }
     if (converged) {
-      if (!have_full) full_check(mm);
+      if (!have_full) full_check(mm, false);
       if (nconv < k) {                              // the two eigensolvers disagree at the threshold: resume
         converged = false;
         if (inflight) { TRY(absorb_step(c0 - P, slot ^ 1)); }
         res_prev = res_last = 0.0;
         if (c0 + P <= m) continue;
         mm = c0;
-        full_check(mm);
+        full_check(mm, true);
       }
     } else {
       mm = c0;
-      full_check(mm);
+      full_check(mm, true);
     }
     res_prev = res_last = 0.0;                      // a restart changes the decay
     if (nconv >= k || restarts >= maxiter) { done = nconv >= k; break; }

@@ -16,4 +16,13 @@ bool sym_eig(int n, std::vector<double>& A, std::vector<double>& V, std::vector<
 // and it skips both cubic-cost stages that carry full eigenvectors: O(2/3 n^3) instead of O(~5 n^3).
 bool sym_eig_last_rows(int n, int p, std::vector<double>& A, std::vector<double>& Y, std::vector<double>& w);
 
+// Band path (block tridiagonal projected matrices, only a few eigenvectors wanted).  A: n x n, upper triangle read
+// (A[i*lda + j], j >= i), entries more than b off the diagonal are ignored.
+// sym_band_eigenvalues: all eigenvalues, ascending.  sym_band_eigenvectors: unit eigenvectors of w[id] for the
+// listed ids, written to S[id*lds .. id*lds + n) (rows of other ids untouched); orthonormal to rounding, also
+// inside clusters.  Both return false if an iteration did not converge as expected (result still usable).
+bool sym_band_eigenvalues(int n, int b, const double* A, int lda, std::vector<double>& w);
+bool sym_band_eigenvectors(int n, int b, const double* A, int lda, const std::vector<double>& w, const std::vector<int>& ids,
+                           double* S, int lds);
+
 }  // namespace plfem

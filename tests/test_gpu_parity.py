@@ -167,6 +167,7 @@ def test_eigenpairs_match_scipy_eigsh(medium):
     P.ctx.factor(P.sigma)
     evals, evecs, st = P.ctx.lanczos(k, ncv, 1e-10, 12000, P.sigma)
     assert st["nconv"] == k
+    assert st["restarts"] >= 1          # a 48-column basis at this tolerance: the thick-restart path is exercised
     w, U = spla.eigsh(P.A_int, k=k, M=P.B_int, sigma=P.sigma, which="LM", tol=1e-7, maxiter=12000)
     o = np.argsort(w)
     w, U = w[o], U[:, o]

@@ -52,3 +52,37 @@ def test_rejects_bad_arguments(built_library):
         _native.debug_symeig(np.zeros((3, 4)))
     with pytest.raises(ValueError):
         _native.debug_symeig(np.eye(3), last_rows=5)
+
+
+@pytest.mark.parametrize("n,nsel", [(1, 1), (3, 3), (8, 4), (44, 22), (100, 22), (104, 32), (164, 22)])
+def test_band_path_selected_vectors(built_library, n, nsel):
+    """Band reduction + QL eigenvalues + inverse iteration for the eigenvalues of largest magnitude (the final
+    Ritz decomposition of a run without restart): eigenvalues of the band part, residuals and orthonormality of
+    the selected vectors — including pairs 1e-9 apart — at the level of the dense solver."""
+    rng = np.random.default_rng(31 * n + nsel)
+    b = 4
+    a = _band_clustered(n, rng, hbw=b) if n >= 8 else np.diag(rng.standard_normal(n))
+    noise = 1e-17 * rng.standard_normal((n, n))            # what full reorthogonalisation leaves outside the band
+    w, v = _native.debug_symeig_band(a + np.triu(noise, b + 1) + np.triu(noise, b + 1).T, b, nsel)
+    scale = max(1.0, np.abs(a).max())
+    assert (np.diff(w) >= 0).all()
+    assert np.abs(w - np.linalg.eigvalsh(a)).max() < 5e-14 * scale * n
+    sel = np.argsort(-np.abs(w), kind="stable")[:nsel]
+    s = v[sel]
+    assert np.abs(np.delete(v, sel, axis=0)).max(initial=0.0) == 0.0
+    assert np.abs(s @ a - s * w[sel][:, None]).max() < 5e-14 * scale * n
+    assert np.abs(s @ s.T - np.eye(nsel)).max() < 5e-14 * n
+
+
+def test_band_path_exactly_repeated_eigenvalues(built_library):
+    """Two decoupled copies of the same band matrix: every eigenvalue is exactly double."""
+    rng = np.random.default_rng(5)
+    blk = _band_clustered(24, rng)
+    a = np.zeros((48, 48))
+    a[:24, :24] = blk
+    a[24:, 24:] = blk
+    w, v = _native.debug_symeig_band(a, 4, 20)
+    sel = np.argsort(-np.abs(w), kind="stable")[:20]
+    s = v[sel]
+    assert np.abs(s @ a - s * w[sel][:, None]).max() < 1e-12
+    assert np.abs(s @ s.T - np.eye(20)).max() < 1e-12
