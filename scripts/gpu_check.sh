@@ -3,7 +3,7 @@
 set -e -o pipefail
 mkdir -p gpurun_out
 timeout -k 10 700 python3 -m pytest tests -m gpu -x -q 2>&1 | tail -3
-PLFEM_LANCZOS_TRACE=1 python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline 2>gpurun_out/bench_tr.log >gpurun_out/bench_short.json
+PLFEM_LANCZOS_TRACE=1 timeout -k 10 300 python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline 2>gpurun_out/bench_tr.log >gpurun_out/bench_short.json
 python3 - <<'PY'
 import json
 d = json.loads([l for l in open("gpurun_out/bench_short.json") if l.startswith("{")][-1])
