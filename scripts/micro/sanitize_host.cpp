@@ -36,6 +36,9 @@ int main(int argc, char** argv) {
     for (int i = 0; i < n; ++i) for (int j = 0; j <= i; ++j) { double v = (double)((i * 131 + j * 71) % 97) / 97.0 - 0.5; A[(size_t)i * n + j] = v; A[(size_t)j * n + i] = v; }
     if (plfem_debug_symeig(n, A.data(), -1, w.data(), V.data())) return 1;
     if (plfem_debug_symeig(n, A.data(), n < 4 ? n : 4, w.data(), V.data())) return 1;
+    // band path (half bandwidth 4): eigenvalues + the vectors of the (up to) 22 largest |w|
+    const int rc = plfem_debug_symeig_band(n, 4, A.data(), n < 22 ? n : 22, w.data(), V.data());
+    if (rc != 0 && rc != PLFEM_ENOCONV) return 1;
   }
   printf("symeig ok\n");
   return 0;
