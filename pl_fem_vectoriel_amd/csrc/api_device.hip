@@ -179,15 +179,19 @@ int create_impl(plfem_ctx* c, const plfem_symbolic* sym, int device, void* strea
         else
           pos += (int64_t)ntx * nty;
       };
+      auto lower = [&](int f, int nt) {                  // blocks tx >= ty of an nt x nt square (symmetric trailing matrix)
+        if (out)
+          for (int ty = 0; ty < nt; ++ty)
+            for (int tx = ty; tx < nt; ++tx) out[pos++] = make_int2(f, tx | (ty << 16));
+        else
+          pos += (int64_t)nt * (nt + 1) / 2;
+      };
       for (int lev = 0; lev <= S.L; ++lev) {
         LevelInfo& li = c->levels[lev];
         const int32_t* o = forder.data() + li.first;
         li.gather_off = pos;
         if (lev < S.L)
-          for (int q = 0; q < li.count; ++q) {
-            const int nt = cdiv(fm[o[q]], 64);
-            rect(o[q], nt, nt);
-          }
+          for (int q = 0; q < li.count; ++q) lower(o[q], cdiv(fm[o[q]], 64));   // nothing reads the blocks above the diagonal
         li.gather_n = (int)(pos - li.gather_off);
         li.step0 = (int)c->upd_n.size();
         const int steps = (li.max_s2 + plfem::NB - 1) / plfem::NB;
@@ -199,7 +203,8 @@ int create_impl(plfem_ctx* c, const plfem_symbolic* sym, int device, void* strea
             const int t0 = k0 + std::min(plfem::NB, fs2[f] - k0);
             const int nt = cdiv(fm[f] - t0, 64);
             // even step of a front that has a next one: only the block column of its next pivot block (k_ldl_update<0>)
-            rect(f, nt, ((kb & 1) == 0 && t0 < fs2[f]) ? std::min(nt, 1) : nt);
+            if ((kb & 1) == 0 && t0 < fs2[f]) rect(f, nt, std::min(nt, 1));
+            else lower(f, nt);
           }
           c->upd_n.push_back((int)(pos - c->upd_off.back()));
         }

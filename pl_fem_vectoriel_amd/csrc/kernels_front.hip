@@ -113,8 +113,15 @@ __global__ __launch_bounds__(256) void k_front_gather(
   for (int jj = 0; jj < 16; ++jj) {
     const int cj = jj & 1, q = jj >> 1;
     double a = 0.0, b = 0.0;
-    if (c0i >= 0 && c0j[q] >= 0) a = F0[(int64_t)(s0 + 2 * c0j[q] + cj) * m0 + (s0 + 2 * c0i + ci)];
-    if (c1i >= 0 && c1j[q] >= 0) b = F1[(int64_t)(s1 + 2 * c1j[q] + cj) * m1 + (s1 + 2 * c1i + ci)];
+    // (row, column) = (larger, smaller) local index: only the lower triangle of a Schur complement is maintained
+    if (c0i >= 0 && c0j[q] >= 0) {
+      const int bi = s0 + 2 * c0i + ci, bj = s0 + 2 * c0j[q] + cj;
+      a = F0[(int64_t)min(bi, bj) * m0 + max(bi, bj)];
+    }
+    if (c1i >= 0 && c1j[q] >= 0) {
+      const int bi = s1 + 2 * c1i + ci, bj = s1 + 2 * c1j[q] + cj;
+      b = F1[(int64_t)min(bi, bj) * m1 + max(bi, bj)];
+    }
     v[jj] = a + b;
   }
 #pragma unroll
@@ -421,6 +428,10 @@ __global__ __launch_bounds__(256) void k_ldl_update(const int2* __restrict__ til
   const int i0 = t0 + ((job.y & 0xffff) * 2 + (wave & 1)) * 32;
   const int j0 = t0 + ((job.y >> 16) * 2 + (wave >> 1)) * 32;
   if (i0 >= m || j0 >= m) return;
+  // The trailing matrix is symmetric and every later reader takes its lower triangle (rows >= columns; pivot
+  // blocks are diagonal 32 x 32 blocks, panels lie below them, the extend-add swaps its indices), so the blocks
+  // strictly above the diagonal are never updated
+  if (i0 < j0) return;
   // MODE 0 and a next step exists: only the columns of its pivot block now (32, or 16 if it is the front's
   // last, partial block) -- everything to their right is updated once, by the rank-64 pass after that step
   const bool next_only = MODE == 0 && t0 < s2;
