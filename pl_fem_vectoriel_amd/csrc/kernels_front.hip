@@ -310,7 +310,7 @@ __device__ __forceinline__ void ldl_invrow_block(int bx, const int32_t* __restri
 }
 
 // Panel below the pivot block: Y = R X^T (= R L^-T), W = Y D^-1 (= the L panel).  Saves W, Y for the
-// update kernel and writes W into F (columns of the pivot block) and mirrored (rows).
+// update kernel and writes W into F (columns of the pivot block).
 __device__ __forceinline__ void ldl_panel_block(int bx, const int32_t* __restrict__ forder, int kb, const int32_t* __restrict__ fs2,
                                                 const int32_t* __restrict__ fm, const int64_t* __restrict__ foff,
                                                 const int64_t* __restrict__ fnode_ptr, double* __restrict__ front,
@@ -333,7 +333,6 @@ __device__ __forceinline__ void ldl_panel_block(int bx, const int32_t* __restric
   // B <- R^T (k = j, col i: the panel columns of F, contiguous in i); the accumulator register r of lane l is
   // Y[i = ibase + (l & 15)][c = 16 tc + (l >> 4) + 4 r]: 128-B runs of W, Y and of the panel columns of F.
   // One wave = 16 rows i x all 32 columns; every operand (24 loads) is requested before the first MFMA.
-  __shared__ double tr[4][NB][17];                     // per-wave transpose for the mirrored (row) copy of W
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int lr = lane & 15, lk = lane >> 4;
   const int ibase = i0 + 16 * wave;
@@ -371,19 +370,9 @@ __device__ __forceinline__ void ldl_panel_block(int bx, const int32_t* __restric
       W[(int64_t)c * m + i] = w;
       Y[(int64_t)c * m + i] = y;
       if (c < nbk) F[(int64_t)(k0 + c) * m + i] = w;
-      tr[wave][c][lr] = w;
     }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  // mirrored copy F[i][k0 + c]: lane = (row i = lane >> 2, 8 consecutive columns) -> 256-B runs per row
-  {
-    const int ri = lane >> 2, c0 = (lane & 3) * 8;
-    double* dst = F + (int64_t)(ibase + ri) * m + k0 + c0;
-#pragma unroll
-    for (int q = 0; q < 8; ++q)
-      if (c0 + q < nbk) dst[q] = tr[wave][c0 + q][ri];
-  }
+  // (no mirrored copy L^T in the rows of the pivot block: those entries are overwritten -- by the triangular-inverse
+  // update inside F11, by Z^T in F12 -- before anything reads them)
 }
 
 // The triangular-inverse update and the panel only depend on the pivot kernel, so one launch runs both:
