@@ -208,18 +208,24 @@ __global__ __launch_bounds__(64) void k_ldl_diag(const int32_t* __restrict__ for
 #pragma unroll
       for (int cc = 0; cc < 16; ++cc) srow[16 * h + cc] = v[cc];
     }
-    if (h == kh && i > k) srow[i] = colk / dk;
+    // 1 / dk by v_rcp_f64 + two Newton steps (full precision, not correctly rounded: ~1 ulp on a multiplier of an
+    // unpivoted LDL^T) -- the IEEE division sequence is 25 of the ~170 instructions of a pivot step, and this
+    // single wave is bound by instruction issue
+    double rdk = __builtin_amdgcn_rcp(dk);
+    rdk = fma(fma(-dk, rdk, 1.0), rdk, rdk);
+    rdk = fma(fma(-dk, rdk, 1.0), rdk, rdk);
+    if (h == kh && i > k) srow[i] = colk * rdk;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     const double li = (i > k) ? srow[i] : 0.0;
     const double t = li * dk;
+    // multiplier of column c = 16 h + cc: t where c > k, li where c <= k.  kc is a compile-time constant of the
+    // unrolled step, so per lane there are only two cases (cc > kc, cc <= kc): two selects instead of sixteen
+    const double m_hi = (h >= kh) ? t : li;
+    const double m_lo = (h > kh) ? t : li;
 #pragma unroll
-    for (int cc = 0; cc < 16; ++cc) {
-      const int c = 16 * h + cc;
-      const double src = srow[c];
-      v[cc] -= ((c > k) ? t : li) * src;
-    }
+    for (int cc = 0; cc < 16; ++cc) v[cc] -= ((cc > kc) ? m_hi : m_lo) * srow[16 * h + cc];
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
