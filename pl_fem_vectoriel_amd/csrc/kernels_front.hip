@@ -141,6 +141,14 @@ __global__ __launch_bounds__(256) void k_front_gather(
 // registers -- entry c is a[i][c] while c > k and x[i][c] once c <= k -- the pivot is broadcast with
 // v_readlane and row k of x / column k of L travel through one LDS row.  blockIdx.y >= 1: the other
 // waves save the block row L[k, <k] of L11 for the triangular-inverse update (tbuf), 64 columns each.
+// 1 / d by v_rcp_f64 + two Newton steps: full precision (~1 ulp, not correctly rounded), 5 instructions instead of
+// the ~25 of the IEEE division sequence; for finite, normal d (pivots are perturbed away from zero)
+__device__ __forceinline__ double fast_rcp(double d) {
+  double r = __builtin_amdgcn_rcp(d);
+  r = fma(fma(-d, r, 1.0), r, r);
+  return fma(fma(-d, r, 1.0), r, r);
+}
+
 __device__ __forceinline__ double readlane_f64(double v, int src) {
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
   const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
@@ -208,12 +216,9 @@ __global__ __launch_bounds__(64) void k_ldl_diag(const int32_t* __restrict__ for
 #pragma unroll
       for (int cc = 0; cc < 16; ++cc) srow[16 * h + cc] = v[cc];
     }
-    // 1 / dk by v_rcp_f64 + two Newton steps (full precision, not correctly rounded: ~1 ulp on a multiplier of an
-    // unpivoted LDL^T) -- the IEEE division sequence is 25 of the ~170 instructions of a pivot step, and this
-    // single wave is bound by instruction issue
-    double rdk = __builtin_amdgcn_rcp(dk);
-    rdk = fma(fma(-dk, rdk, 1.0), rdk, rdk);
-    rdk = fma(fma(-dk, rdk, 1.0), rdk, rdk);
+    // (fast_rcp: the IEEE division sequence is 25 of the ~170 instructions of a pivot step, and this single wave is
+    // bound by instruction issue)
+    const double rdk = fast_rcp(dk);
     if (h == kh && i > k) srow[i] = colk * rdk;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -358,7 +363,7 @@ __device__ __forceinline__ void ldl_panel_block(int bx, const int32_t* __restric
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int c = 16 * tc + lk + 4 * r;
-      di[tc][r] = (c < nbk) ? 1.0 / dl[c] : 0.0;
+      di[tc][r] = (c < nbk) ? fast_rcp(dl[c]) : 0.0;
     }
   v4d y0 = (v4d){0.0, 0.0, 0.0, 0.0}, y1 = (v4d){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
