@@ -124,9 +124,15 @@ def main():
     sync()
     for k in kprof:
         kprof[k] = 0
+    # per-step wall times and host phases (diagnostics only: a shared host shows up as outliers in "context")
+    step_ms, host_ms = [], []
     t0 = time.perf_counter()
     for it in range(args.steps):
+        ts = time.perf_counter()
         solver, modes = step(profile=(it == 0))
+        step_ms.append((time.perf_counter() - ts) * 1e3)
+        ls = solver.last_stats
+        host_ms.append((ls["t_symbolic"] * 1e3, ls["t_context"] * 1e3, ls.get("t_workspace", 0.0) * 1e3))
     sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -176,6 +182,9 @@ def main():
                              "copy_out": stats["t_copy_out"] * 1e3, "warm_step": warm_ms},
             "lanczos": {"n_opinv": stats["n_opinv"], "restarts": stats["restarts"], "nconv": stats["nconv"]},
             "raw_eigenpairs_per_s": world * args.steps * stats["n_req"] / elapsed,
+            "step_ms": [round(v, 2) for v in step_ms],
+            "host_ms_max": {"symbolic": round(max(h[0] for h in host_ms), 2), "context": round(max(h[1] for h in host_ms), 2),
+                            "workspace_alloc": round(max(h[2] for h in host_ms), 2)},
             "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:

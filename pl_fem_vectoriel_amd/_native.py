@@ -8,6 +8,7 @@ PyTorch is used only as the provider of device buffers and of the HIP stream.
 from __future__ import annotations
 
 import ctypes
+import time
 import os
 from typing import Optional
 
@@ -248,7 +249,9 @@ class Context:
         rc = lib.plfem_workspace_bytes(sym._h, int(max_ncv), ctypes.byref(need))
         if rc != PLFEM_OK:
             raise ValueError(f"plfem_workspace_bytes failed ({rc})")
+        t0 = time.perf_counter()
         self.workspace = torch.empty(int(need.value) + 256, dtype=torch.uint8, device=self.tdev)
+        self.t_workspace = time.perf_counter() - t0      # ~0 when the caching allocator recycles a block, ms for a hipMalloc
         base = self.workspace.data_ptr()
         aligned = (base + 255) & ~255
         rc = lib.plfem_create(sym._h, self.device, ctypes.c_void_p(stream), int(max_ncv), ctypes.c_void_p(aligned),

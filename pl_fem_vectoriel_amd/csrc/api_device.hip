@@ -6,7 +6,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <chrono>
+#include <mutex>
 #include <numeric>
+#include <vector>
 
 #include "device.h"
 #include "host_eig.h"
@@ -22,6 +24,41 @@ using plfem::Symbolic;
       return PLFEM_EHIP;                                                                     \
     }                                                                                        \
   } while (0)
+
+namespace {
+// Pinned host blocks outlive their context in a small process-wide cache: hipHostMalloc / hipHostFree pin and unpin
+// pages through the driver (syscalls with unbounded latency on a busy host), and cold solves create a context each.
+struct PinnedBlock { double* p; size_t bytes; };
+std::mutex& pinned_mutex() { static std::mutex* m = new std::mutex(); return *m; }
+std::vector<PinnedBlock>& pinned_cache() { static std::vector<PinnedBlock>* v = new std::vector<PinnedBlock>(); return *v; }
+
+hipError_t pinned_acquire(size_t bytes, double** out, size_t* got) {
+  {
+    std::lock_guard<std::mutex> lk(pinned_mutex());
+    auto& cache = pinned_cache();
+    int best = -1;
+    for (int i = 0; i < (int)cache.size(); ++i)
+      if (cache[i].bytes >= bytes && (best < 0 || cache[i].bytes < cache[best].bytes)) best = i;
+    if (best >= 0) {
+      *out = cache[best].p;
+      *got = cache[best].bytes;
+      cache.erase(cache.begin() + best);
+      return hipSuccess;
+    }
+  }
+  *got = bytes;
+  return hipHostMalloc((void**)out, bytes, hipHostMallocMapped | hipHostMallocCoherent | hipHostMallocPortable);
+}
+
+void pinned_release(double* p, size_t bytes) {
+  {
+    std::lock_guard<std::mutex> lk(pinned_mutex());
+    auto& cache = pinned_cache();
+    if (cache.size() < 8) { cache.push_back({p, bytes}); return; }
+  }
+  (void)hipHostFree(p);
+}
+}  // namespace
 
 namespace plfem {
 std::vector<hipEvent_t>& profile_event_pool() {
@@ -74,7 +111,7 @@ int check_launch(plfem_ctx* c, const char* what) {
 
 void free_all(plfem_ctx* c) {
   if (c->own_slab && c->slab) (void)hipFree(c->slab);
-  if (c->h_pinned) (void)hipHostFree(c->h_pinned);
+  if (c->h_pinned) pinned_release(c->h_pinned, c->h_pinned_bytes);
   for (auto& pr : c->ev)
     for (auto& e : pr)
       if (e) (void)hipEventDestroy(e);
@@ -303,7 +340,7 @@ int create_impl(plfem_ctx* c, const plfem_symbolic* sym, int device, void* strea
   {
     const size_t nc1p = (size_t)max_ncv + 2 + plfem::BLOCK_P;
     // [0, 8192): scalars / counters / core table; then the projected matrix (nc1p^2); then two block-step slots
-    HIP_TRY(c, hipHostMalloc((void**)&c->h_pinned, sizeof(double) * (8192 + nc1p * nc1p + 2 * nc1p * plfem::BLOCK_P), hipHostMallocMapped | hipHostMallocCoherent));
+    HIP_TRY(c, pinned_acquire(sizeof(double) * (8192 + nc1p * nc1p + 2 * nc1p * plfem::BLOCK_P), &c->h_pinned, &c->h_pinned_bytes));
     c->h_slots = c->h_pinned + 8192 + nc1p * nc1p;
   }
   HIP_TRY(c, hipEventRecord(c->ev[4][1], c->stream));

@@ -156,6 +156,7 @@ class TrueVectorialMaxwellSolver:
             t0 = time.perf_counter()
             ent["ctx"] = _native.Context(ent["sym"], self.device, max_ncv=max(max_ncv, 65))
             ent["t_context"] = time.perf_counter() - t0
+            ent["t_workspace"] = ent["ctx"].t_workspace
         return ent
 
     def _basis_size(self, k: int, n2: int) -> int:
@@ -264,6 +265,7 @@ class TrueVectorialMaxwellSolver:
                 "is_vectorial": True, "method": "H-field_V18.10"}))
         self.last_stats = dict(st, sigma=sigma, n_req=n_req, ncv=ncv, N=sym.N, N_solve=N_solve, n=2 * N_solve,
                                t_symbolic=ent.get("t_symbolic", 0.0), t_context=ent.get("t_context", 0.0),
+                               t_workspace=ent.get("t_workspace", 0.0),
                                t_device=t1 - t0, t_copy_out=t2 - t1, frac_core=frac_core, **timings)
         if not modes_raw:
             self.last_stats["t_total"] = time.perf_counter() - t_start
