@@ -8,6 +8,7 @@
 #include <chrono>
 #include <mutex>
 #include <numeric>
+#include <thread>
 #include <vector>
 
 #include "device.h"
@@ -85,12 +86,33 @@ int dalloc(plfem_ctx* c, T** dst, size_t count) {
   return PLFEM_OK;
 }
 
+// Host arrays of a context go up in ONE copy from a pinned staging block: the uploads are placed first in the slab,
+// upload() only records (slab offset, source, bytes), flush_uploads() fills the staging block (a few threads) and
+// issues the copy.  22 separate copies from pageable memory were pinned and unpinned by the runtime one by one.
+struct UploadItem { size_t off; const void* src; size_t bytes; };
+
 template <class T, class A>
-int upload(plfem_ctx* c, T** dst, const std::vector<T, A>& src) {
+int upload(plfem_ctx* c, std::vector<UploadItem>& items, T** dst, const std::vector<T, A>& src) {
+  const size_t off = c->slab_off;
   int rc = dalloc(c, dst, src.size());
   if (rc != PLFEM_OK) return rc;
-  if (c->slab && !src.empty())
-    HIP_TRY(c, hipMemcpyAsync(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice, c->stream));
+  if (c->slab && !src.empty()) items.push_back({off, src.data(), src.size() * sizeof(T)});
+  return PLFEM_OK;
+}
+
+// staging: pinned block of at least `span` bytes (the uploads occupy slab offsets [0, span))
+int flush_uploads(plfem_ctx* c, const std::vector<UploadItem>& items, size_t span, char* staging) {
+  size_t total = 0;
+  for (const auto& it : items) total += it.bytes;
+  const int nthreads = total > (4u << 20) ? 4 : 1;
+  auto work = [&](int t) {                          // thread t copies the items t, t + nthreads, ... (sizes are mixed)
+    for (size_t q = t; q < items.size(); q += nthreads) std::memcpy(staging + items[q].off, items[q].src, items[q].bytes);
+  };
+  std::vector<std::thread> th;
+  for (int t = 1; t < nthreads; ++t) th.emplace_back(work, t);
+  work(0);
+  for (auto& x : th) x.join();
+  HIP_TRY(c, hipMemcpyAsync(c->slab, staging, span, hipMemcpyHostToDevice, c->stream));
   return PLFEM_OK;
 }
 
@@ -112,6 +134,10 @@ int check_launch(plfem_ctx* c, const char* what) {
 void free_all(plfem_ctx* c) {
   if (c->own_slab && c->slab) (void)hipFree(c->slab);
   if (c->h_pinned) pinned_release(c->h_pinned, c->h_pinned_bytes);
+  if (c->h_staging) {
+    (void)hipStreamSynchronize(c->stream);              // (the upload out of the block has long completed)
+    pinned_release(c->h_staging, c->h_staging_bytes);
+  }
   for (auto& pr : c->ev)
     for (auto& e : pr)
       if (e) (void)hipEventDestroy(e);
@@ -254,32 +280,36 @@ int create_impl(plfem_ctx* c, const plfem_symbolic* sym, int device, void* strea
     if (size_only) tiles.resize((size_t)ntiles);          // only its size matters to the placement pass
   }
   const double tt1 = now_ms();
+  std::vector<UploadItem> items;
+  size_t upload_span = 0;
   auto place = [&]() -> int {
   c->slab_off = 0;
-  TRY(upload(c, &c->d_tsorted, S.tsorted));
-  TRY(upload(c, &c->d_blk, blk));
-  TRY(upload(c, &c->d_tiles, tiles));
-  TRY(upload(c, &c->d_forder, forder));
-  TRY(upload(c, &c->d_edof, S.edof));
-  TRY(upload(c, &c->d_rowptr, S.rowptr));
+  items.clear();
+  TRY(upload(c, items, &c->d_tsorted, S.tsorted));
+  TRY(upload(c, items, &c->d_blk, blk));
+  TRY(upload(c, items, &c->d_tiles, tiles));
+  TRY(upload(c, items, &c->d_forder, forder));
+  TRY(upload(c, items, &c->d_edof, S.edof));
+  TRY(upload(c, items, &c->d_rowptr, S.rowptr));
+  TRY(upload(c, items, &c->d_nptr, S.nptr));
+  TRY(upload(c, items, &c->d_nadj, S.nadj));
+  TRY(upload(c, items, &c->d_nloc, S.nloc));
+  TRY(upload(c, items, &c->d_interior, S.interior));
+  TRY(upload(c, items, &c->d_bmask, S.bmask));
+  TRY(upload(c, items, &c->d_doflocs, S.doflocs));
+  TRY(upload(c, items, &c->d_fs2, fs2));
+  TRY(upload(c, items, &c->d_fm, fm));
+  TRY(upload(c, items, &c->d_fnode_ptr, S.fnode_ptr));
+  TRY(upload(c, items, &c->d_foff, S.foff));
+  TRY(upload(c, items, &c->d_fnodes, S.fnodes));
+  TRY(upload(c, items, &c->d_cinv0, S.cinv0));
+  TRY(upload(c, items, &c->d_cinv1, S.cinv1));
+  TRY(upload(c, items, &c->d_epos, S.epos));
+  TRY(upload(c, items, &c->d_leaf_elem_ptr, S.leaf_elem_ptr));
+  TRY(upload(c, items, &c->d_leaf_elems, S.leaf_elems));
+  upload_span = c->slab_off;
   TRY(dalloc(c, &c->d_colind, (size_t)c->nnz));      // filled on the device by launch_pattern_fill below
   TRY(dalloc(c, &c->d_slot_row, (size_t)c->nnz));
-  TRY(upload(c, &c->d_nptr, S.nptr));
-  TRY(upload(c, &c->d_nadj, S.nadj));
-  TRY(upload(c, &c->d_nloc, S.nloc));
-  TRY(upload(c, &c->d_interior, S.interior));
-  TRY(upload(c, &c->d_bmask, S.bmask));
-  TRY(upload(c, &c->d_doflocs, S.doflocs));
-  TRY(upload(c, &c->d_fs2, fs2));
-  TRY(upload(c, &c->d_fm, fm));
-  TRY(upload(c, &c->d_fnode_ptr, S.fnode_ptr));
-  TRY(upload(c, &c->d_foff, S.foff));
-  TRY(upload(c, &c->d_fnodes, S.fnodes));
-  TRY(upload(c, &c->d_cinv0, S.cinv0));
-  TRY(upload(c, &c->d_cinv1, S.cinv1));
-  TRY(upload(c, &c->d_epos, S.epos));
-  TRY(upload(c, &c->d_leaf_elem_ptr, S.leaf_elem_ptr));
-  TRY(upload(c, &c->d_leaf_elems, S.leaf_elems));
   TRY(dalloc(c, &c->d_cores, 64 * 3));
   TRY(dalloc(c, &c->d_elem, (size_t)S.ne * plfem::ELEM_STRIDE));
   for (auto& p : c->d_vals) TRY(dalloc(c, &p, (size_t)c->nnz));
@@ -332,7 +362,13 @@ int create_impl(plfem_ctx* c, const plfem_symbolic* sym, int device, void* strea
   }
   c->slab_bytes = need;
   const double tt2 = now_ms();
-  TRY(place());                      // pass 1: place + upload
+  TRY(place());                      // pass 1: place, then one staged upload
+  double* staging = nullptr;
+  size_t staging_bytes = 0;
+  HIP_TRY(c, pinned_acquire(upload_span, &staging, &staging_bytes));
+  c->h_staging = staging;               // owned by the context from here on: released with it (free_all), so that
+  c->h_staging_bytes = staging_bytes;   // creation does not have to wait for the copy
+  TRY(flush_uploads(c, items, upload_span, reinterpret_cast<char*>(staging)));
   const double tt3 = now_ms();
   HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, 4 * sizeof(int32_t), c->stream));
   plfem::launch_pattern_fill(c);
@@ -345,7 +381,8 @@ int create_impl(plfem_ctx* c, const plfem_symbolic* sym, int device, void* strea
   }
   HIP_TRY(c, hipEventRecord(c->ev[4][1], c->stream));
   const double tt4 = now_ms();
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  // no synchronisation: the upload and the pattern kernel run on while the caller prepares the assembly (every
+  // later use of the context is ordered behind them on the stream)
   if (ctx_trace) fprintf(stderr, "[ctx] lists %.3f  size pass %.3f  upload pass %.3f  pinned+launch %.3f  sync %.3f ms\n", tt1 - tt0, tt2 - tt1, tt3 - tt2, tt4 - tt3, now_ms() - tt4);
   c->ev_used[4] = true;
   return PLFEM_OK;

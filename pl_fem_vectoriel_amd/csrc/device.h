@@ -92,6 +92,8 @@ struct plfem_ctx {
   int npartial = 0;
   double* h_pinned = nullptr;     // pinned staging
   size_t h_pinned_bytes = 0;      // size of that block (it returns to a process-wide cache)
+  double* h_staging = nullptr;    // pinned staging block of the one upload of the host arrays (same cache)
+  size_t h_staging_bytes = 0;
   double* h_slots = nullptr;      // pinned: new projected-matrix columns of the two block steps in flight
   char* slab = nullptr;           // the one device allocation every buffer above is carved from
   size_t slab_off = 0, slab_bytes = 0;
