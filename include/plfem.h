@@ -95,6 +95,9 @@ int plfem_mesh_refine(int32_t nv, int32_t ne, const double* p_host, const int32_
  * plfem_workspace_bytes(sym, max_ncv) bytes, e.g. a torch tensor so that torch's caching allocator
  * recycles it between contexts) out of which EVERY device buffer of the context is carved; NULL / 0 =
  * the library hipMalloc's one slab itself and frees it in plfem_destroy.
+ * plfem_create returns without synchronising: the one staged upload of the index structures (through a
+ * pinned block from a small process-wide cache) and the pattern kernel are still in flight on the stream,
+ * and every later call on the context is ordered behind them.  The symbolic handle must outlive the context.
  * ------------------------------------------------------------------------------------------- */
 int plfem_workspace_bytes(const plfem_symbolic* sym, int32_t max_ncv, int64_t* bytes);
 int plfem_create(const plfem_symbolic* sym, int32_t device, void* hip_stream, int32_t max_ncv,
