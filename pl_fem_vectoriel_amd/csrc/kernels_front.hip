@@ -15,6 +15,8 @@
 // was tried first and is unstable on meshes with sliver elements ("numerics").
 #include <algorithm>
 
+#include <type_traits>
+
 #include "device.h"
 
 namespace plfem {
@@ -280,22 +282,28 @@ __device__ __forceinline__ void ldl_invrow_block(int bx, const int32_t* __restri
   const int lr = lane & 15, lk = lane >> 4;
   const int c = c0 + lr;
   v4d t0 = (v4d){0.0, 0.0, 0.0, 0.0}, t1 = (v4d){0.0, 0.0, 0.0, 0.0};
-  // k0 - c0 is a multiple of 16: four k-steps (12 loads) are requested before their MFMAs
-  for (int j0 = c0; j0 < k0; j0 += 16) {
-    double a0[4], a1[4], b[4];
+  // k0 - c0 is a multiple of 16.  G groups of four k-steps (12 G loads) are requested before their MFMAs: two
+  // groups per trip while they last -- a long row (late steps of a large front) is a chain of memory round trips
+  // (four groups per trip measured the same)
+  auto groups = [&](int j0, auto G_) {
+    constexpr int G = decltype(G_)::value;
+    double a0[4 * G], a1[4 * G], b[4 * G];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
+    for (int t = 0; t < 4 * G; ++t) {
       const int j = j0 + 4 * t + lk;
       a0[t] = T[(int64_t)j * NB + lr];
       a1[t] = T[(int64_t)j * NB + 16 + lr];
       b[t] = (j >= c) ? F[(int64_t)j * m + c] : 0.0;            // X<k[j, c] (unit diagonal stored)
     }
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
+    for (int t = 0; t < 4 * G; ++t) {
       t0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[t], b[t], t0, 0, 0, 0);
       t1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[t], b[t], t1, 0, 0, 0);
     }
-  }
+  };
+  int j0 = c0;
+  for (; j0 + 16 < k0; j0 += 32) groups(j0, std::integral_constant<int, 2>());
+  if (j0 < k0) groups(j0, std::integral_constant<int, 1>());
   v4d x0 = (v4d){0.0, 0.0, 0.0, 0.0}, x1 = (v4d){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
   for (int kk = 0; kk < 8; ++kk) {
