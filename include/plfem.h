@@ -17,8 +17,9 @@
  *    x[0:N] = Hx DOFs, x[N:2N] = Hy DOFs, N = number of P2 DOFs including boundary DOFs, whose
  *    entries are kept at zero (Dirichlet H = 0, solver_fem.py:179-182);
  *  - all floating point data is IEEE double; indices are int32 (nnz < 2^31), offsets int64;
- *  - a plfem_ctx owns one HIP stream's worth of state; contexts are independent (no globals),
- *    one context must not be used from two threads at once.
+ *  - a plfem_ctx owns one HIP stream's worth of state; contexts are independent: the only process-wide
+ *    state is two mutex-protected recycling pools (pinned staging blocks, timing events), so different
+ *    contexts may be used from different threads; one context must not be used from two threads at once.
  */
 #ifndef PLFEM_H
 #define PLFEM_H
@@ -33,7 +34,7 @@ extern "C" {
 #define PLFEM_EINVAL (-1)   /* bad argument / inconsistent sizes            -> ValueError   */
 #define PLFEM_EMESH (-2)    /* malformed mesh                               -> ValueError   */
 #define PLFEM_EHIP (-3)     /* HIP runtime error (message has the call)     -> RuntimeError */
-#define PLFEM_ENOCONV (-4)  /* Lanczos did not converge within maxiter      -> ArpackNoConvergence-like */
+#define PLFEM_ENOCONV (-4)  /* Lanczos did not converge within maxiter      -> scipy ArpackNoConvergence */
 #define PLFEM_ESTATE (-5)   /* call order violated (e.g. solve before factor) -> RuntimeError */
 #define PLFEM_ESINGULAR (-6)/* factorisation broke down (sigma is an eigenvalue) -> RuntimeError */
 
@@ -90,7 +91,11 @@ int plfem_mesh_refine(int32_t nv, int32_t ne, const double* p_host, const int32_
  * Context: binds a symbolic analysis to a device and stream, uploads the index structures and
  * allocates every workspace (nothing is allocated later, so calls are graph-capturable).
  * hip_stream: a hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL = the default (null) stream.
- * max_ncv: largest Lanczos basis the context must hold.
+ * max_ncv: largest Lanczos basis the context must hold, 3 <= max_ncv <= PLFEM_MAX_NCV.
+ * Fails with PLFEM_EINVAL (message names the front order and the limit) when the largest front of the
+ * analysis does not fit the solve sweeps' LDS staging even for one right-hand side (8 (m + 1) bytes of the
+ * device's LDS per workgroup: ~20 000 DOFs on MI355X); between that and the limit for BLOCK_P = 4
+ * right-hand sides (~5 000 DOFs) the eigen-solve silently uses the single-vector recurrence.
  * workspace_dev / workspace_bytes: optional caller-owned device memory (256-byte aligned, at least
  * plfem_workspace_bytes(sym, max_ncv) bytes, e.g. a torch tensor so that torch's caching allocator
  * recycles it between contexts) out of which EVERY device buffer of the context is carved; NULL / 0 =
@@ -99,6 +104,7 @@ int plfem_mesh_refine(int32_t nv, int32_t ne, const double* p_host, const int32_
  * pinned block from a small process-wide cache) and the pattern kernel are still in flight on the stream,
  * and every later call on the context is ordered behind them.  The symbolic handle must outlive the context.
  * ------------------------------------------------------------------------------------------- */
+#define PLFEM_MAX_NCV 320
 int plfem_workspace_bytes(const plfem_symbolic* sym, int32_t max_ncv, int64_t* bytes);
 int plfem_create(const plfem_symbolic* sym, int32_t device, void* hip_stream, int32_t max_ncv,
                  void* workspace_dev, int64_t workspace_bytes, plfem_ctx** out, char* err, int32_t errlen);
@@ -139,9 +145,10 @@ int plfem_spmv(plfem_ctx* ctx, int32_t which, const double* x_dev, double* y_dev
  * Shift-invert operator.
  * Replaces: splu((A - sigma B).tocsc())   scipy arpack.py:915 (via reference solver_fem.py:197)
  *           lu.solve(rhs)                 scipy arpack.py:920-928
- * Multifrontal block Gauss-Jordan factorisation of the symmetric indefinite K = A_int - sigma B_int
- * on the nested-dissection front tree, all fronts dense in HBM; solve = two sweeps of batched
- * dense panel products over the tree levels.  refine_steps extra iterative-refinement passes.
+ * Multifrontal block LDL^T factorisation (static pivoting: vanishing pivots are perturbed and counted,
+ * plfem_timings()[5]) of the symmetric indefinite K = A_int - sigma B_int on the nested-dissection front
+ * tree, all fronts dense in HBM, the unit-triangular pivot blocks inverted explicitly; solve = two sweeps
+ * of batched dense panel products over the tree levels.  refine_steps extra iterative-refinement passes.
  * ------------------------------------------------------------------------------------------- */
 int plfem_factor(plfem_ctx* ctx, double sigma);
 int plfem_solve(plfem_ctx* ctx, const double* rhs_dev, double* x_dev, int32_t refine_steps);
@@ -156,8 +163,11 @@ int plfem_solve(plfem_ctx* ctx, const double* rhs_dev, double* x_dev, int32_t re
  * Requires plfem_assemble_hfield + plfem_factor(sigma) before the call.
  * evals_host[k]; evecs_dev[k][2N] (row c = vector c); stats_host[8] (may be NULL):
  *   [0] converged pairs, [1] OP applications, [2] restarts, [3] max relative Ritz residual.
- * Returns PLFEM_ENOCONV if fewer than k pairs converged after maxiter OP applications (outputs
- * still hold the current Ritz pairs, like ArpackNoConvergence.eigenvalues).
+ * stats_host[4] = passes over the factors (block solves; 0 = single-vector recurrence).
+ * Returns PLFEM_ENOCONV if fewer than k pairs converged after maxiter RESTARTS of the basis (ARPACK
+ * counts implicit restarts too: maxiter -> iparam[2] = mxiter, scipy arpack.py:358; outputs still hold the current Ritz pairs,
+ * like ArpackNoConvergence.eigenvalues).  With the option "refine_steps" > 0 (plfem_set_option) every
+ * OP application is followed by that many iterative-refinement passes r = Bx - K y, y += K^-1 r.
  * ------------------------------------------------------------------------------------------- */
 int plfem_lanczos_shift_invert(plfem_ctx* ctx, int32_t k, int32_t ncv, double tol, int32_t maxiter,
                                double sigma, double* evals_host, double* evecs_dev, double* stats_host);
@@ -178,21 +188,39 @@ enum { PLFEM_POST_NORM = 0, PLFEM_POST_DIV_ENERGY, PLFEM_POST_CORE_X, PLFEM_POST
 int plfem_postprocess(plfem_ctx* ctx, int32_t k, double* evecs_dev, const double* cores_host,
                       int32_t ncore, double* out_host, double* frac_core_host, double* modes_int_dev);
 
+/* ---------------------------------------------------------------------------------------------
+ * A-posteriori check of eigenpairs against the ASSEMBLED pencil (independent of the factorisation):
+ * out_host[i] = || A v_i - lambda_i B v_i ||_2 / || A v_i ||_2 for the k vectors evecs_dev[k][2N].
+ * No reference counterpart (eigsh trusts SuperLU's pivoting); here the LDL^T pivoting is static, so the
+ * Python host checks every solve with this and re-runs with refinement when the check fails.
+ * ------------------------------------------------------------------------------------------- */
+int plfem_residuals(plfem_ctx* ctx, int32_t k, const double* evals_host, const double* evecs_dev, double* out_host);
+
+/* Options by name: "refine_steps" (iterative-refinement passes inside every OP application of
+ * plfem_lanczos_shift_invert, default 0), "debug_perturb" (test hook: relative perturbation applied to
+ * the root front's D after every factorisation, default 0 = off).  PLFEM_EINVAL for unknown names. */
+int plfem_set_option(plfem_ctx* ctx, const char* name, double value);
+
 /* timings of the last calls in microseconds (HIP events on the context's stream):
  * [0] assemble, [1] factor, [2] lanczos, [3] postprocess, [4] upload; plus counters
  * [5] pivot perturbations in the last factorisation. */
 int plfem_timings(plfem_ctx* ctx, double* out_host /* [8] */);
 
 /* ---------------------------------------------------------------------------------------------
- * Live timing of the dominant kernel (bench.py "roofline"; no reference counterpart): between
- * begin and end every launch of the tile-form forward-sweep kernel (k_fwd, the largest single
- * consumer of GPU time in a solve) is bracketed by HIP events on the context's stream.
- * out_host[3] = { launches timed, total microseconds, total algorithmic bytes of those launches }
- * with algorithmic bytes of one launch = 8 B x sum over the level's fronts of
- * (s2 m - s2^2/2 + P (m + s2)): the entries of [L11^-1 ; Z] read once + P staged / written vectors.
+ * Live timing for bench.py's "roofline" object (no reference counterpart): between begin and end
+ * the ranges below are bracketed by HIP events on the context's stream.
+ * out_host[PLFEM_PROF_COUNT][3] = { ranges timed, total microseconds, total algorithmic bytes } per slot:
+ *   KFWD       every launch of the tile-form forward-sweep kernel (k_fwd, the largest single consumer
+ *              of GPU time in a solve); algorithmic bytes of one launch = 8 B x sum over the level's fronts
+ *              of (s2 m - s2^2/2 + P (m + s2)): the entries of [L11^-1 ; Z] read once + P staged / written vectors
+ *   FWD_SWEEP  one whole forward sweep (all levels), same formula summed over all fronts
+ *   BWD_SWEEP  one whole backward sweep
+ *   SPMV_B     the block product B X of a Lanczos step: 12 B x nnz (Minv values + column indices of the
+ *              shared pattern) + 4 B x (N + 1) row pointers + 2 x 8 B x P x 2N vector entries (read, written)
  * ------------------------------------------------------------------------------------------- */
-int plfem_profile_begin(plfem_ctx* ctx, int32_t max_launches);
-int plfem_profile_end(plfem_ctx* ctx, double* out_host /* [3] */);
+enum { PLFEM_PROF_KFWD = 0, PLFEM_PROF_FWD_SWEEP, PLFEM_PROF_BWD_SWEEP, PLFEM_PROF_SPMV_B, PLFEM_PROF_COUNT };
+int plfem_profile_begin(plfem_ctx* ctx, int32_t max_ranges);
+int plfem_profile_end(plfem_ctx* ctx, double* out_host /* [PLFEM_PROF_COUNT][3] */);
 
 /* ---------------------------------------------------------------------------------------------
  * Debugging aids for the test-suite (no reference counterpart): run the factorisation only up to

@@ -32,7 +32,10 @@ EXPORTS = (
     "plfem_solve", "plfem_lanczos_shift_invert", "plfem_postprocess", "plfem_timings",
     "plfem_debug_factor_until", "plfem_debug_copy", "plfem_profile_begin", "plfem_profile_end",
     "plfem_mesh_edge_count", "plfem_mesh_refine", "plfem_debug_symeig", "plfem_debug_symeig_band",
+    "plfem_residuals", "plfem_set_option",
 )
+MAX_NCV = 320                       # PLFEM_MAX_NCV of include/plfem.h
+PROF_SLOTS = ("k_fwd", "fwd_sweep", "bwd_sweep", "spmv_b")
 
 _ARRAY_DTYPES = {
     "edof": np.int32, "tsorted": np.int32, "edges": np.int32, "doflocs": np.float64, "bmask": np.uint8,
@@ -43,13 +46,17 @@ _ARRAY_DTYPES = {
 }
 
 
-class ArpackLikeNoConvergence(RuntimeError):
-    """Raised when the Lanczos iteration does not converge (mirrors ``ArpackNoConvergence``)."""
+from scipy.sparse.linalg import ArpackNoConvergence as _ArpackNoConvergence
+
+
+class ArpackLikeNoConvergence(_ArpackNoConvergence, RuntimeError):
+    """Raised when the Lanczos iteration does not converge.  The reference lets SciPy's
+    ``ArpackNoConvergence`` propagate out of ``eigsh`` (``solver_fem.py:197``), so this IS one: a caller's
+    ``except ArpackNoConvergence`` catches it, and ``.eigenvalues`` / ``.eigenvectors`` hold the current Ritz
+    pairs as SciPy's do (``.eigenvectors`` here is the device tensor, row c = vector c)."""
 
     def __init__(self, msg, eigenvalues=None, eigenvectors=None):
-        super().__init__(msg)
-        self.eigenvalues = eigenvalues
-        self.eigenvectors = eigenvectors
+        _ArpackNoConvergence.__init__(self, msg, eigenvalues, eigenvectors)
 
 
 _lib = None
@@ -109,6 +116,8 @@ def load_library() -> ctypes.CDLL:
                                       ctypes.c_void_p, ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int32]
     lib.plfem_profile_begin.argtypes = [ctypes.c_void_p, ctypes.c_int32]
     lib.plfem_profile_end.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    lib.plfem_residuals.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    lib.plfem_set_option.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_double]
     _lib = lib
     return lib
 
@@ -256,6 +265,8 @@ class Context:
         aligned = (base + 255) & ~255
         rc = lib.plfem_create(sym._h, self.device, ctypes.c_void_p(stream), int(max_ncv), ctypes.c_void_p(aligned),
                               ctypes.c_int64(int(need.value)), ctypes.byref(h), err, 512)
+        if rc in (PLFEM_EINVAL, PLFEM_EMESH):
+            raise ValueError(f"plfem_create: {err.value.decode()}")
         if rc != PLFEM_OK:
             raise RuntimeError(f"plfem_create failed ({rc}): {err.value.decode()}")
         self._h = h
@@ -350,9 +361,25 @@ class Context:
         self._check(self._lib.plfem_profile_begin(self._h, int(max_launches)), "plfem_profile_begin")
 
     def profile_end(self):
-        out = np.zeros(3, dtype=np.float64)
+        """Per slot of ``PROF_SLOTS``: ranges timed, their total HIP-event time and their algorithmic bytes.
+        The ``k_fwd`` slot is also returned flat (``launches`` / ``total_us`` / ``bytes``)."""
+        out = np.zeros((len(PROF_SLOTS), 3), dtype=np.float64)
         self._check(self._lib.plfem_profile_end(self._h, _ptr(out)), "plfem_profile_end")
-        return {"launches": int(out[0]), "total_us": float(out[1]), "bytes": float(out[2])}
+        res = {"launches": int(out[0, 0]), "total_us": float(out[0, 1]), "bytes": float(out[0, 2])}
+        res["slots"] = {name: {"ranges": int(out[i, 0]), "total_us": float(out[i, 1]), "bytes": float(out[i, 2])}
+                        for i, name in enumerate(PROF_SLOTS)}
+        return res
+
+    def residuals(self, evals, evecs) -> np.ndarray:
+        """``||A v_i - lambda_i B v_i|| / ||A v_i||`` against the assembled pencil (``plfem_residuals``)."""
+        lam = np.ascontiguousarray(np.asarray(evals, dtype=np.float64))
+        out = np.zeros(len(lam), dtype=np.float64)
+        self._check(self._lib.plfem_residuals(self._h, len(lam), _ptr(lam), ctypes.c_void_p(evecs.data_ptr()), _ptr(out)),
+                    "plfem_residuals")
+        return out
+
+    def set_option(self, name: str, value: float):
+        self._check(self._lib.plfem_set_option(self._h, name.encode(), float(value)), "plfem_set_option")
 
     def synchronize(self):
         self._check(self._lib.plfem_synchronize(self._h), "plfem_synchronize")

@@ -61,12 +61,26 @@ void pinned_release(double* p, size_t bytes) {
 }
 }  // namespace
 
-namespace plfem {
-std::vector<hipEvent_t>& profile_event_pool() {
-  static std::vector<hipEvent_t>* pool = new std::vector<hipEvent_t>();   // never destroyed: outlives every context
-  return *pool;
+namespace {
+// Process-wide pool of timing events for plfem_profile_*: contexts come and go in a cold-solve loop, the events
+// (a few hundred, ~10 us each to create) stay.  A profiling context TAKES the pool's events at profile_begin and
+// hands them back at profile_end, both under the mutex: two contexts profiling at once (sweep lanes) never share a
+// vector -- the second one simply creates its own events.
+std::mutex& event_mutex() { static std::mutex* m = new std::mutex(); return *m; }
+std::vector<hipEvent_t>& event_pool() { static std::vector<hipEvent_t>* v = new std::vector<hipEvent_t>(); return *v; }
+void events_take(std::vector<hipEvent_t>& mine) {
+  std::lock_guard<std::mutex> lk(event_mutex());
+  auto& pool = event_pool();
+  mine.insert(mine.end(), pool.begin(), pool.end());
+  pool.clear();
 }
-}  // namespace plfem
+void events_give(std::vector<hipEvent_t>& mine) {
+  std::lock_guard<std::mutex> lk(event_mutex());
+  auto& pool = event_pool();
+  pool.insert(pool.end(), mine.begin(), mine.end());
+  mine.clear();
+}
+}  // namespace
 
 namespace {
 
@@ -143,6 +157,7 @@ void free_all(plfem_ctx* c) {
       if (e) (void)hipEventDestroy(e);
   for (auto& e : c->ev_step)
     if (e) (void)hipEventDestroy(e);
+  if (!c->prof_ev.empty()) events_give(c->prof_ev);
 }
 
 static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
@@ -178,6 +193,24 @@ int create_impl(plfem_ctx* c, const plfem_symbolic* sym, int device, void* strea
       // or m (backward) vector entries and writes m (forward) or s2 (backward)
       li.sweep_bytes += 8.0 * ((double)fs2[f] * fm[f] - 0.5 * (double)fs2[f] * fs2[f] + fm[f] + fs2[f]);
       li.sweep_vec_doubles += fm[f] + fs2[f];
+    }
+  }
+  // The solve sweeps stage one front's right-hand sides in LDS: 8 P (max_m + 1) bytes dynamic + the static
+  // partial-sum buffer of the tile kernels (P x 4 KB backward, 8 waves).  Beyond the device limit the launch would
+  // fail as an opaque "invalid argument" much later, so decide here: P = BLOCK_P, else P = 1, else a clear error.
+  if (!size_only) {
+    int lim = 0;
+    HIP_TRY(c, hipDeviceGetAttribute(&lim, hipDeviceAttributeMaxSharedMemoryPerBlock, device));
+    c->lds_limit = lim;
+    int worst = 0;
+    for (const LevelInfo& li : c->levels) worst = std::max(worst, li.max_m);
+    auto need = [&](int P) { return (int64_t)sizeof(double) * P * (worst + 1) + (int64_t)sizeof(double) * 8 * P * 64; };
+    if (need(plfem::BLOCK_P) <= lim) c->max_block_p = plfem::BLOCK_P;
+    else if (need(1) <= lim) c->max_block_p = 1;
+    else {
+      c->err = "plfem_create: largest front has " + std::to_string(worst) + " DOFs; the solve sweeps stage 8 (m + 1) bytes of it in LDS, "
+               "which exceeds this device's " + std::to_string(lim) + " bytes per workgroup (use a smaller leaf size / a coarser mesh)";
+      return PLFEM_EINVAL;
     }
   }
   const bool ctx_trace = getenv("PLFEM_CTX_TRACE") != nullptr;
@@ -412,7 +445,7 @@ extern "C" int plfem_create(const plfem_symbolic* sym, int32_t device, void* hip
     return code;
   };
   if (!sym) return fail("plfem_create: null symbolic handle", PLFEM_EINVAL);
-  if (max_ncv < 3 || max_ncv > 160) return fail("plfem_create: max_ncv must be in [3, 160]", PLFEM_EINVAL);
+  if (max_ncv < 3 || max_ncv > PLFEM_MAX_NCV) return fail("plfem_create: max_ncv must be in [3, " + std::to_string(PLFEM_MAX_NCV) + "]", PLFEM_EINVAL);
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
     return fail("plfem_create: no HIP device available (this library has no CPU fallback)", PLFEM_EHIP);
@@ -430,7 +463,7 @@ extern "C" int plfem_create(const plfem_symbolic* sym, int32_t device, void* hip
 }
 
 extern "C" int plfem_workspace_bytes(const plfem_symbolic* sym, int32_t max_ncv, int64_t* bytes) {
-  if (!sym || !bytes || max_ncv < 3 || max_ncv > 160) return PLFEM_EINVAL;
+  if (!sym || !bytes || max_ncv < 3 || max_ncv > PLFEM_MAX_NCV) return PLFEM_EINVAL;
   plfem_ctx tmp;
   int rc = create_impl(&tmp, sym, 0, nullptr, max_ncv, nullptr, 0, true);
   *bytes = tmp.workspace_need;
@@ -498,6 +531,8 @@ extern "C" int plfem_factor(plfem_ctx* c, double sigma) {
   HIP_TRY(c, hipSetDevice(c->device));
   HIP_TRY(c, hipEventRecord(c->ev[1][0], c->stream));
   plfem::launch_factor(c, sigma);
+  if (c->debug_perturb != 0.0)   // test hook (plfem_set_option "debug_perturb"): a slightly wrong factor
+    plfem::launch_scale(c, (int64_t)2 * c->S->fs[0], 1.0 + c->debug_perturb, c->d_delta);
   HIP_TRY(c, hipEventRecord(c->ev[1][1], c->stream));
   c->ev_used[1] = true;
   TRY(check_launch(c, "factor"));
@@ -506,20 +541,47 @@ extern "C" int plfem_factor(plfem_ctx* c, double sigma) {
   return PLFEM_OK;
 }
 
+static void solve_refined(plfem_ctx* c, const double* b, double* y, int steps);
+
 extern "C" int plfem_solve(plfem_ctx* c, const double* rhs_dev, double* x_dev, int32_t refine_steps) {
   if (!c || !rhs_dev || !x_dev || refine_steps < 0) return PLFEM_EINVAL;
   if (!c->factored) { c->err = "plfem_solve before plfem_factor"; return PLFEM_ESTATE; }
-  plfem::launch_solve(c, rhs_dev, x_dev);
-  for (int it = 0; it < refine_steps; ++it) {
-    // r = rhs - (A - sigma B) x ; x += K^-1 r
-    plfem::launch_spmv(c, 0, x_dev, c->d_t1);
-    plfem::launch_spmv(c, 1, x_dev, c->d_t2);
-    plfem::launch_axpby(c, -1.0, c->d_t1, c->sigma, c->d_t2, c->d_t1);   // t1 = -A x + sigma B x
-    plfem::launch_axpby(c, 1.0, rhs_dev, 1.0, c->d_t1, c->d_t1);          // t1 = rhs + t1
-    plfem::launch_solve(c, c->d_t1, c->d_t2);
-    plfem::launch_axpby(c, 1.0, x_dev, 1.0, c->d_t2, x_dev);
-  }
+  solve_refined(c, rhs_dev, x_dev, refine_steps);
   return check_launch(c, "solve");
+}
+
+// y = K^-1 b followed by `steps` passes of iterative refinement against the ASSEMBLED K = A - sigma B:
+//   r = b - (A y - sigma B y),  y += K^-1 r.
+// Scratch: d_t1 / d_t2 (the sweeps of the single-vector solve do not use them).
+static void solve_refined(plfem_ctx* c, const double* b, double* y, int steps) {
+  plfem::launch_solve(c, b, y);
+  for (int it = 0; it < steps; ++it) {
+    plfem::launch_spmv(c, 0, y, c->d_t1);
+    plfem::launch_spmv(c, 1, y, c->d_t2);
+    plfem::launch_axpby(c, -1.0, c->d_t1, c->sigma, c->d_t2, c->d_t1);   // t1 = -A y + sigma B y
+    plfem::launch_axpby(c, 1.0, b, 1.0, c->d_t1, c->d_t1);               // t1 = b - K y
+    plfem::launch_solve(c, c->d_t1, c->d_t2);
+    plfem::launch_axpby(c, 1.0, y, 1.0, c->d_t2, y);
+  }
+}
+
+// the same for BLOCK_P columns (leading dimension n2, contiguous); scratch: the first 3 BLOCK_P columns of d_V2
+// (the restart double buffer, idle between restarts) -- launch_solve_block itself uses d_t1 / d_t2
+static void solve_block_refined(plfem_ctx* c, const double* b, double* y, bool b_interleaved_in_t1, int steps) {
+  constexpr int P = plfem::BLOCK_P;
+  const int64_t n = c->n2;
+  plfem::launch_solve_block(c, b, y, n, b_interleaved_in_t1);
+  double* ta = c->d_V2;
+  double* tb = c->d_V2 + (size_t)P * n;
+  double* dy = c->d_V2 + (size_t)2 * P * n;
+  for (int it = 0; it < steps; ++it) {
+    plfem::launch_spmv_a_block(c, y, ta, n);
+    plfem::launch_spmv_b_block(c, y, tb, n);
+    plfem::launch_axpby_n(c, n * P, -1.0, ta, c->sigma, tb, ta);          // ta = -A y + sigma B y
+    plfem::launch_axpby_n(c, n * P, 1.0, b, 1.0, ta, ta);                 // ta = b - K y
+    plfem::launch_solve_block(c, ta, dy, n, false);
+    plfem::launch_axpby_n(c, n * P, 1.0, y, 1.0, dy, y);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -542,7 +604,7 @@ static int lanczos_block(plfem_ctx* c, int k, int ncv, double tol, int maxiter, 
   {
     plfem::launch_start_field(c, P, c->d_V2);       // fixed pseudo-random interior block, generated on the device
     plfem::launch_spmv_b_block(c, c->d_V2, c->d_bw, n);
-    plfem::launch_solve_block(c, c->d_bw, c->d_w, n);
+    plfem::launch_solve_block(c, c->d_bw, c->d_w, n);      // (start block: any vector will do, no refinement)
     nop += P; ++nblock;
     plfem::launch_spmv_b_block(c, c->d_w, c->d_bw, n);
     plfem::launch_panel_dot_block(c, c->d_w, P, c->d_bw, n, c->d_G, P);
@@ -571,13 +633,17 @@ static int lanczos_block(plfem_ctx* c, int k, int ncv, double tol, int maxiter, 
   auto launch_step = [&](int c0_, int slot) -> int {
     const int nc = c0_ + P;
     const int lo = (c0_ == cycle_start) ? 0 : std::max(0, nc - 2 * P);
-    plfem::launch_solve_block(c, c->d_BV + (size_t)c0_ * n, c->d_w, n, il_ready == c0_);      // W = OP V_j
+    solve_block_refined(c, c->d_BV + (size_t)c0_ * n, c->d_w, il_ready == c0_, c->refine_steps);   // W = OP V_j
     double* Hblk = c->d_Hcols + (size_t)c0_ * ld;                             // T[0:nc, c0:c0+P] (zero before the step)
     plfem::launch_panel_dot_block(c, c->d_BV + (size_t)lo * n, nc - lo, c->d_w, n, Hblk + lo, ld);
     plfem::launch_panel_axpy_block(c, c->d_V + (size_t)lo * n, nc - lo, Hblk + lo, ld, c->d_w, n);
     plfem::launch_panel_dot_block(c, c->d_BV, nc, c->d_w, n, c->d_hblk, ld, Hblk, ld);  // second pass, T += h2
     plfem::launch_panel_axpy_block(c, c->d_V, nc, c->d_hblk, ld, c->d_w, n);
-    plfem::launch_spmv_b_block(c, c->d_w, c->d_bw, n);
+    {
+      const int pid = plfem::prof_open(c, PLFEM_PROF_SPMV_B, 12.0 * c->nnz + 4.0 * (c->N + 1) + 2.0 * 8.0 * P * (double)n);
+      plfem::launch_spmv_b_block(c, c->d_w, c->d_bw, n);
+      plfem::prof_close(c, pid);
+    }
     plfem::launch_gram_chol_block(c, c->d_w, c->d_bw, n, Hblk + nc, ld, c->d_Rinv);   // W^T B W = R^T R, R -> T[nc:nc+P, c0:c0+P]
     // the last kernel of the step also stores the new columns and the counters into the pinned slot (no copies)
     plfem::launch_block_scale(c, c->d_w, c->d_bw, n, c->d_Rinv, c->d_V + (size_t)nc * n, c->d_BV + (size_t)nc * n, n,
@@ -786,7 +852,7 @@ extern "C" int plfem_lanczos_shift_invert(plfem_ctx* c, int32_t k, int32_t ncv, 
     const bool allow = !(env && env[0] == '0');
     int mblk = ((ncv + plfem::BLOCK_P - 1) / plfem::BLOCK_P) * plfem::BLOCK_P;
     if (mblk > c->max_ncv) mblk = (c->max_ncv / plfem::BLOCK_P) * plfem::BLOCK_P;   // round down instead
-    if (allow && k >= plfem::BLOCK_P && mblk >= k + 3 * plfem::BLOCK_P &&
+    if (allow && c->max_block_p >= plfem::BLOCK_P && k >= plfem::BLOCK_P && mblk >= k + 3 * plfem::BLOCK_P &&
         2 * (int64_t)c->nsolve >= 16 * (int64_t)(mblk + plfem::BLOCK_P))
       return lanczos_block(c, k, ncv, tol, maxiter, sigma, evals_host, evecs_dev, stats_host);
   }
@@ -820,7 +886,7 @@ extern "C" int plfem_lanczos_shift_invert(plfem_ctx* c, int32_t k, int32_t ncv, 
     for (int j = j0; j < m; ++j) {
       double* Vj1 = c->d_V + (size_t)(j + 1) * n;
       double* BVj1 = c->d_BV + (size_t)(j + 1) * n;
-      plfem::launch_solve(c, c->d_BV + (size_t)j * n, c->d_w);          // w = OP v_j = K^-1 B v_j
+      solve_refined(c, c->d_BV + (size_t)j * n, c->d_w, c->refine_steps);   // w = OP v_j = K^-1 B v_j
       ++nop;
       double* hcol = c->d_Hcols + (size_t)j * ld;
       plfem::launch_panel_dot(c, c->d_BV, j + 1, c->d_w, hcol);          // h = V^T B w
@@ -976,13 +1042,14 @@ extern "C" int plfem_debug_copy(plfem_ctx* c, const char* name, int64_t offset, 
 }
 
 // ---- live kernel timing for bench.py's roofline object -------------------------------------------
-extern "C" int plfem_profile_begin(plfem_ctx* c, int32_t max_launches) {
-  if (!c || max_launches < 1) return PLFEM_EINVAL;
+extern "C" int plfem_profile_begin(plfem_ctx* c, int32_t max_ranges) {
+  if (!c || max_ranges < 1) return PLFEM_EINVAL;
   HIP_TRY(c, hipSetDevice(c->device));
-  c->prof_max = max_launches;                        // event pairs are created on demand at the launch site
-  c->prof_ev = &plfem::profile_event_pool();
+  c->prof_max = max_ranges;                          // event pairs are created on demand at the launch site
+  if (c->prof_ev.empty()) events_take(c->prof_ev);
   c->prof_n = 0;
-  c->prof_bytes = 0;
+  c->prof_slot.clear();
+  c->prof_rbytes.clear();
   c->prof_on = true;
   return PLFEM_OK;
 }
@@ -991,14 +1058,40 @@ extern "C" int plfem_profile_end(plfem_ctx* c, double* out_host) {
   if (!c || !out_host) return PLFEM_EINVAL;
   c->prof_on = false;
   HIP_TRY(c, hipStreamSynchronize(c->stream));
-  double total_us = 0;
+  for (int q = 0; q < 3 * PLFEM_PROF_COUNT; ++q) out_host[q] = 0.0;
   for (int q = 0; q < c->prof_n; ++q) {
     float ms = 0;
-    HIP_TRY(c, hipEventElapsedTime(&ms, (*c->prof_ev)[2 * q], (*c->prof_ev)[2 * q + 1]));
-    total_us += ms * 1e3;
+    HIP_TRY(c, hipEventElapsedTime(&ms, c->prof_ev[2 * q], c->prof_ev[2 * q + 1]));
+    double* o = out_host + 3 * c->prof_slot[q];
+    o[0] += 1.0;
+    o[1] += ms * 1e3;
+    o[2] += c->prof_rbytes[q];
   }
-  out_host[0] = c->prof_n;
-  out_host[1] = total_us;
-  out_host[2] = c->prof_bytes;
+  events_give(c->prof_ev);
+  return PLFEM_OK;
+}
+
+// ---- a-posteriori residuals, options ---------------------------------------------------------------
+extern "C" int plfem_residuals(plfem_ctx* c, int32_t k, const double* evals_host, const double* evecs_dev, double* out_host) {
+  if (!c || !evals_host || !evecs_dev || !out_host || k < 1 || k > c->max_ncv) return PLFEM_EINVAL;
+  if (!c->assembled) { c->err = "plfem_residuals before plfem_assemble_hfield"; return PLFEM_ESTATE; }
+  HIP_TRY(c, hipSetDevice(c->device));
+  plfem::launch_residuals(c, k, evals_host, evecs_dev, out_host);
+  return check_launch(c, "residuals");
+}
+
+extern "C" int plfem_set_option(plfem_ctx* c, const char* name, double value) {
+  if (!c || !name) return PLFEM_EINVAL;
+  const std::string n(name);
+  if (n == "refine_steps") {
+    if (value < 0 || value > 8) { c->err = "refine_steps must be in [0, 8]"; return PLFEM_EINVAL; }
+    c->refine_steps = (int)value;
+  } else if (n == "debug_perturb") {
+    c->debug_perturb = value;
+    c->factored = false;              // takes effect at the next plfem_factor
+  } else {
+    c->err = "plfem_set_option: unknown option '" + n + "'";
+    return PLFEM_EINVAL;
+  }
   return PLFEM_OK;
 }

@@ -106,7 +106,14 @@ struct plfem_ctx {
   bool prof_on = false;
   int prof_n = 0, prof_max = 0;
   double prof_bytes = 0;
-  std::vector<hipEvent_t>* prof_ev = nullptr;   // process-wide pool (profile_event_pool), reused by successive contexts
+  std::vector<hipEvent_t> prof_ev;   // taken from the process-wide pool at profile_begin, handed back at profile_end
+  std::vector<int> prof_slot;        // PLFEM_PROF_* of every timed range
+  std::vector<double> prof_rbytes;   // algorithmic bytes of every timed range
+  // options (plfem_set_option)
+  int refine_steps = 0;           // iterative-refinement passes inside every OP application of the Lanczos drivers
+  double debug_perturb = 0.0;     // test hook: relative perturbation of the root front's D after every factorisation
+  int max_block_p = plfem::BLOCK_P;   // right-hand sides per sweep the LDS budget allows (BLOCK_P or 1)
+  int lds_limit = 0;              // bytes of LDS one workgroup may use on this device
   double sigma = 0.0, k0 = 0.0;
   hipEvent_t ev[5][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
   bool ev_used[5] = {false, false, false, false, false};
@@ -115,15 +122,33 @@ struct plfem_ctx {
 
 namespace plfem {
 
+// live timing (plfem_profile_*): a timed range = two HIP events on the context's stream around one or more launches
+inline int prof_open(plfem_ctx* c, int slot, double bytes) {
+  if (!c->prof_on || c->prof_n >= c->prof_max) return -1;
+  while ((int)c->prof_ev.size() < 2 * (c->prof_n + 1)) {
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return -1;
+    c->prof_ev.push_back(e);
+  }
+  const int id = c->prof_n++;
+  c->prof_slot.push_back(slot);
+  c->prof_rbytes.push_back(bytes);
+  (void)hipEventRecord(c->prof_ev[2 * id], c->stream);
+  return id;
+}
+inline void prof_close(plfem_ctx* c, int id) {
+  if (id >= 0) (void)hipEventRecord(c->prof_ev[2 * id + 1], c->stream);
+}
+
 // kernels_assembly.hip
 void launch_element_matrices(plfem_ctx* c, int ncore, double eps_core, double eps_clad, double k0, double alpha_p);
 void launch_csr_gather(plfem_ctx* c);
 void launch_pattern_fill(plfem_ctx* c);   // colind / slot_row from the node -> element adjacency (once per context)
 void launch_spmv(plfem_ctx* c, int which, const double* x, double* y);
 void launch_spmv_b_block(plfem_ctx* c, const double* x, double* y, int64_t ld);   // y_q = B x_q, BLOCK_P vectors
-// process-wide pool of timing events for plfem_profile_*: contexts come and go in a cold-solve loop, the events
-// (a few hundred, ~10 us each to create) stay
-std::vector<hipEvent_t>& profile_event_pool();
+void launch_spmv_a_block(plfem_ctx* c, const double* x, double* y, int64_t ld);   // y_q = A x_q, BLOCK_P vectors
+// out_host[i] = ||A v_i - lambda_i B v_i|| / ||A v_i||  (k vectors, row i of evecs; synchronises)
+void launch_residuals(plfem_ctx* c, int k, const double* lam_host, const double* evecs, double* out_host);
 // kernels_front.hip
 void launch_factor(plfem_ctx* c, double sigma, int stop_level = -1, int stop_step = 0, int stop_stage = 0);
 void launch_solve(plfem_ctx* c, const double* rhs, double* x);
@@ -136,6 +161,8 @@ void launch_vec_add(plfem_ctx* c, double* acc, const double* h, int n);         
 void launch_scale_store(plfem_ctx* c, const double* w, const double* bw, const double* beta2, double* v, double* bv,
                         double* beta_out);  // v = w/sqrt(beta2), bv = bw/sqrt(beta2)
 void launch_axpby(plfem_ctx* c, double a, const double* x, double b, const double* y, double* z);  // z = a x + b y
+void launch_axpby_n(plfem_ctx* c, int64_t n, double a, const double* x, double b, const double* y, double* z);
+void launch_scale(plfem_ctx* c, int64_t n, double a, double* x);   // x *= a
 void launch_rotate(plfem_ctx* c, const double* V, int m, const double* Smat, int ldS, int p, double* out);  // out = V[:, :m] S
 // block (BLOCK_P vectors) variants; H matrices are column major with leading dimension ldh
 // h = Pm^T W (ncols x BLOCK_P); hacc (optional) += the same coefficients

@@ -330,7 +330,57 @@ __global__ __launch_bounds__(256) void k_spmv_b_block(int N, int64_t ld, const i
   }
 }
 
+// y_q = A_int x_q for the P vectors of a block (iterative refinement of the block Lanczos operator)
+template <int P>
+__global__ __launch_bounds__(256) void k_spmv_a_block(int N, int64_t ld, const int32_t* __restrict__ rowptr,
+                                                      const int32_t* __restrict__ colind, const uint8_t* __restrict__ bmask,
+                                                      const double* __restrict__ vxx, const double* __restrict__ vxy,
+                                                      const double* __restrict__ vyx, const double* __restrict__ vyy,
+                                                      const double* __restrict__ x, double* __restrict__ y) {
+  int gt = blockIdx.x * blockDim.x + threadIdx.x;
+  int row = gt >> 3, sub = gt & 7;
+  double sx[P], sy[P];
+#pragma unroll
+  for (int q = 0; q < P; ++q) { sx[q] = 0.0; sy[q] = 0.0; }
+  if (row < N && !bmask[row]) {
+    int q0 = rowptr[row], q1 = rowptr[row + 1];
+    for (int k = q0 + sub; k < q1; k += 8) {
+      const int c = colind[k];
+      const double axx = vxx[k], axy = vxy[k], ayx = vyx[k], ayy = vyy[k];
+#pragma unroll
+      for (int q = 0; q < P; ++q) {
+        const double xx = x[(int64_t)q * ld + c], xy = x[(int64_t)q * ld + N + c];
+        sx[q] += axx * xx + axy * xy;
+        sy[q] += ayx * xx + ayy * xy;
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < P; ++q) {
+#pragma unroll
+    for (int off = 4; off >= 1; off >>= 1) {
+      sx[q] += __shfl_xor(sx[q], off, 8);
+      sy[q] += __shfl_xor(sy[q], off, 8);
+    }
+  }
+  if (row < N && sub == 0) {
+#pragma unroll
+    for (int q = 0; q < P; ++q) {
+      y[(int64_t)q * ld + row] = sx[q];
+      y[(int64_t)q * ld + N + row] = sy[q];
+    }
+  }
+}
+
 }  // namespace
+
+void launch_spmv_a_block(plfem_ctx* c, const double* x, double* y, int64_t ld) {
+  int64_t threads = (int64_t)c->N * 8;
+  int grid = (int)((threads + 255) / 256);
+  hipLaunchKernelGGL(k_spmv_a_block<BLOCK_P>, dim3(grid), dim3(256), 0, c->stream, c->N, ld, c->d_rowptr, c->d_colind,
+                     c->d_bmask, c->d_vals[PLFEM_BLK_AXX], c->d_vals[PLFEM_BLK_AXY], c->d_vals[PLFEM_BLK_AYX],
+                     c->d_vals[PLFEM_BLK_AYY], x, y);
+}
 
 void launch_element_matrices(plfem_ctx* c, int ncore, double eps_core, double eps_clad, double k0, double alpha_p) {
   int grid = (c->ne + EPB - 1) / EPB;

@@ -1022,6 +1022,9 @@ static void launch_solve_p(plfem_ctx* c, const double* rhs, double* x, int64_t l
   // lists of the context (no empty workgroups, large fronts first).  Measured at C1 (P = 4): 4 waves per block in
   // the forward tile kernel, 8 in every backward form, 2 rows per wave at the mid levels
   // (scripts/gpu_trace_levels.sh prints the per-level table).
+  double sweep_total = 0.0;                     // algorithmic bytes of one whole sweep (either direction)
+  for (const LevelInfo& li : c->levels) sweep_total += li.sweep_bytes + 8.0 * (P - 1) * li.sweep_vec_doubles;
+  const int pid_fwd = prof_open(c, PLFEM_PROF_FWD_SWEEP, sweep_total);
   for (int lev = c->L; lev >= 0; --lev) {
     const LevelInfo& li = c->levels[lev];
     const int leaf = lev == c->L ? 1 : 0;
@@ -1038,23 +1041,15 @@ static void launch_solve_p(plfem_ctx* c, const double* rhs, double* x, int64_t l
                          c->d_delta, rhs, c->d_fvec, c->d_fvec2);
     else {
       // optional live timing of this kernel (bench.py roofline): HIP events on the launch stream
-      bool timed = c->prof_on && c->prof_n < c->prof_max;
-      while (timed && (int)c->prof_ev->size() < 2 * (c->prof_n + 1)) {
-        hipEvent_t e;
-        if (hipEventCreate(&e) != hipSuccess) { timed = false; break; }
-        c->prof_ev->push_back(e);
-      }
-      if (timed) (void)hipEventRecord((*c->prof_ev)[2 * c->prof_n], st);
+      const int pid = prof_open(c, PLFEM_PROF_KFWD, li.sweep_bytes + 8.0 * (P - 1) * li.sweep_vec_doubles);
       hipLaunchKernelGGL((k_fwd<P, 4>), dim3(li.fwd_n), dim3(256), lds, st, blk, c->N, ldx, leaf,
                          c->d_fs2, c->d_fm, c->d_foff, c->d_fnode_ptr, c->d_fnodes, c->d_cinv0, c->d_cinv1, c->d_front,
                          c->d_delta, rhs, c->d_fvec, c->d_fvec2);
-      if (timed) {
-        (void)hipEventRecord((*c->prof_ev)[2 * c->prof_n + 1], st);
-        c->prof_bytes += li.sweep_bytes + 8.0 * (P - 1) * li.sweep_vec_doubles;
-        ++c->prof_n;
-      }
+      prof_close(c, pid);
     }
   }
+  prof_close(c, pid_fwd);
+  const int pid_bwd = prof_open(c, PLFEM_PROF_BWD_SWEEP, sweep_total);
   for (int lev = 0; lev <= c->L; ++lev) {
     const LevelInfo& li = c->levels[lev];
     if (li.bwd_n == 0) continue;
@@ -1070,6 +1065,7 @@ static void launch_solve_p(plfem_ctx* c, const double* rhs, double* x, int64_t l
       hipLaunchKernelGGL((k_bwd_rows<P, 8, 2>), dim3(li.bwd_n), dim3(512), lds, st, blk, c->N, ldx,
                          c->d_fs2, c->d_fm, c->d_foff, c->d_fnode_ptr, c->d_fnodes, c->d_front, c->d_fvec2, x);
   }
+  prof_close(c, pid_bwd);
 }
 
 void launch_solve(plfem_ctx* c, const double* rhs, double* x) { launch_solve_p<1>(c, rhs, x, c->n2); }

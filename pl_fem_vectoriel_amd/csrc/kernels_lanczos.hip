@@ -5,6 +5,9 @@
 // Replaces the re-orthogonalisation / Ritz-vector work ARPACK does inside dsaupd / dseupd
 // (scipy arpack.py:542-602, reached from reference solver_fem.py:197) and the per-mode loop of
 // reference solver_fem.py:200-225.
+#include <algorithm>
+#include <cmath>
+
 #include "device.h"
 
 namespace plfem {
@@ -42,7 +45,7 @@ __global__ __launch_bounds__(64) void k_panel_dot_finish(int ncols, int nchunks,
 // w[i] -= sum_c P[i, c] h[c]
 __global__ __launch_bounds__(256) void k_panel_axpy(int64_t n, int ncols, const double* __restrict__ P,
                                                     const double* __restrict__ h, double* __restrict__ w) {
-  __shared__ double sh[192];
+  __shared__ double sh[PLFEM_MAX_NCV + 8];
   for (int c = threadIdx.x; c < ncols; c += 256) sh[c] = h[c];
   __syncthreads();
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -76,6 +79,11 @@ __global__ __launch_bounds__(256) void k_axpby(int64_t n, double a, const double
                                                const double* __restrict__ y, double* __restrict__ z) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i < n) z[i] = a * x[i] + b * y[i];
+}
+
+__global__ __launch_bounds__(256) void k_scale(int64_t n, double a, double* __restrict__ x) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) x[i] *= a;
 }
 
 // ---- block (P-vector) variants for block Lanczos --------------------------------------------------
@@ -405,7 +413,93 @@ __global__ __launch_bounds__(256) void k_gather_interior(int N, int nsolve, cons
   modes_int[(int64_t)mode * 2 * nsolve + i] = evecs[(int64_t)mode * 2 * N + (int64_t)comp * N + interior[q]];
 }
 
+// ---- a-posteriori residuals: per (row chunk, vector) partial sums [0] sum |A v - lambda B v|^2, [1] sum |A v|^2
+// over the interior rows; 8 lanes per scalar row, both field components in one pass over the shared pattern.
+__global__ __launch_bounds__(256) void k_resid_sums(int N, int nblocks, const int32_t* __restrict__ rowptr,
+                                                    const int32_t* __restrict__ colind, const uint8_t* __restrict__ bmask,
+                                                    const double* __restrict__ vxx, const double* __restrict__ vxy,
+                                                    const double* __restrict__ vyx, const double* __restrict__ vyy,
+                                                    const double* __restrict__ vm, const double* __restrict__ lam,
+                                                    const double* __restrict__ evecs, double* __restrict__ partial) {
+  const int mode = blockIdx.y;
+  const double* vx = evecs + (int64_t)mode * 2 * N;
+  const double* vy = vx + N;
+  const double l = lam[mode];
+  __shared__ double red[4][2];
+  double r2 = 0.0, a2 = 0.0;
+  const int sub = threadIdx.x & 7;
+  for (int rr = threadIdx.x >> 3; rr < POST_ROWS; rr += 32) {
+    const int row = blockIdx.x * POST_ROWS + rr;
+    if (row >= N) break;
+    if (bmask[row]) continue;
+    double ax = 0, ay = 0, bx = 0, by = 0;
+    const int q1 = rowptr[row + 1];
+    for (int q = rowptr[row] + sub; q < q1; q += 8) {
+      const int c = colind[q];
+      const double ux = vx[c], uy = vy[c], m = vm[q];
+      ax += vxx[q] * ux + vxy[q] * uy;
+      ay += vyx[q] * ux + vyy[q] * uy;
+      bx += m * ux;
+      by += m * uy;
+    }
+#pragma unroll
+    for (int off = 4; off >= 1; off >>= 1) {
+      ax += __shfl_xor(ax, off, 8); ay += __shfl_xor(ay, off, 8);
+      bx += __shfl_xor(bx, off, 8); by += __shfl_xor(by, off, 8);
+    }
+    if (sub == 0) {
+      const double rx = ax - l * bx, ry = ay - l * by;
+      r2 += rx * rx + ry * ry;
+      a2 += ax * ax + ay * ay;
+    }
+  }
+  for (int off = 32; off >= 1; off >>= 1) { r2 += __shfl_xor(r2, off); a2 += __shfl_xor(a2, off); }
+  if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][0] = r2; red[threadIdx.x >> 6][1] = a2; }
+  __syncthreads();
+  if (threadIdx.x < 2)
+    partial[((int64_t)mode * nblocks + blockIdx.x) * 2 + threadIdx.x] =
+        red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+__global__ __launch_bounds__(64) void k_resid_finish(int nblocks, const double* __restrict__ partial, double* __restrict__ out) {
+  const int t = blockIdx.x;             // mode * 2 + q
+  const int mode = t >> 1, q = t & 1;
+  double acc = 0.0;
+  for (int b = threadIdx.x; b < nblocks; b += 64) acc += partial[((int64_t)mode * nblocks + b) * 2 + q];
+  for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
+  if (threadIdx.x == 0) out[t] = acc;
+}
+
 }  // namespace
+
+void launch_residuals(plfem_ctx* c, int k, const double* lam_host, const double* evecs, double* out_host) {
+  hipStream_t st = c->stream;
+  const int N = c->N;
+  const int nblocks = (N + POST_ROWS - 1) / POST_ROWS;
+  double* hs = c->h_pinned;                          // [0, k): lambda up, [k, 3k): sums down
+  for (int i = 0; i < k; ++i) hs[i] = lam_host[i];
+  (void)hipMemcpyAsync(c->d_hacc, hs, sizeof(double) * k, hipMemcpyHostToDevice, st);
+  double* partial = c->d_post;                       // [k][nblocks][2]
+  double* sums = c->d_post + (int64_t)k * nblocks * 2;
+  hipLaunchKernelGGL(k_resid_sums, dim3(nblocks, k), dim3(256), 0, st, N, nblocks, c->d_rowptr, c->d_colind, c->d_bmask,
+                     c->d_vals[PLFEM_BLK_AXX], c->d_vals[PLFEM_BLK_AXY], c->d_vals[PLFEM_BLK_AYX], c->d_vals[PLFEM_BLK_AYY],
+                     c->d_vals[PLFEM_BLK_MINV], c->d_hacc, evecs, partial);
+  hipLaunchKernelGGL(k_resid_finish, dim3(2 * k), dim3(64), 0, st, nblocks, partial, sums);
+  (void)hipMemcpyAsync(hs + k, sums, sizeof(double) * 2 * k, hipMemcpyDeviceToHost, st);
+  (void)hipStreamSynchronize(st);
+  for (int i = 0; i < k; ++i) {
+    const double r2 = hs[k + 2 * i], a2 = hs[k + 2 * i + 1];
+    out_host[i] = a2 > 0.0 ? std::sqrt(r2 / a2) : (r2 > 0.0 ? INFINITY : 0.0);
+  }
+}
+
+void launch_axpby_n(plfem_ctx* c, int64_t n, double a, const double* x, double b, const double* y, double* z) {
+  hipLaunchKernelGGL(k_axpby, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, n, a, x, b, y, z);
+}
+
+void launch_scale(plfem_ctx* c, int64_t n, double a, double* x) {
+  hipLaunchKernelGGL(k_scale, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, n, a, x);
+}
 
 void launch_panel_dot(plfem_ctx* c, const double* P, int ncols, const double* w, double* h) {
   const int nchunks = c->npartial;
@@ -507,10 +601,17 @@ void launch_start_field(plfem_ctx* c, int nvec, double* out) {
 }
 
 void launch_rotate(plfem_ctx* c, const double* V, int m, const double* Smat, int ldS, int p, double* out) {
-  const int mpad = (m + 3) & ~3, ppad = (p + 15) & ~15;
-  size_t lds = sizeof(double) * mpad * ppad;
+  // S is staged in LDS (8 mpad ppad bytes): output columns go in chunks that keep it under ~64 KB, so that a long
+  // basis (m up to PLFEM_MAX_NCV + BLOCK_P) never asks for more LDS than a workgroup may have
+  const int mpad = (m + 3) & ~3;
+  const int chunk = std::max(16, ((64 * 1024) / (8 * mpad)) & ~15);
   unsigned grid = (unsigned)((c->n2 + 63) / 64);
-  hipLaunchKernelGGL(k_rotate, dim3(grid), dim3(256), lds, c->stream, c->n2, m, p, V, Smat, ldS, out);
+  for (int p0 = 0; p0 < p; p0 += chunk) {
+    const int pc = std::min(chunk, p - p0);
+    const size_t lds = sizeof(double) * mpad * ((pc + 15) & ~15);
+    hipLaunchKernelGGL(k_rotate, dim3(grid), dim3(256), lds, c->stream, c->n2, m, pc, V, Smat + (size_t)p0 * ldS, ldS,
+                       out + (size_t)p0 * c->n2);
+  }
 }
 
 void launch_post(plfem_ctx* c, int k, double* evecs, int ncore, double* out_host, double* frac_core,

@@ -111,6 +111,7 @@ class TrueVectorialMaxwellSolver:
     BASIS_FACTOR = 6         # Lanczos basis = 6 k columns (SciPy's default is 2k + 1): the driver tests convergence
     BASIS_MAX = 160          # after every block step, so a long basis costs memory, not work, and avoids restarts
     BASIS_BYTES = 16e9       # cap of the four basis panels (V, BV and their restart doubles)
+    RESIDUAL_TOL = 1e-7      # a-posteriori bound on ||A v - lambda B v|| / ||A v|| of every returned pair
 
     def __init__(self, geometry, use_pml: bool = False, n_modes: Optional[int] = None, device: Optional[int] = None,
                  eig_tol: float = 1e-10, leaf_elems: int = 0, reuse_symbolic: bool = True, mesh_refinement: float = 1.0,
@@ -160,7 +161,10 @@ class TrueVectorialMaxwellSolver:
         return ent
 
     def _basis_size(self, k: int, n2: int) -> int:
-        floor = max(2 * k + 1, 20)
+        floor = max(2 * k + 1, 20)           # SciPy's ncv (scipy arpack.py:306-311): never below it
+        if floor > _native.MAX_NCV:
+            raise ValueError(f"n_modes_target too large: k = {k} eigenpairs need a Lanczos basis of {floor} columns, "
+                             f"the device context holds at most {_native.MAX_NCV} (k <= {(_native.MAX_NCV - 1) // 2})")
         by_memory = int(self.BASIS_BYTES // (32 * max(n2, 1)))
         return max(floor, min(self.BASIS_FACTOR * k, self.BASIS_MAX, max(by_memory, floor)))
 
@@ -187,7 +191,11 @@ class TrueVectorialMaxwellSolver:
         colind = sym.array("colind")
 
         def blk(name):
-            return sp.csr_matrix((ctx.block_values(name), colind, rowptr), shape=(N, N))
+            # asm() -> COOData.tocsr() drops explicit zeros (e.g. the vertex / adjacent-edge
+            # mass entries vanish on every element), so the structural zeros of the shared pattern go too
+            m = sp.csr_matrix((ctx.block_values(name), colind, rowptr), shape=(N, N))
+            m.eliminate_zeros()
+            return m
 
         A = sp.bmat([[blk("Axx"), blk("Axy")], [blk("Ayx"), blk("Ayy")]], format="csr")
         M_inv = blk("Minv")
@@ -218,9 +226,28 @@ class TrueVectorialMaxwellSolver:
         ctx.factor(sigma)
         if self.profile_kernel:
             ctx.profile_begin(4096)
+        ctx.set_option("refine_steps", self.refine_steps)
         evals, evecs, st = ctx.lanczos(n_req, ncv, self.eig_tol, self.MAXITER, sigma)
         if self.profile_kernel:
             st = dict(st, kernel_profile=ctx.profile_end())
+        # A-posteriori guard: the LDL^T pivots statically and the Lanczos convergence test trusts K^-1, so every
+        # solve is checked against the ASSEMBLED pencil; a failed check (or a perturbed pivot) re-runs the eigen-solve
+        # with iterative refinement inside the operator, and a second failure is an error, never a silent result.
+        true_res = float(ctx.residuals(evals, evecs).max())
+        st = dict(st, true_residual=true_res, true_residual_first=true_res, refined=False)
+        if not (true_res <= self.RESIDUAL_TOL) or ctx.timings()["pivot_perturbations"] > 0:
+            logger.warning(f"eigenpairs failed the a-posteriori check (residual {true_res:.2e}, "
+                           f"{ctx.timings()['pivot_perturbations']} perturbed pivots): re-running with refinement")
+            ctx.set_option("refine_steps", max(1, self.refine_steps + 1))
+            try:
+                evals, evecs, st2 = ctx.lanczos(n_req, ncv, self.eig_tol, self.MAXITER, sigma)
+            finally:
+                ctx.set_option("refine_steps", self.refine_steps)
+            res2 = float(ctx.residuals(evals, evecs).max())
+            st = dict(st, **st2, true_residual=res2, refined=True)
+            if not (res2 <= self.RESIDUAL_TOL):
+                raise RuntimeError(f"shift-invert factorisation inaccurate on this mesh: eigen-residual {res2:.2e} "
+                                   f"after refinement (first pass {true_res:.2e}, bound {self.RESIDUAL_TOL:.0e})")
         post, frac_core, modes_int = ctx.postprocess(evecs, cores, want_interior=True)
         t1 = time.perf_counter()
         # (k, 2 N_solve) to the host: the caller owns NumPy arrays, as in the reference.  They live in pinned memory

@@ -19,6 +19,20 @@ from .geometry import ARRANGEMENTS, MCFGeometry
 
 K_MAX = 48          # padded record width: up to 48 effective indices per solve
 REC_WIDTH = K_MAX + 4
+# record[3]: status of the solve -- every rank always reaches the gather, errors travel in the record
+ST_OK, ST_NOCONV, ST_ERROR, ST_SKIPPED = 0, 1, 2, 3
+
+
+class SweepError(RuntimeError):
+    """Raised on EVERY rank after the gather when any record of the sweep carries an error status;
+    ``failures`` = [(item index, rank, status), ...], ``table`` = the records that did succeed."""
+
+    def __init__(self, failures, table):
+        names = {ST_NOCONV: "no convergence", ST_ERROR: "error", ST_SKIPPED: "skipped after an earlier error"}
+        super().__init__("sweep: " + ", ".join(f"item {i} on rank {r}: {names.get(s, s)}" for i, r, s in failures[:8])
+                         + (" ..." if len(failures) > 8 else ""))
+        self.failures = failures
+        self.table = table
 
 
 @dataclass(frozen=True)
@@ -120,7 +134,7 @@ def default_solve(device: Optional[int] = None) -> Callable[[SweepItem, dict], n
     return solve
 
 
-def _run_lane(entries, solve, rank: int, rec: np.ndarray, device, own_stream: bool) -> None:
+def _run_lane(entries, solve, rank: int, rec: np.ndarray, device, own_stream: bool, errors: list) -> None:
     """One lane = a sequential pass over ``entries`` [(row in rec, item), ...] with its own solver cache (and, on
     a GPU, its own stream so that lanes overlap on the device); the next different mesh is prepared on a host
     thread while the current one is being solved."""
@@ -146,9 +160,24 @@ def _run_lane(entries, solve, rank: int, rec: np.ndarray, device, own_stream: bo
                     if nxt is not None:
                         prefetch = threading.Thread(target=solve.prepare, args=(nxt, cache), daemon=True)
                         prefetch.start()
-            ne = np.asarray(solve(it, cache), dtype=np.float64)[:K_MAX]
-            rec[q, 0], rec[q, 1], rec[q, 2], rec[q, 3] = it.index, len(ne), rank, 0
-            rec[q, 4:4 + len(ne)] = ne
+            # an exception in one solve must not keep this rank from the collective (the other ranks would block in it
+            # forever): it becomes a status code in the item's record, n_eff stays NaN, and run_sweep raises on every
+            # rank after the gather
+            rec[q, 0], rec[q, 1], rec[q, 2] = it.index, 0, rank
+            try:
+                ne = np.asarray(solve(it, cache), dtype=np.float64)[:K_MAX]
+                rec[q, 1], rec[q, 3] = len(ne), ST_OK
+                rec[q, 4:4 + len(ne)] = ne
+            except Exception as exc:                       # noqa: BLE001 - reported through the record
+                from scipy.sparse.linalg import ArpackNoConvergence
+                rec[q, 3] = ST_NOCONV if isinstance(exc, ArpackNoConvergence) else ST_ERROR
+                errors.append((it.index, exc))
+                ent = cache.pop("cur", None)               # the context may be in an undefined state: drop it
+                if ent is not None and "solver" in ent:
+                    try:
+                        ent["solver"].clear_cache()
+                    except Exception:                      # noqa: BLE001
+                        pass
         if prefetch is not None:
             prefetch.join()
         ent = cache.get("cur")
@@ -178,8 +207,14 @@ def run_sweep(items: Sequence[SweepItem], rank: int = 0, world_size: int = 1,
     rec = np.full((per_rank, REC_WIDTH), np.nan)
     rec[:, 0] = -1
     lanes = max(1, int(lanes))
+    errors: list = []            # (item index, exception) of this rank's failed solves, for the message only
+    for q, it in enumerate(mine):            # a lane that dies outside a solve leaves these as they are
+        rec[q, 0], rec[q, 1], rec[q, 2], rec[q, 3] = it.index, 0, rank, ST_SKIPPED
     if lanes == 1:
-        _run_lane(list(enumerate(mine)), solve, rank, rec, device, own_stream=False)
+        try:
+            _run_lane(list(enumerate(mine)), solve, rank, rec, device, own_stream=False, errors=errors)
+        except Exception as exc:               # noqa: BLE001 - e.g. mesh preparation failed: still reach the gather
+            errors.append((-1, exc))
     else:
         import threading
         # deal whole mesh groups to the lanes, heaviest first, always to the lane with the least work so far
@@ -194,21 +229,18 @@ def run_sweep(items: Sequence[SweepItem], rank: int = 0, world_size: int = 1,
             lane_items[k].extend(g)
             load[k] += sum(it.cost() for _, it in g)
         on_gpu = device is not None and torch.cuda.is_available()
-        errors: list = []
 
         def work(entries):
             try:
-                _run_lane(entries, solve, rank, rec, device, own_stream=on_gpu)
-            except BaseException as exc:       # surfaced on the caller's thread below
-                errors.append(exc)
+                _run_lane(entries, solve, rank, rec, device, own_stream=on_gpu, errors=errors)
+            except Exception as exc:           # noqa: BLE001 - the lane's remaining items stay ST_SKIPPED
+                errors.append((-1, exc))
 
         threads = [threading.Thread(target=work, args=(e,)) for e in lane_items if e]
         for t in threads:
             t.start()
         for t in threads:
             t.join()
-        if errors:
-            raise errors[0]
     table: Dict[int, np.ndarray] = {}
     if world_size > 1 and gather:
         import torch.distributed as dist
@@ -220,7 +252,16 @@ def run_sweep(items: Sequence[SweepItem], rank: int = 0, world_size: int = 1,
         allrec = torch.stack(bufs).cpu().numpy().reshape(-1, REC_WIDTH)
     else:
         allrec = rec
+    failures = []
     for row in allrec:
         if row[0] >= 0:
-            table[int(row[0])] = row[4:4 + int(row[1])].copy()
+            if int(row[3]) == ST_OK:
+                table[int(row[0])] = row[4:4 + int(row[1])].copy()
+            else:
+                failures.append((int(row[0]), int(row[2]), int(row[3])))
+    if failures:
+        err = SweepError(sorted(failures), table)
+        if errors:
+            raise err from errors[0][1]
+        raise err
     return table, len(mine)

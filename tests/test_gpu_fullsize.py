@@ -1,0 +1,93 @@
+"""BASELINE.json configurations at FULL size on the GPU (configs[2] ladder rung L = 2, configs[3] the 64-solve
+multi-band sweep, configs[4] the 19-core stress case).  The oracle needs minutes to hours at these sizes, so the
+checks are the size-independent properties of the eigenproblem: every returned pair is an
+eigenpair of the ASSEMBLED pencil (residual through plfem_spmv / plfem_residuals, which do not involve the
+factorisation), the vectors are B-orthonormal, the shift-invert operator maps B v to v / (lambda - sigma), no
+pivot was perturbed -- plus the sizes SURVEY.md quotes and a memory bound."""
+import numpy as np
+import pytest
+
+from pl_fem_vectoriel_amd import MCFGeometry, _native
+from pl_fem_vectoriel_amd.mesh import generate_mesh
+from pl_fem_vectoriel_amd.solver_fem import TrueVectorialMaxwellSolver, _core_table, shift_estimate
+
+pytestmark = pytest.mark.gpu
+
+
+def _eigen_properties(g, mesh, n_modes, device, expect_N, max_front_bound, mem_bound_gb):
+    import torch
+    torch.cuda.empty_cache()
+    torch.cuda.reset_peak_memory_stats(device)
+    solver = TrueVectorialMaxwellSolver(g, device=device)
+    k = n_modes + 12
+    sym = _native.Symbolic(mesh.p, mesh.t)
+    assert sym.N == expect_N
+    assert sym.info["max_front"] <= max_front_bound
+    ncv = solver._basis_size(k, 2 * sym.N)
+    ctx = _native.Context(sym, device, max_ncv=ncv)
+    assert ctx.workspace.numel() <= mem_bound_gb * 1e9
+    ctx.assemble(_core_table(g), g.n_core ** 2, g.n_clad ** 2, g.k0, 1.0)
+    sigma = shift_estimate(g)
+    ctx.factor(sigma)
+    evals, V, st = ctx.lanczos(k, ncv, 1e-10, 12000, sigma)
+    assert st["nconv"] == k and (np.diff(evals) >= 0).all()
+    assert ctx.timings()["pivot_perturbations"] == 0
+    n_eff = np.sqrt(evals) / g.k0
+    assert (n_eff > g.n_clad).all() and (n_eff < g.n_core).all()
+    res = ctx.residuals(evals, V)
+    assert res.max() < 1e-8, res.max()
+    # the same residual from the two SpMV entry points (cross-check of plfem_residuals on three vectors)
+    for i in (0, k // 2, k - 1):
+        av, bv = ctx.spmv("A", V[i]), ctx.spmv("B", V[i])
+        r = ((av - evals[i] * bv).norm() / av.norm()).item()
+        assert abs(r - res[i]) <= 1e-6 * max(r, 1e-16) + 1e-18
+    BV = torch.stack([ctx.spmv("B", V[i]) for i in range(k)])
+    G = V @ BV.T
+    assert (G - torch.eye(k, device=G.device, dtype=G.dtype)).abs().max().item() < 1e-10      # B-orthonormal
+    for i in (1, k - 2):                          # K^-1 (B v) = v / (lambda - sigma)
+        x = ctx.solve(BV[i], 0)
+        assert ((x - V[i] / (evals[i] - sigma)).norm() / x.norm()).item() < 1e-7
+    peak = torch.cuda.max_memory_allocated(device)
+    assert peak <= (mem_bound_gb + 2) * 1e9, peak
+    ctx.close()
+    return evals, st, sym
+
+
+def test_ladder_rung_l2_full_size(c1_geometry, gpu_device, built_library):
+    """BASELINE configs[2], finest rung: 7-core, 2 uniform refinements, N = 362 285, n = 723 498."""
+    mesh = generate_mesh(c1_geometry, 1.0, 2)
+    evals, st, sym = _eigen_properties(c1_geometry, mesh, 10, gpu_device, expect_N=362285, max_front_bound=2400, mem_bound_gb=24)
+    assert 2 * sym.nsolve == 723498
+    # the band of the L = 1 rung (26.122 .. 26.180) moves by < 1e-2 under refinement
+    assert abs(evals[0] - 26.122) < 1e-2 and abs(evals[-1] - 26.180) < 1e-2
+
+
+def test_c5_nineteen_cores_full_size(gpu_device, built_library):
+    """BASELINE configs[4]: hex_1plus6plus12_19, 20 modes -> k = 32, fine mesh N = 744 037 (n = 1.49 M).
+    max_front = 3 024 DOFs here: 97 KB of LDS staging per sweep workgroup at P = 4."""
+    g = MCFGeometry(19, 8.0, 1.5, 1.535, 1.0, wavelength_um=1.55)
+    mesh = generate_mesh(g, 1.0, 2)
+    evals, st, sym = _eigen_properties(g, mesh, 20, gpu_device, expect_N=744037, max_front_bound=3400, mem_bound_gb=64)
+    assert st["n_block_solves"] > 0                     # the P = 4 block path fits the LDS budget at this size
+    assert 8 * 4 * (sym.info["max_front"] + 1) > 64 * 1024      # ... and is the > 64 KB case the guard is about
+
+
+def test_c4_full_multiband_sweep_on_one_gpu(gpu_device, built_library):
+    """BASELINE configs[3]: the 64 (arrangement x wavelength) solves through run_sweep on ONE GPU (the 8-GPU
+    launch shards the same list 8 per rank); 8 sampled items compared with isolated direct solves."""
+    from pl_fem_vectoriel_amd.sweep import multiband_sweep_items, run_sweep
+    items = multiband_sweep_items()
+    assert len(items) == 64
+    table, n_local = run_sweep(items, 0, 1, device=gpu_device)
+    assert n_local == 64 and sorted(table) == list(range(64))
+    for i in range(64):
+        assert 0 < len(table[i]) <= 22 and (np.diff(table[i]) <= 0).all()      # k = 22 requested per solve, descending n_eff
+        assert (table[i] > 1.0).all() and (table[i] < 1.535).all()
+    for it in items[3::8]:
+        g = it.geometry()
+        mesh = generate_mesh(g, it.mesh_refinement, it.mesh_levels)
+        solver = TrueVectorialMaxwellSolver(g, device=gpu_device)
+        direct = np.array([m["n_eff"] for m in solver.solve_vectorial_modes(mesh, it.n_modes)])
+        assert solver.last_stats["true_residual"] < 1e-8 and solver.last_stats["refined"] is False
+        assert len(direct) == len(table[it.index]) and np.abs(direct - table[it.index]).max() < 1e-10
+        solver.clear_cache()

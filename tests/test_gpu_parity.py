@@ -327,6 +327,10 @@ def test_live_kernel_profile_hooks(small):
     tile_levels = sum(1 for lev in range(T.L + 1) if (1 << lev) > 32)
     assert prof["launches"] == 3 * tile_levels
     assert prof["total_us"] > 0 and prof["bytes"] > 0
+    sl = prof["slots"]
+    assert sl["fwd_sweep"]["ranges"] == sl["bwd_sweep"]["ranges"] == 3 and sl["spmv_b"]["ranges"] == 0
+    assert sl["fwd_sweep"]["bytes"] == sl["bwd_sweep"]["bytes"] >= sl["k_fwd"]["bytes"] > 0
+    assert sl["fwd_sweep"]["total_us"] >= sl["k_fwd"]["total_us"] > 0
     # algorithmic bytes of one backward sweep never exceed the bytes of the stored factors + vectors
     assert prof["bytes"] / 3 <= 8.0 * (P.sym.info["solve_entries"] + 4 * P.sym.info["front_doubles"] ** 0.5 * T.nf)
 
@@ -460,3 +464,100 @@ def test_sweep_lanes_give_identical_results(gpu_device, built_library):
     for i in one:
         np.testing.assert_array_equal(one[i], two[i])
 
+
+
+def test_residuals_against_the_assembled_pencil(medium):
+    """plfem_residuals = ||A v - lambda B v|| / ||A v|| on the interior pencil, for arbitrary vectors."""
+    P = medium
+    rng = np.random.default_rng(5)
+    V = rng.standard_normal((3, len(P.idx)))
+    lam = np.array([26.0, -3.0, 0.5])
+    Vd = P.torch.stack([P.embed(v) for v in V])
+    got = P.ctx.residuals(lam, Vd)
+    for i in range(3):
+        av, bv = P.A_int @ V[i], P.B_int @ V[i]
+        ref = np.linalg.norm(av - lam[i] * bv) / np.linalg.norm(av)
+        assert abs(got[i] - ref) <= 1e-12 * ref
+
+
+def test_a_posteriori_guard_fires_on_a_bad_factor(small, gpu_device):
+    """a factorisation that lost accuracy must never yield silently wrong modes.  The test hook
+    perturbs D of the root front after every factorisation; the eigen-solve then converges (its test trusts K^-1),
+    the check against the assembled pencil fails, the re-run with refinement inside the operator repairs it."""
+    solver = TrueVectorialMaxwellSolver(small.g, device=gpu_device)
+    clean = solver.solve_vectorial_modes(small.mesh, 6)
+    st = solver.last_stats
+    assert st["refined"] is False and st["true_residual"] < 1e-9
+    ctx = next(iter(solver._cache.values()))["ctx"]
+    ctx.set_option("debug_perturb", 1e-4)
+    try:
+        modes = solver.solve_vectorial_modes(small.mesh, 6)
+        st = solver.last_stats
+        assert st["refined"] is True
+        assert st["true_residual_first"] > TrueVectorialMaxwellSolver.RESIDUAL_TOL >= st["true_residual"]
+        assert len(modes) == len(clean)
+        assert max(abs(a["n_eff"] - b["n_eff"]) for a, b in zip(modes, clean)) < 1e-7
+        assert mode_field_errors(modes, clean).max() < FIELD_TOL
+        # a factor too wrong for one refinement pass to repair: an error (inaccurate factor, or no convergence of the
+        # refined operator -- both RuntimeError), never a result
+        ctx.set_option("debug_perturb", 0.6)
+        with pytest.raises(RuntimeError):
+            solver.solve_vectorial_modes(small.mesh, 6)
+    finally:
+        ctx.set_option("debug_perturb", 0.0)
+    again = solver.solve_vectorial_modes(small.mesh, 6)
+    assert solver.last_stats["refined"] is False
+    for a, b in zip(again, clean):
+        assert a["n_eff"] == b["n_eff"]
+    with pytest.raises(ValueError):
+        ctx.set_option("no_such_option", 1.0)
+
+
+def test_no_convergence_is_scipys_exception(small):
+    """The reference lets scipy.sparse.linalg.ArpackNoConvergence propagate (solver_fem.py:197): ours IS one."""
+    P = small
+    P.ctx.factor(P.sigma)
+    with pytest.raises(spla.ArpackNoConvergence) as ei:
+        P.ctx.lanczos(22, 45, 1e-15, 0, P.sigma)       # no restart allowed at an unreachable tolerance
+    assert ei.value.eigenvalues is not None and len(ei.value.eigenvalues) == 22
+
+
+def test_long_basis_many_modes(small, gpu_device):
+    """n_modes_target = 80 -> k = 92 pairs, SciPy's ncv = 185 > the 160 columns of round 1: the
+    context now holds up to 320 columns, the Ritz rotation stages S in LDS chunk by chunk."""
+    solver = TrueVectorialMaxwellSolver(small.g, device=gpu_device)
+    solver.solve_vectorial_modes(small.mesh, n_modes_target=80)
+    st = solver.last_stats
+    assert st["n_req"] == 92 and st["nconv"] == 92 and 185 <= st["ncv"] <= 320
+    assert st["true_residual"] < 1e-8
+    P = small
+    w = spla.eigsh(P.A_int, k=92, M=P.B_int, sigma=P.sigma, which="LM", tol=1e-9, return_eigenvectors=False)
+    ctx = next(iter(solver._cache.values()))["ctx"]
+    ctx.factor(P.sigma)
+    evals, _, _ = ctx.lanczos(92, st["ncv"], 1e-10, 12000, P.sigma)
+    assert np.abs(np.sort(w) - evals).max() < 1e-8
+    with pytest.raises(ValueError, match="n_modes_target too large"):
+        solver.solve_vectorial_modes(small.mesh, n_modes_target=200)
+
+
+def test_front_too_large_for_the_lds_staging(gpu_device, built_library):
+    """The sweeps stage a front's right-hand side in LDS: one front of ~7 000 DOFs exceeds the budget
+    for 4 right-hand sides -> the single-vector recurrence is used, results unchanged; one front of ~21 000 DOFs
+    exceeds it for one -> plfem_create fails with PLFEM_EINVAL and says why."""
+    g1 = MCFGeometry(1, 0.0, 0.3, 1.535, 1.0, wavelength_um=1.55)
+    sq = unit_square_mesh(30)
+    sq.p[:] = sq.p - 0.5
+    solver = TrueVectorialMaxwellSolver(g1, device=gpu_device, leaf_elems=10 ** 6)      # one front = the whole mesh
+    modes = solver.solve_vectorial_modes(sq, n_modes_target=6)
+    st = solver.last_stats
+    sym = next(iter(solver._cache.values()))["sym"]
+    assert sym.info["nfronts"] == 1 and sym.info["max_front"] > 5200
+    assert st["n_block_solves"] == 0 and st["nconv"] == 18 and st["true_residual"] < 1e-8
+    ref = hfield.solve_vectorial_modes(g1, MeshTriLite(sq.p, sq.t), 6, fused=True)
+    assert len(modes) == len(ref) and max(abs(a["n_eff"] - b["n_eff"]) for a, b in zip(modes, ref)) < N_EFF_TOL
+    solver.clear_cache()
+    big = unit_square_mesh(52)
+    symb = _native.Symbolic(big.p, big.t, leaf_elems=10 ** 6)
+    assert symb.info["max_front"] > 20000
+    with pytest.raises(ValueError, match="largest front has .* DOFs.*LDS"):
+        _native.Context(symb, gpu_device)

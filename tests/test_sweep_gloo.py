@@ -6,7 +6,10 @@ import socket
 import numpy as np
 import torch.multiprocessing as mp
 
-from pl_fem_vectoriel_amd.sweep import K_MAX, SweepItem, multiband_sweep_items, partition, run_sweep
+import pytest
+
+from pl_fem_vectoriel_amd.sweep import (K_MAX, ST_ERROR, ST_NOCONV, SweepError, SweepItem, multiband_sweep_items, partition,
+                                        run_sweep)
 
 
 def fake_solve(item: SweepItem, cache: dict) -> np.ndarray:
@@ -63,3 +66,46 @@ def test_two_rank_gloo_sweep(tmp_path):
     n = [int(np.load(tmp_path / f"n{r}.npy")[0]) for r in range(2)]
     assert sum(n) == 24 and min(n) >= 8
     assert K_MAX >= 32
+
+
+def failing_solve(item: SweepItem, cache: dict) -> np.ndarray:
+    from pl_fem_vectoriel_amd._native import ArpackLikeNoConvergence
+    if item.index == 5:
+        raise ArpackLikeNoConvergence("no convergence (test)", None, None)
+    if item.index == 13:
+        raise RuntimeError("HIP error (test)")
+    return fake_solve(item, cache)
+
+
+def _worker_failing(rank, world_size, port, out_dir):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world_size))
+    dist.init_process_group("gloo", rank=rank, world_size=world_size)
+    items = multiband_sweep_items()[:24]
+    try:
+        run_sweep(items, rank, world_size, solve=failing_solve)
+        outcome = "no exception"
+    except SweepError as e:       # raised on BOTH ranks, after the collective
+        outcome = repr(e.failures) + f" ok={len(e.table)}"
+    dist.barrier()                # neither rank is stuck in the all_gather
+    with open(os.path.join(out_dir, f"f{rank}.txt"), "w") as fh:
+        fh.write(outcome)
+    dist.destroy_process_group()
+
+
+def test_failed_solve_reaches_the_gather_and_raises_on_every_rank(tmp_path):
+    """an exception in one rank's solve used to skip the all_gather and hang the other ranks."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_worker_failing, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    outs = [open(tmp_path / f"f{r}.txt").read() for r in range(2)]
+    assert outs[0] == outs[1]
+    parts = partition(multiband_sweep_items()[:24], 2)
+    rank_of = {it.index: r for r, p in enumerate(parts) for it in p}
+    assert outs[0] == repr([(5, rank_of[5], ST_NOCONV), (13, rank_of[13], ST_ERROR)]) + " ok=22"
+    # single process: same behaviour, the original exception is chained
+    with pytest.raises(SweepError) as ei:
+        run_sweep(multiband_sweep_items()[:24], 0, 1, solve=failing_solve)
+    assert [f[0] for f in ei.value.failures] == [5, 13] and ei.value.__cause__ is not None
