@@ -97,8 +97,10 @@ def partition(items: Sequence[SweepItem], world_size: int) -> List[List[SweepIte
     return out
 
 
-def default_solve(device: Optional[int] = None) -> Callable[[SweepItem, dict], np.ndarray]:
+def default_solve(device: Optional[int] = None, meshes: Optional[dict] = None) -> Callable[[SweepItem, dict], np.ndarray]:
     """Solve one item on the GPU; ``cache`` keeps one solver (symbolic analysis + context) per mesh.
+    ``meshes``: optional ``{item.mesh_key: TriMesh}`` of meshes produced beforehand (bench.py keeps the mesh
+    producer, the step before the path, outside its timed region); missing keys are generated on demand.
 
     ``solve.prepare(item, cache)`` may be called from a background thread for the NEXT mesh: mesh
     generation (SciPy Delaunay + native refinement) and the host-side symbolic analysis release the GIL,
@@ -109,7 +111,9 @@ def default_solve(device: Optional[int] = None) -> Callable[[SweepItem, dict], n
 
     def build(item: SweepItem) -> dict:
         g = item.geometry()
-        mesh = generate_mesh(g, item.mesh_refinement, item.mesh_levels)
+        mesh = (meshes or {}).get(item.mesh_key)
+        if mesh is None:
+            mesh = generate_mesh(g, item.mesh_refinement, item.mesh_levels)
         return {"key": item.mesh_key, "mesh": mesh, "sym": _native.Symbolic(mesh.p, mesh.t)}
 
     def prepare(item: SweepItem, cache: dict) -> None:
