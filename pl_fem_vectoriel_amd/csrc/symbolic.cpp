@@ -395,8 +395,8 @@ void nd_tree(Symbolic& S, int leaf_elems, int nthreads) {
   constexpr int NBIN = 512;
   struct Hist {
     double x0 = 1e300, x1 = -1e300, y0 = 1e300, y1 = -1e300;
-    int32_t cnt[2][NBIN + 1];
-    int32_t diff[2][NBIN + 2];
+    int32_t cnt[3][NBIN + 1];      // "axis" 2 = distance from the subdomain's median point (circular cuts)
+    int32_t diff[3][NBIN + 2];
   };
   // Bisection of G[lo, hi).  Large subdomains: the cut is an axis-parallel line chosen among NBIN-1
   // candidates per axis to minimise the number of straddled elements (~ separator size) subject to
@@ -427,7 +427,7 @@ void nd_tree(Symbolic& S, int leaf_elems, int nthreads) {
     if (n >= 192 && n >= 4 * min_side) {
       // both children must stay within a factor RHO of the ideal size ne / 2^(level+1): bounds the
       // leaf-size spread by RHO overall (no compounding), so batched front kernels stay balanced
-      constexpr double RHO = 2.2;
+      static const double RHO = getenv("PLFEM_RHO") ? atof(getenv("PLFEM_RHO")) : 2.2;
       const double ideal = (double)ne / (double)((int64_t)2 << level);
       const double clo = ideal / RHO, chi = ideal * RHO;
       const double a0s[2] = {x0, y0};
@@ -457,14 +457,61 @@ void nd_tree(Symbolic& S, int leaf_elems, int nthreads) {
         }
       };
       if (nt > 1) parallel_for(n, nt, hist, 1); else hist(0, n, 0);
+      auto chunk_ran = [&](int t) { return t == 0 || (int64_t)t * ((n + nt - 1) / nt) < n; };   // else its arrays are stale
+      // Third family of cuts: circles around the median point O of the element centroids (from the two histograms,
+      // integer counts: independent of the thread count).  The lantern meshes are polar inside every core -- a
+      // straight cut through a core crosses every ring twice, a circle between two rings crosses one ring's worth
+      // of elements -- and a subdomain dominated by one core has its median point near that core's centre.
+      double O[2] = {0.0, 0.0}, rscale = 0.0;
+      {
+        for (int axis = 0; axis < 2; ++axis) {
+          int64_t acc = 0;
+          int j = 0;
+          for (; j < NBIN; ++j) {
+            for (int t = 0; t < nt; ++t) if (chunk_ran(t)) acc += hs[t].cnt[axis][j];
+            if (2 * acc >= n) break;
+          }
+          O[axis] = scales[axis] > 0.0 ? a0s[axis] + (j + 0.5) / scales[axis] : a0s[axis];
+        }
+        const double ex = std::max(O[0] - x0, x1 - O[0]), ey = std::max(O[1] - y0, y1 - O[1]);
+        const double rmax = std::sqrt(ex * ex + ey * ey);
+        rscale = rmax > 0.0 ? NBIN / rmax : 0.0;
+      }
+      if (rscale > 0.0) {
+        auto rhist = [&](int64_t b, int64_t e_, int tid) {
+          Hist& h = hs[tid];
+          std::memset(h.cnt[2], 0, sizeof(h.cnt[2]));
+          std::memset(h.diff[2], 0, sizeof(h.diff[2]));
+          for (int64_t q = b; q < e_; ++q) {
+            const ElemGeo& g = Gl[q];
+            const double cx = g.c[0] - O[0], cy = g.c[1] - O[1];
+            int bc = std::min(NBIN - 1, std::max(0, (int)(std::sqrt(cx * cx + cy * cy) * rscale)));
+            h.cnt[2][bc]++;
+            // radial extent of the element's bounding box (a superset of the element: cost estimate only)
+            const double nx = std::max(std::max(g.lo[0] - O[0], O[0] - g.hi[0]), 0.0);
+            const double ny = std::max(std::max(g.lo[1] - O[1], O[1] - g.hi[1]), 0.0);
+            const double fx = std::max(std::fabs(g.lo[0] - O[0]), std::fabs(g.hi[0] - O[0]));
+            const double fy = std::max(std::fabs(g.lo[1] - O[1]), std::fabs(g.hi[1] - O[1]));
+            const double v0 = std::sqrt(nx * nx + ny * ny) * rscale - 1e-9, v1 = std::sqrt(fx * fx + fy * fy) * rscale + 1e-9;
+            const int t0 = (int)v0, t1 = (int)v1;
+            int j0 = t0 + (v0 > (double)t0);
+            int j1 = t1 - (v1 < (double)t1);
+            j0 = std::max(j0, 1); j1 = std::min(j1, NBIN - 1);
+            if (j0 <= j1) { h.diff[2][j0]++; h.diff[2][j1 + 1]--; }
+          }
+        };
+        if (nt > 1) parallel_for(n, nt, rhist, 1); else rhist(0, n, 0);
+      }
+      const double a0s3[3] = {x0, y0, 0.0};
+      const double scales3[3] = {scales[0], scales[1], rscale};
       double best_cost = 1e300, best_thr = 0;
       int best_axis = -1;
-      for (int axis = 0; axis < 2; ++axis) {
-        if (!(scales[axis] > 0.0)) continue;
+      for (int axis = 0; axis < 3; ++axis) {
+        if (!(scales3[axis] > 0.0)) continue;
         int64_t below = 0, strad = 0;
         for (int j = 1; j < NBIN; ++j) {
           for (int t = 0; t < nt; ++t) {
-            if (t > 0 && (int64_t)t * ((n + nt - 1) / nt) >= n) break;     // chunk never ran: its arrays are stale
+            if (!chunk_ran(t)) break;
             below += hs[t].cnt[axis][j - 1];
             strad += hs[t].diff[axis][j];
           }
@@ -472,17 +519,23 @@ void nd_tree(Symbolic& S, int leaf_elems, int nthreads) {
           if (below < clo || below > chi || n - below < clo || n - below > chi) continue;
           if (below < min_side || n - below < min_side) continue;
           double cost = (double)strad * (1.0 + 0.5 * std::fabs(f - 0.5));
-          if (cost < best_cost) { best_cost = cost; best_thr = a0s[axis] + j / scales[axis]; best_axis = axis; }
+          if (cost < best_cost) { best_cost = cost; best_thr = a0s3[axis] + j / scales3[axis]; best_axis = axis; }
         }
       }
       if (best_axis >= 0) {
         const int ax = best_axis;
+        const double thr2 = best_thr * best_thr;
+        auto left = [&](const ElemGeo& g) {
+          if (ax < 2) return g.c[ax] < best_thr;
+          const double cx = g.c[0] - O[0], cy = g.c[1] - O[1];
+          return cx * cx + cy * cy < thr2;
+        };
         if (nt > 1) {
           // stable two-pass partition through scratch
           std::vector<int64_t> nl(nt + 1, 0);
           parallel_for(n, nt, [&](int64_t b, int64_t e_, int tid) {
             int64_t k = 0;
-            for (int64_t q = b; q < e_; ++q) k += Gl[q].c[ax] < best_thr;
+            for (int64_t q = b; q < e_; ++q) k += left(Gl[q]);
             nl[tid + 1] = k;
           }, 1);
           for (int t = 0; t < nt; ++t) nl[t + 1] += nl[t];
@@ -491,7 +544,7 @@ void nd_tree(Symbolic& S, int leaf_elems, int nthreads) {
           parallel_for(n, nt, [&](int64_t b, int64_t e_, int tid) {
             int64_t wl = nl[tid], wr = nleft + (b - nl[tid]);
             for (int64_t q = b; q < e_; ++q) {
-              if (Gl[q].c[ax] < best_thr) Sc[wl++] = Gl[q]; else Sc[wr++] = Gl[q];
+              if (left(Gl[q])) Sc[wl++] = Gl[q]; else Sc[wr++] = Gl[q];
             }
           }, 1);
           parallel_for(n, nt, [&](int64_t b, int64_t e_, int) {
@@ -499,7 +552,7 @@ void nd_tree(Symbolic& S, int leaf_elems, int nthreads) {
           }, 1);
           mid = lo + (int)nleft;
         } else {
-          auto it = std::partition(G.begin() + lo, G.begin() + hi, [&](const ElemGeo& g) { return g.c[ax] < best_thr; });
+          auto it = std::partition(G.begin() + lo, G.begin() + hi, left);
           mid = (int)(it - G.begin());
         }
         if (mid - lo < min_side || hi - mid < min_side) mid = -1;

@@ -193,7 +193,8 @@ class TrueVectorialMaxwellSolver:
         def blk(name):
             # asm() -> COOData.tocsr() drops explicit zeros (e.g. the vertex / adjacent-edge
             # mass entries vanish on every element), so the structural zeros of the shared pattern go too
-            m = sp.csr_matrix((ctx.block_values(name), colind, rowptr), shape=(N, N))
+            # (eliminate_zeros works in place: every block gets its own copy of the shared index arrays)
+            m = sp.csr_matrix((ctx.block_values(name), colind.copy(), rowptr.copy()), shape=(N, N))
             m.eliminate_zeros()
             return m
 
