@@ -245,8 +245,9 @@ int create_impl(plfem_ctx* c, const plfem_symbolic* sym, int device, void* strea
         for (int t = 0; t * li.fwd_rows < fm[o[q]]; ++t) blk.push_back(make_int2(o[q], t));
       li.fwd_n = (int)(blk.size() - li.fwd_off);
       li.bwd_off = (int64_t)blk.size();
+      // (a non-leaf front without owned DOFs still gets one workgroup: it republishes its boundary values for its children)
       for (int q = 0; q < li.count; ++q)
-        for (int t = 0; t * li.bwd_rows < fs2[o[q]]; ++t) blk.push_back(make_int2(o[q], t));
+        for (int t = 0; t * li.bwd_rows < std::max(fs2[o[q]], lev < S.L ? 1 : 0); ++t) blk.push_back(make_int2(o[q], t));
       li.bwd_n = (int)(blk.size() - li.bwd_off);
     }
   }
@@ -312,6 +313,28 @@ int create_impl(plfem_ctx* c, const plfem_symbolic* sym, int device, void* strea
     }
     if (size_only) tiles.resize((size_t)ntiles);          // only its size matters to the placement pass
   }
+  // front order of the solve vectors: node -> position of its owned slot; local node -> local node in the parent front
+  std::vector<int32_t> npos, prow;
+  if (!size_only) {
+    npos.assign((size_t)S.N, -1);
+    prow.assign((size_t)S.fnode_ptr[S.nfronts], -1);
+    for (int f = 0; f < S.nfronts; ++f) {
+      const int64_t np = S.fnode_ptr[f];
+      for (int q = 0; q < S.fs_true[f]; ++q) npos[S.fnodes[np + q]] = (int32_t)(np + q);
+      if (2 * f + 2 < S.nfronts) {
+        const int64_t n0 = S.fnode_ptr[2 * f + 1] + S.fs[2 * f + 1], n1 = S.fnode_ptr[2 * f + 2] + S.fs[2 * f + 2];
+        const int mn = S.fs[f] + S.fb[f];
+        for (int q = 0; q < mn; ++q) {
+          const int32_t c0 = S.cinv0[np + q], c1 = S.cinv1[np + q];
+          if (c0 >= 0) prow[n0 + c0] = q;
+          if (c1 >= 0) prow[n1 + c1] = q;
+        }
+      }
+    }
+  } else {
+    npos.resize((size_t)S.N);
+    prow.resize((size_t)S.fnode_ptr[S.nfronts]);
+  }
   const double tt1 = now_ms();
   std::vector<UploadItem> items;
   size_t upload_span = 0;
@@ -340,6 +363,8 @@ int create_impl(plfem_ctx* c, const plfem_symbolic* sym, int device, void* strea
   TRY(upload(c, items, &c->d_epos, S.epos));
   TRY(upload(c, items, &c->d_leaf_elem_ptr, S.leaf_elem_ptr));
   TRY(upload(c, items, &c->d_leaf_elems, S.leaf_elems));
+  TRY(upload(c, items, &c->d_npos, npos));
+  TRY(upload(c, items, &c->d_prow, prow));
   upload_span = c->slab_off;
   TRY(dalloc(c, &c->d_colind, (size_t)c->nnz));      // filled on the device by launch_pattern_fill below
   TRY(dalloc(c, &c->d_slot_row, (size_t)c->nnz));
@@ -356,6 +381,9 @@ int create_impl(plfem_ctx* c, const plfem_symbolic* sym, int device, void* strea
   TRY(dalloc(c, &c->d_delta, (size_t)2 * fnodes_total));
   TRY(dalloc(c, &c->d_tbuf, (size_t)2 * fnodes_total * plfem::NB));
   TRY(dalloc(c, &c->d_fvec2, (size_t)2 * fnodes_total * plfem::BLOCK_P));
+  TRY(dalloc(c, &c->d_u0, (size_t)2 * fnodes_total * plfem::BLOCK_P));
+  TRY(dalloc(c, &c->d_u1, (size_t)2 * fnodes_total * plfem::BLOCK_P));
+  TRY(dalloc(c, &c->d_xl, (size_t)2 * fnodes_total * plfem::BLOCK_P));
   TRY(dalloc(c, &c->d_counters, 4));
   const size_t n2 = (size_t)c->n2, nc1 = (size_t)max_ncv + 1 + plfem::BLOCK_P;
   TRY(dalloc(c, &c->d_V, n2 * nc1));
@@ -404,6 +432,9 @@ int create_impl(plfem_ctx* c, const plfem_symbolic* sym, int device, void* strea
   TRY(flush_uploads(c, items, upload_span, reinterpret_cast<char*>(staging)));
   const double tt3 = now_ms();
   HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, 4 * sizeof(int32_t), c->stream));
+  // the padding rows of the front-ordered right-hand side are never written and are multiplied by exact zeros of the
+  // factors: they must be finite (the workspace may hold anything)
+  HIP_TRY(c, hipMemsetAsync(c->d_fvec, 0, sizeof(double) * 2 * c->fnodes_total * plfem::BLOCK_P, c->stream));
   plfem::launch_pattern_fill(c);
   TRY(check_launch(c, "pattern fill"));
   {
@@ -530,6 +561,7 @@ extern "C" int plfem_factor(plfem_ctx* c, double sigma) {
   if (!c->assembled) { c->err = "plfem_factor before plfem_assemble_hfield"; return PLFEM_ESTATE; }
   HIP_TRY(c, hipSetDevice(c->device));
   HIP_TRY(c, hipEventRecord(c->ev[1][0], c->stream));
+  HIP_TRY(c, hipMemsetAsync(c->d_fvec, 0, sizeof(double) * 2 * c->fnodes_total * plfem::BLOCK_P, c->stream));   // (see plfem_create)
   plfem::launch_factor(c, sigma);
   if (c->debug_perturb != 0.0)   // test hook (plfem_set_option "debug_perturb"): a slightly wrong factor
     plfem::launch_scale(c, (int64_t)2 * c->S->fs[0], 1.0 + c->debug_perturb, c->d_delta);
@@ -566,11 +598,11 @@ static void solve_refined(plfem_ctx* c, const double* b, double* y, int steps) {
 }
 
 // the same for BLOCK_P columns (leading dimension n2, contiguous); scratch: the first 3 BLOCK_P columns of d_V2
-// (the restart double buffer, idle between restarts) -- launch_solve_block itself uses d_t1 / d_t2
-static void solve_block_refined(plfem_ctx* c, const double* b, double* y, bool b_interleaved_in_t1, int steps) {
+// (the restart double buffer, idle between restarts)
+static void solve_block_refined(plfem_ctx* c, const double* b, double* y, bool b_in_front_order, int steps) {
   constexpr int P = plfem::BLOCK_P;
   const int64_t n = c->n2;
-  plfem::launch_solve_block(c, b, y, n, b_interleaved_in_t1);
+  plfem::launch_solve_block(c, b, y, n, b_in_front_order);
   double* ta = c->d_V2;
   double* tb = c->d_V2 + (size_t)P * n;
   double* dy = c->d_V2 + (size_t)2 * P * n;
@@ -609,7 +641,7 @@ static int lanczos_block(plfem_ctx* c, int k, int ncv, double tol, int maxiter, 
     plfem::launch_spmv_b_block(c, c->d_w, c->d_bw, n);
     plfem::launch_panel_dot_block(c, c->d_w, P, c->d_bw, n, c->d_G, P);
     plfem::launch_chol_block(c, c->d_G, P, c->d_hblk, P, c->d_Rinv);      // R itself is not needed for the start block
-    plfem::launch_block_scale(c, c->d_w, c->d_bw, n, c->d_Rinv, c->d_V, c->d_BV, n, nullptr, 0, nullptr, nullptr, c->d_t1);
+    plfem::launch_block_scale(c, c->d_w, c->d_bw, n, c->d_Rinv, c->d_V, c->d_BV, n, nullptr, 0, nullptr, nullptr, c->d_fvec);
   }
   HIP_TRY(c, hipMemsetAsync(c->d_Hcols, 0, sizeof(double) * ld * ld, st));
   int c0 = 0, mm = 0, nconv = 0;
@@ -629,7 +661,7 @@ static int lanczos_block(plfem_ctx* c, int k, int ncv, double tol, int maxiter, 
   // (full reorthogonalisation of what rounding left, no cancellation any more).  The first step after a thick
   // restart couples with every kept Ritz vector: both passes full.
   int cycle_start = -1;                          // first column of the current cycle when it follows a restart
-  int il_ready = 0;                              // basis column whose B V block d_t1 holds interleaved (k_block_scale)
+  int il_ready = 0;                              // basis column whose B V block d_fvec holds in front order (k_block_scale)
   auto launch_step = [&](int c0_, int slot) -> int {
     const int nc = c0_ + P;
     const int lo = (c0_ == cycle_start) ? 0 : std::max(0, nc - 2 * P);
@@ -647,7 +679,7 @@ static int lanczos_block(plfem_ctx* c, int k, int ncv, double tol, int maxiter, 
     plfem::launch_gram_chol_block(c, c->d_w, c->d_bw, n, Hblk + nc, ld, c->d_Rinv);   // W^T B W = R^T R, R -> T[nc:nc+P, c0:c0+P]
     // the last kernel of the step also stores the new columns and the counters into the pinned slot (no copies)
     plfem::launch_block_scale(c, c->d_w, c->d_bw, n, c->d_Rinv, c->d_V + (size_t)nc * n, c->d_BV + (size_t)nc * n, n,
-                              Hblk, ld * P, slots_dev + (size_t)slot * ld * P, hcnt_dev + 4 * slot, c->d_t1);
+                              Hblk, ld * P, slots_dev + (size_t)slot * ld * P, hcnt_dev + 4 * slot, c->d_fvec);
     il_ready = nc;
     int rc = check_launch(c, "block lanczos step");
     if (rc != PLFEM_OK) return rc;
@@ -1026,6 +1058,7 @@ extern "C" int plfem_debug_copy(plfem_ctx* c, const char* name, int64_t offset, 
   else if (n == "dinv") src = c->d_dinv;
   else if (n == "delta") src = c->d_delta;
   else if (n == "fvec2") src = c->d_fvec2;
+  else if (n == "xl") src = c->d_xl;
   else if (n == "elem") src = c->d_elem;
   else if (n == "colind" || n == "slot_row") {            // int32 index arrays, delivered as doubles
     if (offset + count > c->nnz) return PLFEM_EINVAL;

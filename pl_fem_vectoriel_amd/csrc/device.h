@@ -74,12 +74,16 @@ struct plfem_ctx {
   double* d_elem = nullptr;       // [ne][8][36]
   double* d_vals[PLFEM_BLK_COUNT] = {nullptr};
   double* d_front = nullptr;      // dense fronts
-  double* d_fvec = nullptr;       // per-front solve vectors, offset 2*fnode_ptr[f]
+  double* d_fvec = nullptr;       // per-front solve vectors in front order, offset 2*fnode_ptr[f]: right-hand side (owned rows)
+  double *d_u0 = nullptr, *d_u1 = nullptr;   // updates pushed into a front's rows by its left / right child (forward sweep)
+  double* d_xl = nullptr;         // complete local solution of every front (backward sweep)
+  int32_t* d_npos = nullptr;      // [N] node -> front-order node position fnode_ptr[owner] + local index, -1 = Dirichlet
+  int32_t* d_prow = nullptr;      // per local node of a front: local node index in the PARENT front, -1 = none / padding
   double *d_wbuf = nullptr, *d_rbuf = nullptr;   // per-front panels m x NB, offset 2*fnode_ptr[f]*NB
   double* d_dinv = nullptr;       // per-front NB x NB (inverse of the current unit-lower pivot block)
   double* d_delta = nullptr;      // per-front D of the LDL^T (offset 2*fnode_ptr[f])
   double* d_tbuf = nullptr;       // per-front NB x s2 scratch (block row of L11), offset 2*fnode_ptr[f]*NB
-  double* d_fvec2 = nullptr;      // second per-front solve vector
+  double* d_fvec2 = nullptr;      // forward-sweep results of the owned rows (ys = D^-1 L11^-1 r), front order
   int32_t* d_counters = nullptr;  // [0] pivot perturbations
   // ---- Lanczos workspace
   double *d_V = nullptr, *d_BV = nullptr, *d_V2 = nullptr, *d_BV2 = nullptr;   // n2 x (max_ncv+1), column major
@@ -149,10 +153,10 @@ void launch_spmv_b_block(plfem_ctx* c, const double* x, double* y, int64_t ld); 
 void launch_spmv_a_block(plfem_ctx* c, const double* x, double* y, int64_t ld);   // y_q = A x_q, BLOCK_P vectors
 // out_host[i] = ||A v_i - lambda_i B v_i|| / ||A v_i||  (k vectors, row i of evecs; synchronises)
 void launch_residuals(plfem_ctx* c, int k, const double* lam_host, const double* evecs, double* out_host);
-// kernels_front.hip
+// kernels_front.hip (factorisation), kernels_sweep.hip (solve sweeps)
 void launch_factor(plfem_ctx* c, double sigma, int stop_level = -1, int stop_step = 0, int stop_stage = 0);
 void launch_solve(plfem_ctx* c, const double* rhs, double* x);
-void launch_solve_block(plfem_ctx* c, const double* rhs, double* x, int64_t ldx, bool rhs_interleaved_in_t1 = false);   // BLOCK_P right-hand sides
+void launch_solve_block(plfem_ctx* c, const double* rhs, double* x, int64_t ldx, bool rhs_in_front_order = false);   // BLOCK_P right-hand sides
 // kernels_lanczos.hip
 void launch_panel_dot(plfem_ctx* c, const double* P, int ncols, const double* w, double* h);   // h = P^T w
 void launch_panel_axpy(plfem_ctx* c, const double* P, int ncols, const double* h, double* w);  // w -= P h
@@ -174,7 +178,7 @@ void launch_gram_chol_block(plfem_ctx* c, const double* W, const double* BW, int
 void launch_chol_block(plfem_ctx* c, const double* G, int ldg, double* Tblk, int ldT, double* Rinv);
 void launch_block_scale(plfem_ctx* c, const double* W, const double* BW, int64_t ldw, const double* Rinv, double* Vn,
                         double* BVn, int64_t ldv, const double* exp_src = nullptr, int exp_n = 0, double* exp_dst = nullptr,
-                        int32_t* cnt_dst = nullptr, double* bv_il = nullptr);
+                        int32_t* cnt_dst = nullptr, double* bv_front = nullptr);
 void launch_start_field(plfem_ctx* c, int nvec, double* out);
 void launch_post(plfem_ctx* c, int k, double* evecs, int ncore, double* out_host, double* frac_core, double* modes_int);
 

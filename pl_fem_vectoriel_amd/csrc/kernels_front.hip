@@ -575,369 +575,6 @@ __global__ __launch_bounds__(256) void k_mirror_z(const int2* __restrict__ tiles
   }
 }
 
-// ------------------------------------------------------------------------------------------------
-// solve sweeps: one kernel per level and direction, P right-hand sides at a time (P = 1: plfem_solve
-// and single-vector Lanczos; P = 4: block Lanczos -- every entry of the factors is read once for P
-// vectors).
-//   forward : [ys; u] = [D^-1 L11^-1 r ;  w_b - Z r],     r = rhs_own + children's updates
-//   backward: x_own   = L11^-T ys - Z^T x_b
-// Forward: "tile" form (levels with many fronts, k_fwd): lane = output row, the block's waves split the columns,
-// partial sums meet in LDS in a fixed order; "row" form (at most 32 fronts, k_fwd_rows): a wave owns R rows of
-// [L11^-1 ; Z] and runs along their columns in the mirrored upper storage.  Backward: row form (k_bwd_rows: the
-// contiguous columns of the lower storage) except at the leaf level, where the fronts have about as many owned
-// rows as boundary columns and the tile form (k_bwd) is faster.  All read contiguous runs of F thanks to the
-// mirrored storage; the cross-lane sums of the row forms use multi_reduce (V - 1 + log2(64 / V) shuffles).
-// Global vectors: column q of rhs / x at offset q*ldx.  Per-front vectors: [dof][P] interleaved.
-// ------------------------------------------------------------------------------------------------
-// global vector element (dof index i, right-hand side u): ldx > 0 -> separate columns (u*ldx + i),
-// ldx == 0 -> interleaved [i][P] (the block solve: P values of a DOF in one 32-B run)
-template <int P>
-__device__ __forceinline__ int64_t vidx(int64_t i, int u, int64_t ldx) {
-  return ldx ? (int64_t)u * ldx + i : i * P + u;
-}
-
-// local right-hand side of local DOF i: global rhs (owned DOFs) + the children's updates
-template <int P>
-__device__ __forceinline__ void gather_rhs(double (&v)[P], int f, int i, int s2, int N, int64_t ldx, int leaf_level,
-                                           int64_t np, const int32_t* __restrict__ fs2,
-                                           const int64_t* __restrict__ fnode_ptr, const int32_t* __restrict__ fnodes,
-                                           const int32_t* __restrict__ cinv0, const int32_t* __restrict__ cinv1,
-                                           const double* __restrict__ rhs, const double* __restrict__ fvec) {
-  const int q = i >> 1, c = i & 1;
-  const int node = fnodes[np + q];
-#pragma unroll
-  for (int u = 0; u < P; ++u) v[u] = 0.0;
-  if (i < s2 && node >= 0) {
-#pragma unroll
-    for (int u = 0; u < P; ++u) v[u] = rhs[vidx<P>((int64_t)c * N + node, u, ldx)];
-  }
-  if (!leaf_level) {
-    int c0 = cinv0[np + q], c1 = cinv1[np + q];
-    if (c0 >= 0) {
-      int ch = 2 * f + 1;
-      const double* s = fvec + (2 * fnode_ptr[ch] + fs2[ch] + 2 * c0 + c) * P;
-#pragma unroll
-      for (int u = 0; u < P; ++u) v[u] += s[u];
-    }
-    if (c1 >= 0) {
-      int ch = 2 * f + 2;
-      const double* s = fvec + (2 * fnode_ptr[ch] + fs2[ch] + 2 * c1 + c) * P;
-#pragma unroll
-      for (int u = 0; u < P; ++u) v[u] += s[u];
-    }
-  }
-}
-
-constexpr int TILE_BATCH = 8;
-template <int P, int NW>
-__device__ __forceinline__ void tile_sum(double (&out)[P], const double* __restrict__ p, int64_t ld, bool valid,
-                                         int cb, int ce, const double* __restrict__ v, double* __restrict__ red) {
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  double acc[P];
-#pragma unroll
-  for (int u = 0; u < P; ++u) acc[u] = 0.0;
-  if (valid) {
-    // this wave's columns: c == wave (mod NW), TILE_BATCH predicated loads in flight per lane -- also for the
-    // last, partial batch (a one-load-per-iteration remainder loop costs a memory round trip per column)
-    for (int c = cb + ((wave - cb) & (NW - 1)); c < ce; c += TILE_BATCH * NW) {
-      double a[TILE_BATCH];
-#pragma unroll
-      for (int t = 0; t < TILE_BATCH; ++t) a[t] = (c + NW * t < ce) ? p[(int64_t)(c + NW * t) * ld] : 0.0;
-#pragma unroll
-      for (int t = 0; t < TILE_BATCH; ++t) {
-        if (c + NW * t < ce) {
-#pragma unroll
-          for (int u = 0; u < P; ++u) acc[u] += a[t] * v[(c + NW * t) * P + u];
-        }
-      }
-    }
-  }
-#pragma unroll
-  for (int u = 0; u < P; ++u) red[(wave * P + u) * 64 + lane] = acc[u];
-  __syncthreads();
-#pragma unroll
-  for (int u = 0; u < P; ++u) {
-    double t = 0.0;
-#pragma unroll
-    for (int w = 0; w < NW; ++w) t += red[(w * P + u) * 64 + lane];
-    out[u] = t;
-  }
-}
-
-template <int P, int NW>
-__global__ __launch_bounds__(NW * 64) void k_fwd(const int2* __restrict__ blk, int N, int64_t ldx, int leaf_level,
-                                             const int32_t* __restrict__ fs2, const int32_t* __restrict__ fm,
-                                             const int64_t* __restrict__ foff, const int64_t* __restrict__ fnode_ptr,
-                                             const int32_t* __restrict__ fnodes, const int32_t* __restrict__ cinv0,
-                                             const int32_t* __restrict__ cinv1, const double* __restrict__ front,
-                                             const double* __restrict__ delta, const double* __restrict__ rhs,
-                                             double* __restrict__ fvec, double* __restrict__ fvec2) {
-  extern __shared__ double sv[];
-  __shared__ double red[NW * P * 64];
-  const int2 job = blk[blockIdx.x];
-  const int f = job.x;
-  const int m = fm[f], s2 = fs2[f];
-  const int r0 = job.y * 64;
-  const int64_t np = fnode_ptr[f];
-  for (int i = threadIdx.x; i < s2; i += NW * 64) {
-    double v[P];
-    gather_rhs<P>(v, f, i, s2, N, ldx, leaf_level, np, fs2, fnode_ptr, fnodes, cinv0, cinv1, rhs, fvec);
-#pragma unroll
-    for (int u = 0; u < P; ++u) sv[i * P + u] = v[u];
-  }
-  __syncthreads();
-  const int r = r0 + (threadIdx.x & 63);
-  const bool valid = r < m;
-  const int ce = (r < s2) ? r + 1 : s2;               // rows of L11^-1 are lower triangular
-  double acc[P];
-  tile_sum<P, NW>(acc, front + foff[f] + r, m, valid, 0, ce, sv, red);
-  // (fetching the epilogue operands before the sum is slower: the dependent index -> value loads of
-  // gather_rhs would sit in front of the matrix loads in the in-order memory counter)
-  if (threadIdx.x < 64 && valid) {
-    if (r < s2) {
-      const double di = 1.0 / delta[2 * np + r];
-#pragma unroll
-      for (int u = 0; u < P; ++u) fvec2[(2 * np + r) * P + u] = acc[u] * di;
-    } else {
-      double w[P];
-      gather_rhs<P>(w, f, r, s2, N, ldx, leaf_level, np, fs2, fnode_ptr, fnodes, cinv0, cinv1, nullptr, fvec);
-#pragma unroll
-      for (int u = 0; u < P; ++u) fvec[(2 * np + r) * P + u] = w[u] - acc[u];
-    }
-  }
-}
-
-// stage v = [ys ; -x_b] of front f in LDS (entries >= lo only), [dof][P]
-template <int P>
-__device__ __forceinline__ void stage_bwd(double* sv, int lo, int m, int s2, int N, int64_t ldx, int64_t np,
-                                          const int32_t* __restrict__ fnodes, const double* __restrict__ fvec2,
-                                          const double* __restrict__ x) {
-  for (int i = lo + threadIdx.x; i < m; i += blockDim.x) {
-    if (i < s2) {
-#pragma unroll
-      for (int u = 0; u < P; ++u) sv[i * P + u] = fvec2[(2 * np + i) * P + u];
-    } else {
-      const int node = fnodes[np + (i >> 1)];
-#pragma unroll
-      for (int u = 0; u < P; ++u)
-        sv[i * P + u] = node >= 0 ? -x[vidx<P>((int64_t)(i & 1) * N + node, u, ldx)] : 0.0;
-    }
-  }
-}
-
-template <int P, int NW>
-__global__ __launch_bounds__(NW * 64) void k_bwd(const int2* __restrict__ blk, int N, int64_t ldx, const int32_t* __restrict__ fs2,
-                                             const int32_t* __restrict__ fm, const int64_t* __restrict__ foff,
-                                             const int64_t* __restrict__ fnode_ptr, const int32_t* __restrict__ fnodes,
-                                             const double* __restrict__ front, const double* __restrict__ fvec2,
-                                             double* __restrict__ x) {
-  extern __shared__ double sv[];
-  __shared__ double red[NW * P * 64];
-  const int2 job = blk[blockIdx.x];
-  const int f = job.x;
-  const int m = fm[f], s2 = fs2[f];
-  const int r0 = job.y * 64;
-  const int64_t np = fnode_ptr[f];
-  stage_bwd<P>(sv, r0, m, s2, N, ldx, np, fnodes, fvec2, x);
-  __syncthreads();
-  const int r = r0 + (threadIdx.x & 63);
-  const bool valid = r < s2;
-  // element (j = r, i) of [L11^-T | Z^T] at F[r + i m], i in [r, m)
-  const int node = (threadIdx.x < 64 && valid) ? fnodes[np + (r >> 1)] : -1;
-  double acc[P];
-  tile_sum<P, NW>(acc, front + foff[f] + r, m, valid, r, m, sv, red);
-  if (threadIdx.x < 64 && valid) {
-    if (node >= 0) {
-#pragma unroll
-      for (int u = 0; u < P; ++u) x[vidx<P>((int64_t)(r & 1) * N + node, u, ldx)] = acc[u];
-    }
-  }
-}
-
-// Sums V (a power of two <= 64) per-lane values over the 64 lanes with V - 1 + log2(64 / V) shuffles instead of
-// 6 V: each butterfly step halves the values a lane still carries.  On return a[0] of lane l is the complete sum
-// of value multi_reduce_index<V>(l); lanes 0 .. V-1 cover every value once.  Fixed order, so deterministic.
-template <int V>
-__device__ __forceinline__ int multi_reduce_index(int lane) {
-  int idx = 0;
-#pragma unroll
-  for (int h = V / 2, s = 0; h >= 1; h >>= 1, ++s) idx += ((lane >> s) & 1) ? h : 0;
-  return idx;
-}
-
-template <int V>
-__device__ __forceinline__ void multi_reduce(double (&a)[V], int lane) {
-#pragma unroll
-  for (int h = V / 2, bit = 1; h >= 1; h >>= 1, bit <<= 1) {
-    const bool up = (lane & bit) != 0;
-#pragma unroll
-    for (int k = 0; k < h; ++k) {
-      const double send = up ? a[k] : a[k + h];
-      const double keep = up ? a[k + h] : a[k];
-      a[k] = keep + __shfl_xor(send, bit);
-    }
-  }
-#pragma unroll
-  for (int off = V; off < 64; off <<= 1) a[0] += __shfl_xor(a[0], off);
-}
-
-// Forward sweep, row form (top of the tree: few large fronts): row r of [L11^-1 ; Z] is contiguous in the mirrored
-// upper storage, a wave owns R rows and runs along their columns; NW R rows share one staged right-hand side.
-template <int P, int NW, int R>
-__global__ __launch_bounds__(NW * 64) void k_fwd_rows(const int2* __restrict__ blk, int N, int64_t ldx, int leaf_level,
-                                                      const int32_t* __restrict__ fs2, const int32_t* __restrict__ fm,
-                                                      const int64_t* __restrict__ foff, const int64_t* __restrict__ fnode_ptr,
-                                                      const int32_t* __restrict__ fnodes, const int32_t* __restrict__ cinv0,
-                                                      const int32_t* __restrict__ cinv1, const double* __restrict__ front,
-                                                      const double* __restrict__ delta, const double* __restrict__ rhs,
-                                                      double* __restrict__ fvec, double* __restrict__ fvec2) {
-  extern __shared__ double sv[];
-  constexpr int RB = NW * R, UNR = 8 / R, V = R * P;
-  const int2 job = blk[blockIdx.x];
-  const int f = job.x;
-  const int m = fm[f], s2 = fs2[f];
-  const int j0 = job.y * RB;
-  const int64_t np = fnode_ptr[f];
-  const int need = min(s2, j0 + RB);                      // rows < s2 only read r[0 .. row]
-  for (int i = threadIdx.x; i < need; i += NW * 64) {
-    double v[P];
-    gather_rhs<P>(v, f, i, s2, N, ldx, leaf_level, np, fs2, fnode_ptr, fnodes, cinv0, cinv1, rhs, fvec);
-#pragma unroll
-    for (int u = 0; u < P; ++u) sv[i * P + u] = v[u];
-  }
-  __syncthreads();
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const double* F = front + foff[f];
-  int ce[R], cmax = 0;
-#pragma unroll
-  for (int q = 0; q < R; ++q) {
-    const int r = j0 + wave + NW * q;
-    ce[q] = r < m ? ((r < s2) ? r + 1 : s2) : 0;
-    cmax = max(cmax, ce[q]);
-  }
-  double acc[V];
-#pragma unroll
-  for (int v = 0; v < V; ++v) acc[v] = 0.0;
-  for (int c = 0; c < cmax; c += 64 * UNR) {
-    double a[UNR][R];
-#pragma unroll
-    for (int t = 0; t < UNR; ++t) {
-      const int i = c + 64 * t + lane;
-#pragma unroll
-      for (int q = 0; q < R; ++q) a[t][q] = (i < ce[q]) ? F[(int64_t)(j0 + wave + NW * q) * m + i] : 0.0;
-    }
-#pragma unroll
-    for (int t = 0; t < UNR; ++t) {
-      const int i = c + 64 * t + lane;
-      if (i < cmax) {
-#pragma unroll
-        for (int u = 0; u < P; ++u) {
-          const double vi = sv[i * P + u];
-#pragma unroll
-          for (int q = 0; q < R; ++q) acc[q * P + u] += a[t][q] * vi;
-        }
-      }
-    }
-  }
-  multi_reduce<V>(acc, lane);
-  if (lane < V) {
-    const int idx = multi_reduce_index<V>(lane);
-    const int r = j0 + wave + NW * (idx / P), u = idx % P;
-    if (r < m) {
-      if (r < s2) {
-        fvec2[(2 * np + r) * P + u] = acc[0] / delta[2 * np + r];
-      } else {
-        double w[P];
-        gather_rhs<P>(w, f, r, s2, N, ldx, leaf_level, np, fs2, fnode_ptr, fnodes, cinv0, cinv1, nullptr, fvec);
-        double wu = w[0];
-#pragma unroll
-        for (int q = 1; q < P; ++q) wu = (u == q) ? w[q] : wu;
-        fvec[(2 * np + r) * P + u] = wu - acc[0];
-      }
-    }
-  }
-}
-
-// Backward sweep, row form: x_j = sum_{i >= j} [L11^-1 ; Z](i, j) v_i with v = [ys ; -x_b] staged in LDS.
-// Column j of the lower storage is contiguous in i, so a wave reads 512-byte runs; a wave owns R rows
-// (j0 + wave + NW q) and keeps R x 8/R loads in flight; a block (NW waves) shares one staged vector for NW R rows.
-template <int P, int NW, int R>
-__global__ __launch_bounds__(NW * 64) void k_bwd_rows(const int2* __restrict__ blk, int N, int64_t ldx, const int32_t* __restrict__ fs2,
-                                                      const int32_t* __restrict__ fm, const int64_t* __restrict__ foff,
-                                                      const int64_t* __restrict__ fnode_ptr,
-                                                      const int32_t* __restrict__ fnodes, const double* __restrict__ front,
-                                                      const double* __restrict__ fvec2, double* __restrict__ x) {
-  extern __shared__ double sv[];
-  constexpr int RB = NW * R, UNR = 8 / R, V = R * P;
-  const int2 job = blk[blockIdx.x];
-  const int f = job.x;
-  const int m = fm[f], s2 = fs2[f];
-  const int j0 = job.y * RB;
-  const int64_t np = fnode_ptr[f];
-  stage_bwd<P>(sv, j0 & ~63, m, s2, N, ldx, np, fnodes, fvec2, x);
-  __syncthreads();
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const double* F = front + foff[f];
-  int jq[R];
-#pragma unroll
-  for (int q = 0; q < R; ++q) {
-    const int j = j0 + wave + NW * q;
-    jq[q] = j < s2 ? j : m;                                   // rows past the owned block: every term masked
-  }
-  // the lane that will hold output (q, u) after the reduction looks its node up now, under the matrix loads
-  const int oidx = multi_reduce_index<V>(lane & (V - 1));
-  const int oj = j0 + wave + NW * (oidx / P);
-  const int onode = (lane < V && oj < s2) ? fnodes[np + (oj >> 1)] : -1;
-  double acc[V];
-#pragma unroll
-  for (int v = 0; v < V; ++v) acc[v] = 0.0;
-  for (int c = (j0 + wave) & ~63; c < m; c += 64 * UNR) {
-    double a[UNR][R];
-#pragma unroll
-    for (int t = 0; t < UNR; ++t) {
-      const int i = c + 64 * t + lane;
-#pragma unroll
-      for (int q = 0; q < R; ++q) a[t][q] = (i < m && i >= jq[q]) ? F[i + (int64_t)jq[q] * m] : 0.0;
-    }
-#pragma unroll
-    for (int t = 0; t < UNR; ++t) {
-      const int i = c + 64 * t + lane;
-      if (i < m) {
-#pragma unroll
-        for (int u = 0; u < P; ++u) {
-          const double vi = sv[i * P + u];
-#pragma unroll
-          for (int q = 0; q < R; ++q) acc[q * P + u] += a[t][q] * vi;
-        }
-      }
-    }
-  }
-  multi_reduce<V>(acc, lane);
-  if (onode >= 0) x[vidx<P>((int64_t)(oj & 1) * N + onode, oidx % P, ldx)] = acc[0];
-}
-
-// columns (ld) -> interleaved [i][P] and back
-template <int P>
-__global__ __launch_bounds__(256) void k_interleave(int64_t n, const double* __restrict__ cols, int64_t ld,
-                                                    double* __restrict__ il) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-#pragma unroll
-  for (int u = 0; u < P; ++u) il[i * P + u] = cols[(int64_t)u * ld + i];
-}
-
-// the sweeps never write the Dirichlet DOFs of the interleaved result: they are set to zero here (bmask), so the
-// result buffer needs no memset per solve
-template <int P>
-__global__ __launch_bounds__(256) void k_deinterleave(int64_t n, int N, const uint8_t* __restrict__ bmask,
-                                                      const double* __restrict__ il, double* __restrict__ cols, int64_t ld) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  const bool fixed = bmask[i < N ? i : i - N] != 0;
-#pragma unroll
-  for (int u = 0; u < P; ++u) cols[(int64_t)u * ld + i] = fixed ? 0.0 : il[i * P + u];
-}
-
 }  // namespace
 
 void launch_factor(plfem_ctx* c, double sigma, int stop_level, int stop_step, int stop_stage) {
@@ -1011,74 +648,6 @@ void launch_factor(plfem_ctx* c, double sigma, int stop_level, int stop_step, in
     }
     if (lev == stop_level && stop_stage == 5) return;
   }
-}
-
-template <int P>
-static void launch_solve_p(plfem_ctx* c, const double* rhs, double* x, int64_t ldx) {
-  hipStream_t st = c->stream;
-  // (interleaved results, ldx == 0, get their Dirichlet entries zeroed by k_deinterleave)
-  for (int u = 0; u < P && ldx != 0; ++u) (void)hipMemsetAsync(x + (int64_t)u * ldx, 0, sizeof(double) * c->n2, st);
-  // Kernel form by level: fwd_block_rows / bwd_block_rows (device.h); workgroups come from the compact launch
-  // lists of the context (no empty workgroups, large fronts first).  Measured at C1 (P = 4): 4 waves per block in
-  // the forward tile kernel, 8 in every backward form, 2 rows per wave at the mid levels
-  // (scripts/gpu_trace_levels.sh prints the per-level table).
-  double sweep_total = 0.0;                     // algorithmic bytes of one whole sweep (either direction)
-  for (const LevelInfo& li : c->levels) sweep_total += li.sweep_bytes + 8.0 * (P - 1) * li.sweep_vec_doubles;
-  const int pid_fwd = prof_open(c, PLFEM_PROF_FWD_SWEEP, sweep_total);
-  for (int lev = c->L; lev >= 0; --lev) {
-    const LevelInfo& li = c->levels[lev];
-    const int leaf = lev == c->L ? 1 : 0;
-    const size_t lds = sizeof(double) * P * (li.max_s2 + 1);
-    const int2* blk = c->d_blk + li.fwd_off;
-    if (li.fwd_n == 0) continue;
-    if (li.fwd_rows == 8)
-      hipLaunchKernelGGL((k_fwd_rows<P, 8, 1>), dim3(li.fwd_n), dim3(512), lds, st, blk, c->N, ldx, leaf,
-                         c->d_fs2, c->d_fm, c->d_foff, c->d_fnode_ptr, c->d_fnodes, c->d_cinv0, c->d_cinv1, c->d_front,
-                         c->d_delta, rhs, c->d_fvec, c->d_fvec2);
-    else if (li.fwd_rows == 16)
-      hipLaunchKernelGGL((k_fwd_rows<P, 8, 2>), dim3(li.fwd_n), dim3(512), lds, st, blk, c->N, ldx, leaf,
-                         c->d_fs2, c->d_fm, c->d_foff, c->d_fnode_ptr, c->d_fnodes, c->d_cinv0, c->d_cinv1, c->d_front,
-                         c->d_delta, rhs, c->d_fvec, c->d_fvec2);
-    else {
-      // optional live timing of this kernel (bench.py roofline): HIP events on the launch stream
-      const int pid = prof_open(c, PLFEM_PROF_KFWD, li.sweep_bytes + 8.0 * (P - 1) * li.sweep_vec_doubles);
-      hipLaunchKernelGGL((k_fwd<P, 4>), dim3(li.fwd_n), dim3(256), lds, st, blk, c->N, ldx, leaf,
-                         c->d_fs2, c->d_fm, c->d_foff, c->d_fnode_ptr, c->d_fnodes, c->d_cinv0, c->d_cinv1, c->d_front,
-                         c->d_delta, rhs, c->d_fvec, c->d_fvec2);
-      prof_close(c, pid);
-    }
-  }
-  prof_close(c, pid_fwd);
-  const int pid_bwd = prof_open(c, PLFEM_PROF_BWD_SWEEP, sweep_total);
-  for (int lev = 0; lev <= c->L; ++lev) {
-    const LevelInfo& li = c->levels[lev];
-    if (li.bwd_n == 0) continue;
-    const size_t lds = sizeof(double) * P * (li.max_m + 1);
-    const int2* blk = c->d_blk + li.bwd_off;
-    if (li.bwd_rows == 64)    // leaf fronts (about as many owned rows as boundary columns): tile form
-      hipLaunchKernelGGL((k_bwd<P, 8>), dim3(li.bwd_n), dim3(512), lds, st, blk, c->N, ldx,
-                         c->d_fs2, c->d_fm, c->d_foff, c->d_fnode_ptr, c->d_fnodes, c->d_front, c->d_fvec2, x);
-    else if (li.bwd_rows == 8)   // few large fronts: one row per wave, most blocks
-      hipLaunchKernelGGL((k_bwd_rows<P, 8, 1>), dim3(li.bwd_n), dim3(512), lds, st, blk, c->N, ldx,
-                         c->d_fs2, c->d_fm, c->d_foff, c->d_fnode_ptr, c->d_fnodes, c->d_front, c->d_fvec2, x);
-    else
-      hipLaunchKernelGGL((k_bwd_rows<P, 8, 2>), dim3(li.bwd_n), dim3(512), lds, st, blk, c->N, ldx,
-                         c->d_fs2, c->d_fm, c->d_foff, c->d_fnode_ptr, c->d_fnodes, c->d_front, c->d_fvec2, x);
-  }
-  prof_close(c, pid_bwd);
-}
-
-void launch_solve(plfem_ctx* c, const double* rhs, double* x) { launch_solve_p<1>(c, rhs, x, c->n2); }
-
-// BLOCK_P right-hand sides given as columns (ldx apart): interleaved inside the sweeps so that the P
-// values of a DOF are one 32-byte access (t1/t2 scratch: n2 x BLOCK_P each)
-// rhs_interleaved_in_t1: the caller's previous kernel already left the interleaved right-hand side in d_t1
-void launch_solve_block(plfem_ctx* c, const double* rhs, double* x, int64_t ldx, bool rhs_interleaved_in_t1) {
-  const unsigned grid = (unsigned)((c->n2 + 255) / 256);
-  if (!rhs_interleaved_in_t1)
-    hipLaunchKernelGGL(k_interleave<BLOCK_P>, dim3(grid), dim3(256), 0, c->stream, c->n2, rhs, ldx, c->d_t1);
-  launch_solve_p<BLOCK_P>(c, c->d_t1, c->d_t2, 0);
-  hipLaunchKernelGGL(k_deinterleave<BLOCK_P>, dim3(grid), dim3(256), 0, c->stream, c->n2, c->N, c->d_bmask, c->d_t2, x, ldx);
 }
 
 }  // namespace plfem

@@ -257,7 +257,7 @@ __global__ __launch_bounds__(256) void k_block_scale(int64_t n, const double* __
                                                      double* __restrict__ Vn, double* __restrict__ BVn, int64_t ldv,
                                                      const double* __restrict__ exp_src, int exp_n, double* __restrict__ exp_dst,
                                                      const int32_t* __restrict__ cnt_src, int32_t* __restrict__ cnt_dst,
-                                                     double* __restrict__ bv_il) {
+                                                     double* __restrict__ bv_front, const int32_t* __restrict__ npos, int N) {
   __shared__ double X[P * P];
   if (threadIdx.x < P * P) X[threadIdx.x] = Rinv[threadIdx.x];
   if (blockIdx.x == 0 && exp_dst) {
@@ -270,6 +270,13 @@ __global__ __launch_bounds__(256) void k_block_scale(int64_t n, const double* __
   double w[P], bw[P];
 #pragma unroll
   for (int q = 0; q < P; ++q) { w[q] = W[(int64_t)q * ldw + i]; bw[q] = BW[(int64_t)q * ldw + i]; }
+  // the next solve's right-hand side also goes out in the sweeps' layout (front order, P values per DOF together)
+  int64_t fo = -1;
+  if (bv_front) {
+    const int c = i >= N;
+    const int pos = npos[(int)(i - (int64_t)c * N)];
+    if (pos >= 0) fo = (2 * (int64_t)pos + c) * P;
+  }
 #pragma unroll
   for (int q = 0; q < P; ++q) {
     double a = 0.0, b = 0.0;
@@ -277,7 +284,7 @@ __global__ __launch_bounds__(256) void k_block_scale(int64_t n, const double* __
     for (int k = 0; k <= q; ++k) { a += w[k] * X[k + q * P]; b += bw[k] * X[k + q * P]; }
     Vn[(int64_t)q * ldv + i] = a;
     BVn[(int64_t)q * ldv + i] = b;
-    if (bv_il) bv_il[i * P + q] = b;     // the next solve's right-hand side, already in the sweeps' interleaved layout
+    if (fo >= 0) bv_front[fo + q] = b;
   }
 }
 
@@ -566,9 +573,9 @@ void launch_gram_chol_block(plfem_ctx* c, const double* W, const double* BW, int
 
 void launch_block_scale(plfem_ctx* c, const double* W, const double* BW, int64_t ldw, const double* Rinv, double* Vn,
                         double* BVn, int64_t ldv, const double* exp_src, int exp_n, double* exp_dst, int32_t* cnt_dst,
-                        double* bv_il) {
+                        double* bv_front) {
   hipLaunchKernelGGL(k_block_scale<BLOCK_P>, dim3((unsigned)((c->n2 + 255) / 256)), dim3(256), 0, c->stream, c->n2, W,
-                     BW, ldw, Rinv, Vn, BVn, ldv, exp_src, exp_n, exp_dst, c->d_counters, cnt_dst, bv_il);
+                     BW, ldw, Rinv, Vn, BVn, ldv, exp_src, exp_n, exp_dst, c->d_counters, cnt_dst, bv_front, c->d_npos, c->N);
 }
 
 // Start block of the Lanczos drivers: the fixed pseudo-random interior field (a 64-bit LCG stream, element e of the

@@ -1,0 +1,586 @@
+// gfx950 kernels: the two solve sweeps of the multifrontal shift-invert operator (lu.solve of the reference's
+// eigsh(..., sigma=...): scipy arpack.py:920-928 via reference solver_fem.py:197), P right-hand sides at a time
+// (P = 1: plfem_solve and the single-vector Lanczos; P = 4: block Lanczos -- every entry of the factors is read
+// once for P vectors).
+//
+//   forward : [ys; u] = [D^-1 L11^-1 r ;  w_b - Z r],     r = rhs_own + children's updates
+//   backward: x_own   = L11^-T ys - Z^T x_b
+//
+// One kernel per tree level and direction.  A workgroup of such a kernel is latency, not bandwidth (a few tens of
+// KB of factor entries each), so everything is laid out for ONE memory round trip before the arithmetic starts:
+//   * all vectors live in FRONT ORDER (entry (2 fnode_ptr[f] + i) * P + u for local DOF i of front f): the
+//     right-hand side arrives permuted (k_permute_in, or straight from the Lanczos block scaling), so staging a
+//     front's vector is a contiguous read, not node index -> value;
+//   * a front PUSHES its update u into its parent's rows (u0: pushed by left children, u1: by right children; prow =
+//     local node index in the parent, precomputed on the host), so the parent reads contiguous slots masked by its
+//     child maps instead of chasing index -> child vector;
+//   * the backward sweep keeps every front's complete local solution (xl); a child reads its boundary values from
+//     the parent's xl through prow -- the index loads do not depend on data and are requested first;
+//   * the epilogue operands (D, the row's own update slots, the push destination) and the first batch of matrix
+//     entries are requested BEFORE the staged vector is written to LDS, so they travel together.
+// Forward "tile" form (levels with many fronts): lane = output row, the waves split the columns, partial sums
+// meet in LDS in a fixed order; "row" form (at most 32 fronts): a wave owns R rows of [L11^-1 ; Z] and runs along
+// their columns in the mirrored upper storage.  Backward: row form (contiguous columns of the lower storage)
+// except at the leaf level.  The cross-lane sums of the row forms use multi_reduce.  Deterministic throughout.
+#include <algorithm>
+
+#include "device.h"
+
+namespace plfem {
+namespace {
+
+struct SweepArgs {
+  const int2* blk;
+  int leaf_level;
+  const int32_t *fs2, *fm;
+  const int64_t *foff, *fnode_ptr;
+  const int32_t *cinv0, *cinv1, *prow;
+  const double *front, *delta;
+  double *fr, *u0, *u1, *ys, *xl;
+};
+
+// Sums V (a power of two <= 64) per-lane values over the 64 lanes with V - 1 + log2(64 / V) shuffles instead of
+// 6 V: each butterfly step halves the values a lane still carries.  On return a[0] of lane l is the complete sum
+// of value multi_reduce_index<V>(l); lanes 0 .. V-1 cover every value once.  Fixed order, so deterministic.
+template <int V>
+__device__ __forceinline__ int multi_reduce_index(int lane) {
+  int idx = 0;
+#pragma unroll
+  for (int h = V / 2, s = 0; h >= 1; h >>= 1, ++s) idx += ((lane >> s) & 1) ? h : 0;
+  return idx;
+}
+
+template <int V>
+__device__ __forceinline__ void multi_reduce(double (&a)[V], int lane) {
+#pragma unroll
+  for (int h = V / 2, bit = 1; h >= 1; h >>= 1, bit <<= 1) {
+    const bool up = (lane & bit) != 0;
+#pragma unroll
+    for (int k = 0; k < h; ++k) {
+      const double send = up ? a[k] : a[k + h];
+      const double keep = up ? a[k + h] : a[k];
+      a[k] = keep + __shfl_xor(send, bit);
+    }
+  }
+#pragma unroll
+  for (int off = V; off < 64; off <<= 1) a[0] += __shfl_xor(a[0], off);
+}
+
+// ---- staging -------------------------------------------------------------------------------------------------
+// forward: r_i = fr_i (owned rows) + the children's pushes (masked by the child maps)
+template <int P>
+struct FwdStage {
+  double a[P], b0[P], b1[P];
+  int c0, c1;
+  __device__ __forceinline__ void request(const SweepArgs& A, int64_t np, int i, bool on) {
+    c0 = c1 = -1;
+#pragma unroll
+    for (int u = 0; u < P; ++u) { a[u] = 0.0; b0[u] = 0.0; b1[u] = 0.0; }
+    if (!on) return;
+    const int64_t e = (2 * np + i) * P;
+#pragma unroll
+    for (int u = 0; u < P; ++u) a[u] = A.fr[e + u];
+    if (!A.leaf_level) {
+      c0 = A.cinv0[np + (i >> 1)];
+      c1 = A.cinv1[np + (i >> 1)];
+#pragma unroll
+      for (int u = 0; u < P; ++u) { b0[u] = A.u0[e + u]; b1[u] = A.u1[e + u]; }   // unconditional: no dependent load
+    }
+  }
+  __device__ __forceinline__ double value(int u) const {
+    return a[u] + (c0 >= 0 ? b0[u] : 0.0) + (c1 >= 0 ? b1[u] : 0.0);
+  }
+};
+
+template <int P>
+__device__ __forceinline__ void stage_fwd(const SweepArgs& A, double* sv, int64_t np, int need, int T, int tid,
+                                          FwdStage<P>& first) {
+  for (int i = tid + T; i < need; i += T) {            // (fronts with more than T owned DOFs only)
+    FwdStage<P> s;
+    s.request(A, np, i, true);
+#pragma unroll
+    for (int u = 0; u < P; ++u) sv[i * P + u] = s.value(u);
+  }
+  first.request(A, np, tid, tid < need);
+}
+
+// epilogue of one forward row r (already summed: acc = [L11^-1 ; Z] r): owned rows -> ys = acc / D, boundary rows ->
+// u = w - acc pushed into the parent's slot.  The operands are requested by `request` before the sums.
+template <int P>
+struct FwdOut {
+  double dl, w0[P], w1[P];
+  int c0, c1;
+  int64_t dst;
+  __device__ __forceinline__ void request(const SweepArgs& A, int f, int64_t np, int s2, int m, int r) {
+    dl = 1.0;
+    c0 = c1 = -1;
+    dst = -1;
+#pragma unroll
+    for (int u = 0; u < P; ++u) { w0[u] = 0.0; w1[u] = 0.0; }
+    if (r >= m) return;
+    if (r < s2) { dl = A.delta[2 * np + r]; return; }
+    const int pr = A.prow[np + (r >> 1)];
+    if (!A.leaf_level) {
+      c0 = A.cinv0[np + (r >> 1)];
+      c1 = A.cinv1[np + (r >> 1)];
+      const int64_t e = (2 * np + r) * P;
+#pragma unroll
+      for (int u = 0; u < P; ++u) { w0[u] = A.u0[e + u]; w1[u] = A.u1[e + u]; }
+    }
+    if (pr >= 0) dst = (2 * A.fnode_ptr[(f - 1) >> 1] + 2 * pr + (r & 1)) * P;
+  }
+  __device__ __forceinline__ double w(int u) const { return (c0 >= 0 ? w0[u] : 0.0) + (c1 >= 0 ? w1[u] : 0.0); }
+};
+
+// ---- forward, tile form ------------------------------------------------------------------------------------------
+constexpr int TB = 8;      // matrix loads in flight per lane and trip
+template <int P, int NW>
+__global__ __launch_bounds__(NW * 64) void k_fwd(SweepArgs A) {
+  extern __shared__ double sv[];
+  __shared__ double red[NW * P * 64];
+  const int2 job = A.blk[blockIdx.x];
+  const int f = job.x;
+  const int m = A.fm[f], s2 = A.fs2[f];
+  const int r0 = job.y * 64;
+  const int64_t np = A.fnode_ptr[f];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int need = (r0 + 64 <= s2) ? r0 + 64 : s2;
+  const int r = r0 + lane;
+  const bool valid = r < m;
+  const int ce = valid ? ((r < s2) ? r + 1 : s2) : 0;               // rows of L11^-1 are lower triangular
+  const double* p = A.front + A.foff[f] + r;
+  FwdOut<P> out;
+  if (wave == 0) out.request(A, f, np, s2, m, r);
+  FwdStage<P> st;
+  stage_fwd<P>(A, sv, np, need, NW * 64, tid, st);
+  // first batch of this wave's columns (c == wave mod NW), requested before the staged vector is complete
+  double a0[TB];
+#pragma unroll
+  for (int t = 0; t < TB; ++t) a0[t] = (wave + NW * t < ce) ? p[(int64_t)(wave + NW * t) * m] : 0.0;
+  if (tid < need) {
+#pragma unroll
+    for (int u = 0; u < P; ++u) sv[tid * P + u] = st.value(u);
+  }
+  __syncthreads();
+  double acc[P];
+#pragma unroll
+  for (int u = 0; u < P; ++u) acc[u] = 0.0;
+#pragma unroll
+  for (int t = 0; t < TB; ++t) {
+    const int c = wave + NW * t;
+    if (c < ce) {
+#pragma unroll
+      for (int u = 0; u < P; ++u) acc[u] += a0[t] * sv[c * P + u];
+    }
+  }
+  for (int c = wave + NW * TB; c < ce; c += TB * NW) {
+    double a[TB];
+#pragma unroll
+    for (int t = 0; t < TB; ++t) a[t] = (c + NW * t < ce) ? p[(int64_t)(c + NW * t) * m] : 0.0;
+#pragma unroll
+    for (int t = 0; t < TB; ++t) {
+      if (c + NW * t < ce) {
+#pragma unroll
+        for (int u = 0; u < P; ++u) acc[u] += a[t] * sv[(c + NW * t) * P + u];
+      }
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < P; ++u) red[(wave * P + u) * 64 + lane] = acc[u];
+  __syncthreads();
+  if (wave == 0 && valid) {
+    double tot[P];
+#pragma unroll
+    for (int u = 0; u < P; ++u) {
+      double t = 0.0;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) t += red[(w * P + u) * 64 + lane];
+      tot[u] = t;
+    }
+    if (r < s2) {
+      const double di = 1.0 / out.dl;
+#pragma unroll
+      for (int u = 0; u < P; ++u) A.ys[(2 * np + r) * P + u] = tot[u] * di;
+    } else if (out.dst >= 0) {
+      double* d = ((f & 1) ? A.u0 : A.u1) + out.dst;
+#pragma unroll
+      for (int u = 0; u < P; ++u) d[u] = out.w(u) - tot[u];
+    }
+  }
+}
+
+// ---- forward, row form -------------------------------------------------------------------------------------------
+template <int P, int NW, int R>
+__global__ __launch_bounds__(NW * 64) void k_fwd_rows(SweepArgs A) {
+  extern __shared__ double sv[];
+  constexpr int RB = NW * R, UNR = 8 / R, V = R * P;
+  const int2 job = A.blk[blockIdx.x];
+  const int f = job.x;
+  const int m = A.fm[f], s2 = A.fs2[f];
+  const int j0 = job.y * RB;
+  const int64_t np = A.fnode_ptr[f];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int need = min(s2, j0 + RB);                      // rows < s2 only read r[0 .. row]
+  const double* F = A.front + A.foff[f];
+  int ce[R], cmax = 0;
+#pragma unroll
+  for (int q = 0; q < R; ++q) {
+    const int r = j0 + wave + NW * q;
+    ce[q] = r < m ? ((r < s2) ? r + 1 : s2) : 0;
+    cmax = max(cmax, ce[q]);
+  }
+  // the lane that will hold output (q, u) after the reduction requests that row's epilogue operands now
+  const int oidx = multi_reduce_index<V>(lane & (V - 1));
+  const int orow = j0 + wave + NW * (oidx / P);
+  FwdOut<P> out;
+  out.request(A, f, np, s2, m, lane < V ? orow : m);
+  FwdStage<P> st;
+  stage_fwd<P>(A, sv, np, need, NW * 64, tid, st);
+  double a0[UNR][R];
+#pragma unroll
+  for (int t = 0; t < UNR; ++t) {
+    const int i = 64 * t + lane;
+#pragma unroll
+    for (int q = 0; q < R; ++q) a0[t][q] = (i < ce[q]) ? F[(int64_t)(j0 + wave + NW * q) * m + i] : 0.0;
+  }
+  if (tid < need) {
+#pragma unroll
+    for (int u = 0; u < P; ++u) sv[tid * P + u] = st.value(u);
+  }
+  __syncthreads();
+  double acc[V];
+#pragma unroll
+  for (int v = 0; v < V; ++v) acc[v] = 0.0;
+#pragma unroll
+  for (int t = 0; t < UNR; ++t) {
+    const int i = 64 * t + lane;
+    if (i < cmax) {
+#pragma unroll
+      for (int u = 0; u < P; ++u) {
+        const double vi = sv[i * P + u];
+#pragma unroll
+        for (int q = 0; q < R; ++q) acc[q * P + u] += a0[t][q] * vi;
+      }
+    }
+  }
+  for (int c = 64 * UNR; c < cmax; c += 64 * UNR) {
+    double a[UNR][R];
+#pragma unroll
+    for (int t = 0; t < UNR; ++t) {
+      const int i = c + 64 * t + lane;
+#pragma unroll
+      for (int q = 0; q < R; ++q) a[t][q] = (i < ce[q]) ? F[(int64_t)(j0 + wave + NW * q) * m + i] : 0.0;
+    }
+#pragma unroll
+    for (int t = 0; t < UNR; ++t) {
+      const int i = c + 64 * t + lane;
+      if (i < cmax) {
+#pragma unroll
+        for (int u = 0; u < P; ++u) {
+          const double vi = sv[i * P + u];
+#pragma unroll
+          for (int q = 0; q < R; ++q) acc[q * P + u] += a[t][q] * vi;
+        }
+      }
+    }
+  }
+  multi_reduce<V>(acc, lane);
+  if (lane < V && orow < m) {
+    const int u = oidx % P;
+    if (orow < s2) {
+      A.ys[(2 * np + orow) * P + u] = acc[0] / out.dl;
+    } else if (out.dst >= 0) {
+      double wu = out.w(0);
+#pragma unroll
+      for (int q = 1; q < P; ++q) wu = (u == q) ? out.w(q) : wu;
+      (((f & 1) ? A.u0 : A.u1) + out.dst)[u] = wu - acc[0];
+    }
+  }
+}
+
+// ---- backward ------------------------------------------------------------------------------------------------------
+// stage v = [ys ; -x_b] of front f in LDS (entries >= lo only), [dof][P]; x_b comes from the parent's local solution
+// through prow.  The workgroup with publish = true also writes the boundary part of this front's own local solution
+// (its children will read it).  `first`: the entry of this thread in the first chunk, completed by finish().
+template <int P>
+struct BwdStage {
+  double v[P];
+  int pr, i;
+  bool own, on;
+  __device__ __forceinline__ void request_index(const SweepArgs& A, int64_t np, int s2, int i_, bool on_) {
+    i = i_;
+    on = on_;
+    own = i < s2;
+    pr = -1;
+    if (on && !own) pr = A.prow[np + (i >> 1)];
+    if (on && own) {
+#pragma unroll
+      for (int u = 0; u < P; ++u) v[u] = A.ys[(2 * np + i) * P + u];
+    }
+  }
+  __device__ __forceinline__ void request_value(const SweepArgs& A, int64_t npp) {
+    if (on && !own) {
+#pragma unroll
+      for (int u = 0; u < P; ++u) v[u] = pr >= 0 ? -A.xl[(2 * npp + 2 * pr + (i & 1)) * P + u] : 0.0;
+    }
+  }
+  __device__ __forceinline__ void finish(const SweepArgs& A, double* sv, int64_t np, bool publish) const {
+    if (!on) return;
+#pragma unroll
+    for (int u = 0; u < P; ++u) sv[i * P + u] = v[u];
+    if (publish && !own) {
+#pragma unroll
+      for (int u = 0; u < P; ++u) A.xl[(2 * np + i) * P + u] = -v[u];
+    }
+  }
+};
+
+template <int P>
+__device__ __forceinline__ void stage_bwd_rest(const SweepArgs& A, double* sv, int lo, int m, int s2, int64_t np,
+                                               int64_t npp, int T, int tid, bool publish) {
+  for (int i = lo + tid + T; i < m; i += T) {             // (fronts with more than T DOFs behind lo only)
+    BwdStage<P> s;
+    s.request_index(A, np, s2, i, true);
+    s.request_value(A, npp);
+    s.finish(A, sv, np, publish);
+  }
+}
+
+template <int P, int NW>
+__global__ __launch_bounds__(NW * 64) void k_bwd(SweepArgs A) {
+  extern __shared__ double sv[];
+  __shared__ double red[NW * P * 64];
+  const int2 job = A.blk[blockIdx.x];
+  const int f = job.x;
+  const int m = A.fm[f], s2 = A.fs2[f];
+  const int r0 = job.y * 64;
+  const int64_t np = A.fnode_ptr[f];
+  const int64_t npp = f > 0 ? A.fnode_ptr[(f - 1) >> 1] : 0;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const bool publish = job.y == 0 && !A.leaf_level;
+  BwdStage<P> st;
+  st.request_index(A, np, s2, r0 + tid, r0 + tid < m);
+  const int r = r0 + lane;
+  const bool valid = r < s2;
+  // element (j = r, i) of [L11^-T | Z^T] at F[r + i m], i in [r, m)
+  const double* p = A.front + A.foff[f] + r;
+  const int cb = valid ? r : m, ce = m;
+  const int cstart = cb + ((wave - cb) & (NW - 1));
+  double a0[TB];
+#pragma unroll
+  for (int t = 0; t < TB; ++t) a0[t] = (cstart + NW * t < ce) ? p[(int64_t)(cstart + NW * t) * m] : 0.0;
+  st.request_value(A, npp);
+  stage_bwd_rest<P>(A, sv, r0, m, s2, np, npp, NW * 64, tid, publish);
+  st.finish(A, sv, np, publish);
+  __syncthreads();
+  double acc[P];
+#pragma unroll
+  for (int u = 0; u < P; ++u) acc[u] = 0.0;
+#pragma unroll
+  for (int t = 0; t < TB; ++t) {
+    const int c = cstart + NW * t;
+    if (c < ce) {
+#pragma unroll
+      for (int u = 0; u < P; ++u) acc[u] += a0[t] * sv[c * P + u];
+    }
+  }
+  for (int c = cstart + NW * TB; c < ce; c += TB * NW) {
+    double a[TB];
+#pragma unroll
+    for (int t = 0; t < TB; ++t) a[t] = (c + NW * t < ce) ? p[(int64_t)(c + NW * t) * m] : 0.0;
+#pragma unroll
+    for (int t = 0; t < TB; ++t) {
+      if (c + NW * t < ce) {
+#pragma unroll
+        for (int u = 0; u < P; ++u) acc[u] += a[t] * sv[(c + NW * t) * P + u];
+      }
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < P; ++u) red[(wave * P + u) * 64 + lane] = acc[u];
+  __syncthreads();
+  if (wave == 0 && valid) {
+#pragma unroll
+    for (int u = 0; u < P; ++u) {
+      double t = 0.0;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) t += red[(w * P + u) * 64 + lane];
+      A.xl[(2 * np + r) * P + u] = t;
+    }
+  }
+}
+
+// Backward sweep, row form: x_j = sum_{i >= j} [L11^-1 ; Z](i, j) v_i with v = [ys ; -x_b] staged in LDS.
+// Column j of the lower storage is contiguous in i, so a wave reads 512-byte runs; a wave owns R rows
+// (j0 + wave + NW q) and keeps R x 8/R loads in flight; a block (NW waves) shares one staged vector for NW R rows.
+template <int P, int NW, int R>
+__global__ __launch_bounds__(NW * 64) void k_bwd_rows(SweepArgs A) {
+  extern __shared__ double sv[];
+  constexpr int RB = NW * R, UNR = 8 / R, V = R * P;
+  const int2 job = A.blk[blockIdx.x];
+  const int f = job.x;
+  const int m = A.fm[f], s2 = A.fs2[f];
+  const int j0 = job.y * RB;
+  const int64_t np = A.fnode_ptr[f];
+  const int64_t npp = f > 0 ? A.fnode_ptr[(f - 1) >> 1] : 0;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const bool publish = job.y == 0 && !A.leaf_level;
+  const int lo = j0 & ~63;
+  BwdStage<P> st;
+  st.request_index(A, np, s2, lo + tid, lo + tid < m);
+  const double* F = A.front + A.foff[f];
+  int jq[R];
+#pragma unroll
+  for (int q = 0; q < R; ++q) {
+    const int j = j0 + wave + NW * q;
+    jq[q] = j < s2 ? j : m;                                   // rows past the owned block: every term masked
+  }
+  const int c0 = (j0 + wave) & ~63;
+  double a0[UNR][R];
+#pragma unroll
+  for (int t = 0; t < UNR; ++t) {
+    const int i = c0 + 64 * t + lane;
+#pragma unroll
+    for (int q = 0; q < R; ++q) a0[t][q] = (i < m && i >= jq[q]) ? F[i + (int64_t)jq[q] * m] : 0.0;
+  }
+  st.request_value(A, npp);
+  stage_bwd_rest<P>(A, sv, lo, m, s2, np, npp, NW * 64, tid, publish);
+  st.finish(A, sv, np, publish);
+  __syncthreads();
+  const int oidx = multi_reduce_index<V>(lane & (V - 1));
+  const int oj = j0 + wave + NW * (oidx / P);
+  double acc[V];
+#pragma unroll
+  for (int v = 0; v < V; ++v) acc[v] = 0.0;
+#pragma unroll
+  for (int t = 0; t < UNR; ++t) {
+    const int i = c0 + 64 * t + lane;
+    if (i < m) {
+#pragma unroll
+      for (int u = 0; u < P; ++u) {
+        const double vi = sv[i * P + u];
+#pragma unroll
+        for (int q = 0; q < R; ++q) acc[q * P + u] += a0[t][q] * vi;
+      }
+    }
+  }
+  for (int c = c0 + 64 * UNR; c < m; c += 64 * UNR) {
+    double a[UNR][R];
+#pragma unroll
+    for (int t = 0; t < UNR; ++t) {
+      const int i = c + 64 * t + lane;
+#pragma unroll
+      for (int q = 0; q < R; ++q) a[t][q] = (i < m && i >= jq[q]) ? F[i + (int64_t)jq[q] * m] : 0.0;
+    }
+#pragma unroll
+    for (int t = 0; t < UNR; ++t) {
+      const int i = c + 64 * t + lane;
+      if (i < m) {
+#pragma unroll
+        for (int u = 0; u < P; ++u) {
+          const double vi = sv[i * P + u];
+#pragma unroll
+          for (int q = 0; q < R; ++q) acc[q * P + u] += a[t][q] * vi;
+        }
+      }
+    }
+  }
+  multi_reduce<V>(acc, lane);
+  if (lane < V && oj < s2) A.xl[(2 * np + oj) * P + oidx % P] = acc[0];
+}
+
+// ---- global order <-> front order ---------------------------------------------------------------------------------
+// fr[(2 npos[node] + c) P + u] = rhs[u ldx + c N + node]  (Dirichlet nodes: npos = -1, nothing to do)
+template <int P>
+__global__ __launch_bounds__(256) void k_permute_in(int64_t n2, int N, const int32_t* __restrict__ npos,
+                                                    const double* __restrict__ rhs, int64_t ldx, double* __restrict__ fr) {
+  const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (g >= n2) return;
+  const int c = g >= N, node = (int)(g - (int64_t)c * N);
+  const int pos = npos[node];
+  if (pos < 0) return;
+#pragma unroll
+  for (int u = 0; u < P; ++u) fr[(2 * (int64_t)pos + c) * P + u] = rhs[(int64_t)u * ldx + g];
+}
+
+// x[u ldx + g] = xl[(2 npos[node] + c) P + u], Dirichlet entries = 0 (the result needs no memset)
+template <int P>
+__global__ __launch_bounds__(256) void k_permute_out(int64_t n2, int N, const int32_t* __restrict__ npos,
+                                                     const double* __restrict__ xl, double* __restrict__ x, int64_t ldx) {
+  const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (g >= n2) return;
+  const int c = g >= N, node = (int)(g - (int64_t)c * N);
+  const int pos = npos[node];
+#pragma unroll
+  for (int u = 0; u < P; ++u) x[(int64_t)u * ldx + g] = pos >= 0 ? xl[(2 * (int64_t)pos + c) * P + u] : 0.0;
+}
+
+template <int P>
+void sweeps(plfem_ctx* c) {
+  hipStream_t st = c->stream;
+  SweepArgs A;
+  A.fs2 = c->d_fs2; A.fm = c->d_fm; A.foff = c->d_foff; A.fnode_ptr = c->d_fnode_ptr;
+  A.cinv0 = c->d_cinv0; A.cinv1 = c->d_cinv1; A.prow = c->d_prow;
+  A.front = c->d_front; A.delta = c->d_delta;
+  A.fr = c->d_fvec; A.u0 = c->d_u0; A.u1 = c->d_u1; A.ys = c->d_fvec2; A.xl = c->d_xl;
+  double sweep_total = 0.0;                     // algorithmic bytes of one whole sweep (either direction)
+  for (const LevelInfo& li : c->levels) sweep_total += li.sweep_bytes + 8.0 * (P - 1) * li.sweep_vec_doubles;
+  // Kernel form by level: fwd_block_rows / bwd_block_rows (device.h); workgroups come from the compact launch
+  // lists of the context (no empty workgroups, large fronts first).
+  const int pid_fwd = prof_open(c, PLFEM_PROF_FWD_SWEEP, sweep_total);
+  for (int lev = c->L; lev >= 0; --lev) {
+    const LevelInfo& li = c->levels[lev];
+    if (li.fwd_n == 0) continue;
+    A.leaf_level = lev == c->L ? 1 : 0;
+    A.blk = c->d_blk + li.fwd_off;
+    const size_t lds = sizeof(double) * P * (li.max_s2 + 1);
+    if (li.fwd_rows == 8)
+      hipLaunchKernelGGL((k_fwd_rows<P, 8, 1>), dim3(li.fwd_n), dim3(512), lds, st, A);
+    else if (li.fwd_rows == 16)
+      hipLaunchKernelGGL((k_fwd_rows<P, 8, 2>), dim3(li.fwd_n), dim3(512), lds, st, A);
+    else {
+      // optional live timing of this kernel (bench.py roofline): HIP events on the launch stream
+      const int pid = prof_open(c, PLFEM_PROF_KFWD, li.sweep_bytes + 8.0 * (P - 1) * li.sweep_vec_doubles);
+      hipLaunchKernelGGL((k_fwd<P, 4>), dim3(li.fwd_n), dim3(256), lds, st, A);
+      prof_close(c, pid);
+    }
+  }
+  prof_close(c, pid_fwd);
+  const int pid_bwd = prof_open(c, PLFEM_PROF_BWD_SWEEP, sweep_total);
+  for (int lev = 0; lev <= c->L; ++lev) {
+    const LevelInfo& li = c->levels[lev];
+    if (li.bwd_n == 0) continue;
+    A.leaf_level = lev == c->L ? 1 : 0;
+    A.blk = c->d_blk + li.bwd_off;
+    const size_t lds = sizeof(double) * P * (li.max_m + 1);
+    if (li.bwd_rows == 64)    // leaf fronts (about as many owned rows as boundary columns): tile form
+      hipLaunchKernelGGL((k_bwd<P, 8>), dim3(li.bwd_n), dim3(512), lds, st, A);
+    else if (li.bwd_rows == 8)   // few large fronts: one row per wave, most blocks
+      hipLaunchKernelGGL((k_bwd_rows<P, 8, 1>), dim3(li.bwd_n), dim3(512), lds, st, A);
+    else
+      hipLaunchKernelGGL((k_bwd_rows<P, 8, 2>), dim3(li.bwd_n), dim3(512), lds, st, A);
+  }
+  prof_close(c, pid_bwd);
+}
+
+}  // namespace
+
+void launch_solve(plfem_ctx* c, const double* rhs, double* x) {
+  const unsigned grid = (unsigned)((c->n2 + 255) / 256);
+  hipLaunchKernelGGL(k_permute_in<1>, dim3(grid), dim3(256), 0, c->stream, c->n2, c->N, c->d_npos, rhs, c->n2, c->d_fvec);
+  sweeps<1>(c);
+  hipLaunchKernelGGL(k_permute_out<1>, dim3(grid), dim3(256), 0, c->stream, c->n2, c->N, c->d_npos, c->d_xl, x, c->n2);
+}
+
+// BLOCK_P right-hand sides given as columns (ldx apart); inside the sweeps the P values of a DOF are one 32-byte
+// access.  rhs_in_front_order: the caller's previous kernel (k_block_scale) already left the right-hand side in the
+// sweeps' layout (context buffer d_fvec)
+void launch_solve_block(plfem_ctx* c, const double* rhs, double* x, int64_t ldx, bool rhs_in_front_order) {
+  const unsigned grid = (unsigned)((c->n2 + 255) / 256);
+  if (!rhs_in_front_order)
+    hipLaunchKernelGGL(k_permute_in<BLOCK_P>, dim3(grid), dim3(256), 0, c->stream, c->n2, c->N, c->d_npos, rhs, ldx, c->d_fvec);
+  sweeps<BLOCK_P>(c);
+  hipLaunchKernelGGL(k_permute_out<BLOCK_P>, dim3(grid), dim3(256), 0, c->stream, c->n2, c->N, c->d_npos, c->d_xl, x, ldx);
+}
+
+}  // namespace plfem

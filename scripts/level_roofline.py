@@ -38,7 +38,8 @@ nblk = {}
 for L in range(nlev):
     s_, m_ = fs[lev == L], fs[lev == L] + fb[lev == L]
     nblk[("fwd", int(np.ceil(m_ / fwd_rows(cnt[L])).sum()))] = L
-    nblk[("bwd", int(np.ceil(s_ / bwd_rows(cnt[L], L == nlev - 1)).sum()))] = L
+    # (a non-leaf front without owned DOFs still gets one backward workgroup: it republishes its boundary values)
+    nblk[("bwd", int(np.ceil(np.maximum(s_, 0 if L == nlev - 1 else 1) / bwd_rows(cnt[L], L == nlev - 1)).sum()))] = L
 
 rows = list(csv.DictReader(open(sys.argv[1])))
 agg = {}

@@ -561,3 +561,22 @@ def test_front_too_large_for_the_lds_staging(gpu_device, built_library):
     assert symb.info["max_front"] > 20000
     with pytest.raises(ValueError, match="largest front has .* DOFs.*LDS"):
         _native.Context(symb, gpu_device)
+
+
+def test_loss_consumer_takes_the_mode_records_of_a_real_solve(medium, gpu_device):
+    """Row f2: the reference's documented consumer of the path (losses.py:742-825) fed with the records of a GPU
+    solve -- the key contract of row a9 end to end (n_eff, beta, P_x, P_y, PDL_dB, confinement, is_vectorial) -- and
+    the same numbers from the oracle's records of the same mesh."""
+    from pl_fem_vectoriel_amd.losses import LossCalculator
+    P = medium
+    solver = TrueVectorialMaxwellSolver(P.g, device=gpu_device)
+    modes = solver.solve_vectorial_modes(P.mesh, n_modes_target=10)
+    ref_modes = hfield.solve_vectorial_modes(P.g, P.om, n_modes_target=10, fused=True)
+    for direction in ("mux", "demux"):
+        got = LossCalculator.calculate_physical_losses(modes, P.g, direction, 1550.0)
+        ref = LossCalculator.calculate_physical_losses(ref_modes, P.g, direction, 1550.0)
+        assert got["success"] and got["is_vectorial"] and got["n_modes_used"] == len(modes) == 22
+        for key in ("IL_dB", "MDL_dB", "PDL_dB", "crosstalk_dB", "radiation_loss_dB_per_m", "avg_confinement"):
+            assert np.isfinite(got[key])
+            assert abs(got[key] - ref[key]) <= 1e-6 * max(1.0, abs(ref[key])), (direction, key)
+    assert 0.0 < got["IL_dB"] < 40.0 and -40.0 <= got["crosstalk_dB"] <= -15.0
