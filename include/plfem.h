@@ -15,7 +15,9 @@
  *    pointer must live.  The library never frees caller memory;
  *  - DOF order of all full-length vectors is the reference's block order (solver_fem.py:166):
  *    x[0:N] = Hx DOFs, x[N:2N] = Hy DOFs, N = number of P2 DOFs including boundary DOFs, whose
- *    entries are kept at zero (Dirichlet H = 0, solver_fem.py:179-182);
+ *    entries are kept at zero (Dirichlet H = 0, solver_fem.py:179-182); a context of the scalar solver
+ *    (plfem_symbolic_create_ex with one unknown per node) has vectors of length N and, with dirichlet = 0, no
+ *    eliminated DOFs -- wherever a size below says 2N / 2 nsolve it is dofs_per_node x N / nsolve;
  *  - all floating point data is IEEE double; indices are int32 (nnz < 2^31), offsets int64;
  *  - a plfem_ctx owns one HIP stream's worth of state; contexts are independent: the only process-wide
  *    state is two mutex-protected recycling pools (pinned staging blocks, timing events), so different
@@ -53,6 +55,12 @@ typedef struct plfem_ctx plfem_ctx;           /* device + stream + workspaces fo
 int plfem_symbolic_create(int32_t nv, int32_t ne, const double* p_host, const int32_t* t_host,
                           int32_t leaf_elems, int32_t nthreads, plfem_symbolic** out,
                           char* err, int32_t errlen);
+/* The same analysis for the scalar solver of the reference (ScalarHelmholtzSolver.solve, solver_fem.py:245-276,
+ * SURVEY.md row f3): dofs_per_node = 1 (one unknown per P2 node; 2 = the vectorial H-field path) and
+ * dirichlet = 0 (natural boundary: every node is kept, solver_fem.py:259 passes the full matrices to eigsh). */
+int plfem_symbolic_create_ex(int32_t nv, int32_t ne, const double* p_host, const int32_t* t_host,
+                             int32_t leaf_elems, int32_t nthreads, int32_t dofs_per_node, int32_t dirichlet,
+                             plfem_symbolic** out, char* err, int32_t errlen);
 void plfem_symbolic_destroy(plfem_symbolic* sym);
 
 /* info[] indices */
@@ -61,7 +69,7 @@ enum {
   PLFEM_INFO_NNZ, PLFEM_INFO_LEVELS, PLFEM_INFO_NFRONTS, PLFEM_INFO_FRONT_DOUBLES,
   PLFEM_INFO_MAX_FRONT, PLFEM_INFO_SOLVE_ENTRIES, PLFEM_INFO_FACTOR_FLOPS,
   PLFEM_INFO_T_NUMBERING_US, PLFEM_INFO_T_PATTERN_US, PLFEM_INFO_T_TREE_US, PLFEM_INFO_T_FRONTS_US,
-  PLFEM_INFO_COUNT
+  PLFEM_INFO_DOFS_PER_NODE, PLFEM_INFO_COUNT
 };
 int plfem_symbolic_info(const plfem_symbolic* sym, int64_t* info /* [PLFEM_INFO_COUNT] */);
 
@@ -125,6 +133,14 @@ int plfem_synchronize(plfem_ctx* ctx);
  * ------------------------------------------------------------------------------------------- */
 int plfem_assemble_hfield(plfem_ctx* ctx, const double* cores_host, int32_t ncore, double eps_core,
                           double eps_clad, double k0, double alpha_p);
+
+/* Scalar Helmholtz pencil of the reference's ScalarHelmholtzSolver.solve, for a context whose
+ * analysis has one unknown per node:
+ * Replaces: stiff / mass_s / eps_m forms + 3 x asm() and K - k0^2 Me   reference solver_fem.py:251-259
+ * Fills the AXX slot with K - k0^2 M_eps (the "A" of plfem_spmv / plfem_factor / plfem_lanczos_shift_invert /
+ * plfem_residuals), the MINV slot with the plain mass matrix M (their "B"); all vectors then have length N. */
+int plfem_assemble_scalar(plfem_ctx* ctx, const double* cores_host, int32_t ncore, double eps_core,
+                          double eps_clad, double k0);
 
 enum { PLFEM_BLK_AXX = 0, PLFEM_BLK_AXY, PLFEM_BLK_AYX, PLFEM_BLK_AYY, PLFEM_BLK_MINV,
        PLFEM_BLK_DXX, PLFEM_BLK_DXY, PLFEM_BLK_DYY, PLFEM_BLK_COUNT };

@@ -21,7 +21,7 @@ PLFEM_OK = 0
 PLFEM_EINVAL, PLFEM_EMESH, PLFEM_EHIP, PLFEM_ENOCONV, PLFEM_ESTATE, PLFEM_ESINGULAR = -1, -2, -3, -4, -5, -6
 BLOCKS = ("Axx", "Axy", "Ayx", "Ayy", "Minv", "Dxx", "Dxy", "Dyy")
 INFO_NAMES = ("nv", "ne", "nedges", "N", "nsolve", "nnz", "levels", "nfronts", "front_doubles", "max_front",
-              "solve_entries", "factor_flops", "t_numbering_us", "t_pattern_us", "t_tree_us", "t_fronts_us")
+              "solve_entries", "factor_flops", "t_numbering_us", "t_pattern_us", "t_tree_us", "t_fronts_us", "dofs_per_node")
 POST_NAMES = ("norm", "div_energy", "core_x", "core_y", "all_x", "all_y")
 
 # every symbol include/plfem.h declares (tests check the library exports all of them)
@@ -32,7 +32,7 @@ EXPORTS = (
     "plfem_solve", "plfem_lanczos_shift_invert", "plfem_postprocess", "plfem_timings",
     "plfem_debug_factor_until", "plfem_debug_copy", "plfem_profile_begin", "plfem_profile_end",
     "plfem_mesh_edge_count", "plfem_mesh_refine", "plfem_debug_symeig", "plfem_debug_symeig_band",
-    "plfem_residuals", "plfem_set_option",
+    "plfem_residuals", "plfem_set_option", "plfem_symbolic_create_ex", "plfem_assemble_scalar",
 )
 MAX_NCV = 320                       # PLFEM_MAX_NCV of include/plfem.h
 PROF_SLOTS = ("k_fwd", "fwd_sweep", "bwd_sweep", "spmv_b")
@@ -80,6 +80,8 @@ def load_library() -> ctypes.CDLL:
     c_void_pp = ctypes.POINTER(ctypes.c_void_p)
     lib.plfem_symbolic_create.argtypes = [ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p,
                                           ctypes.c_int32, ctypes.c_int32, c_void_pp, ctypes.c_char_p, ctypes.c_int32]
+    lib.plfem_symbolic_create_ex.argtypes = [ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32,
+                                             ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, c_void_pp, ctypes.c_char_p, ctypes.c_int32]
     lib.plfem_symbolic_destroy.argtypes = [ctypes.c_void_p]
     lib.plfem_symbolic_destroy.restype = None
     lib.plfem_symbolic_info.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
@@ -96,6 +98,8 @@ def load_library() -> ctypes.CDLL:
     lib.plfem_synchronize.argtypes = [ctypes.c_void_p]
     lib.plfem_assemble_hfield.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_double,
                                           ctypes.c_double, ctypes.c_double, ctypes.c_double]
+    lib.plfem_assemble_scalar.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_double,
+                                          ctypes.c_double, ctypes.c_double]
     lib.plfem_block_values_dev.argtypes = [ctypes.c_void_p, ctypes.c_int32, c_void_pp]
     lib.plfem_block_values_host.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p]
     lib.plfem_spmv.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]
@@ -187,7 +191,7 @@ def debug_symeig_band(a, b: int, nsel: int):
 class Symbolic:
     """Mesh-only analysis (P2 numbering, CSR pattern, front tree).  Host only — needs no GPU."""
 
-    def __init__(self, p, t, leaf_elems: int = 0, nthreads: int = 0):
+    def __init__(self, p, t, leaf_elems: int = 0, nthreads: int = 0, dofs_per_node: int = 2, dirichlet: bool = True):
         lib = load_library()
         p = np.ascontiguousarray(np.asarray(p, dtype=np.float64))
         t = np.ascontiguousarray(np.asarray(t, dtype=np.int32))
@@ -199,8 +203,8 @@ class Symbolic:
             nthreads = int(os.environ.get("PLFEM_HOST_THREADS", min(os.cpu_count() or 1, 8)))
         if leaf_elems <= 0:
             leaf_elems = int(os.environ.get("PLFEM_LEAF_ELEMS", 0))
-        rc = lib.plfem_symbolic_create(p.shape[1], t.shape[1], _ptr(p), _ptr(t), int(leaf_elems), int(nthreads),
-                                       ctypes.byref(h), err, 512)
+        rc = lib.plfem_symbolic_create_ex(p.shape[1], t.shape[1], _ptr(p), _ptr(t), int(leaf_elems), int(nthreads),
+                                          int(dofs_per_node), 1 if dirichlet else 0, ctypes.byref(h), err, 512)
         if rc != PLFEM_OK:
             raise ValueError(f"plfem_symbolic_create failed ({rc}): {err.value.decode()}")
         self._h = h
@@ -210,6 +214,7 @@ class Symbolic:
         self.info = {k: int(info[i]) for i, k in enumerate(INFO_NAMES)}
         for k in ("nv", "ne", "nedges", "N", "nsolve", "nnz"):
             setattr(self, k, self.info[k])
+        self.dofs_per_node = self.info["dofs_per_node"]
 
     def array(self, name: str) -> np.ndarray:
         nb = self._lib.plfem_symbolic_array_bytes(self._h, name.encode())
@@ -272,7 +277,8 @@ class Context:
         self._h = h
         self.max_ncv = int(max_ncv)
         self.N = sym.N
-        self.n2 = 2 * sym.N
+        self.dpn = sym.dofs_per_node
+        self.n2 = self.dpn * sym.N            # length of every global vector
 
     # -- helpers ----------------------------------------------------------------------------------
     def _check(self, rc, what):
@@ -295,6 +301,11 @@ class Context:
         c, n = self._cores(cores)
         self._check(self._lib.plfem_assemble_hfield(self._h, _ptr(c), n, float(eps_core), float(eps_clad),
                                                     float(k0), float(alpha_p)), "plfem_assemble_hfield")
+
+    def assemble_scalar(self, cores, eps_core, eps_clad, k0):
+        c, n = self._cores(cores)
+        self._check(self._lib.plfem_assemble_scalar(self._h, _ptr(c), n, float(eps_core), float(eps_clad), float(k0)),
+                    "plfem_assemble_scalar")
 
     def block_values(self, name: str) -> np.ndarray:
         out = np.empty(self.sym.nnz, dtype=np.float64)
@@ -334,7 +345,7 @@ class Context:
         c, n = self._cores(cores)
         out = np.zeros((k, len(POST_NAMES)), dtype=np.float64)
         frac = ctypes.c_double(0.0)
-        modes_int = self.empty(k, 2 * self.sym.nsolve) if want_interior else None
+        modes_int = self.empty(k, self.dpn * self.sym.nsolve) if want_interior else None
         self._check(self._lib.plfem_postprocess(self._h, int(k), ctypes.c_void_p(evecs.data_ptr()), _ptr(c), n,
                                                 _ptr(out), ctypes.byref(frac),
                                                 ctypes.c_void_p(modes_int.data_ptr()) if want_interior else None),

@@ -176,10 +176,10 @@ int create_impl(plfem_ctx* c, const plfem_symbolic* sym, int device, void* strea
     HIP_TRY(c, hipEventRecord(c->ev[4][0], c->stream));
   }
   c->nv = S.nv; c->ne = S.ne; c->N = S.N; c->nnz = S.rowptr.empty() ? 0 : (int)S.rowptr[S.N]; c->nsolve = S.nsolve;
-  c->L = S.L; c->nfronts = S.nfronts; c->n2 = 2 * (int64_t)S.N; c->max_ncv = max_ncv;
+  c->L = S.L; c->nfronts = S.nfronts; c->dpn = S.dpn; c->sh = S.dpn - 1; c->n2 = S.dpn * (int64_t)S.N; c->max_ncv = max_ncv;
   // per-front DOF counts + level table
   std::vector<int32_t> fs2(S.nfronts), fm(S.nfronts);
-  for (int f = 0; f < S.nfronts; ++f) { fs2[f] = 2 * S.fs[f]; fm[f] = 2 * (S.fs[f] + S.fb[f]); }
+  for (int f = 0; f < S.nfronts; ++f) { fs2[f] = S.dpn * S.fs[f]; fm[f] = S.dpn * (S.fs[f] + S.fb[f]); }
   c->levels.assign(S.L + 1, LevelInfo());
   for (int lev = 0; lev <= S.L; ++lev) {
     LevelInfo& li = c->levels[lev];
@@ -320,7 +320,7 @@ int create_impl(plfem_ctx* c, const plfem_symbolic* sym, int device, void* strea
     prow.assign((size_t)S.fnode_ptr[S.nfronts], -1);
     for (int f = 0; f < S.nfronts; ++f) {
       const int64_t np = S.fnode_ptr[f];
-      for (int q = 0; q < S.fs_true[f]; ++q) npos[S.fnodes[np + q]] = (int32_t)(np + q);
+      for (int q = 0; q < S.fs_true[f]; ++q) npos[S.fnodes[np + q]] = (int32_t)(2 * np + S.dpn * q);
       if (2 * f + 2 < S.nfronts) {
         const int64_t n0 = S.fnode_ptr[2 * f + 1] + S.fs[2 * f + 1], n1 = S.fnode_ptr[2 * f + 2] + S.fs[2 * f + 2];
         const int mn = S.fs[f] + S.fb[f];
@@ -521,6 +521,7 @@ extern "C" int plfem_assemble_hfield(plfem_ctx* c, const double* cores_host, int
                                      double eps_clad, double k0, double alpha_p) {
   if (!c) return PLFEM_EINVAL;
   if (!(eps_core > 0) || !(eps_clad > 0)) { c->err = "permittivities must be positive"; return PLFEM_EINVAL; }
+  if (c->dpn != 2) { c->err = "plfem_assemble_hfield: the analysis of this context has one unknown per node (use plfem_assemble_scalar)"; return PLFEM_EINVAL; }
   HIP_TRY(c, hipSetDevice(c->device));
   TRY(upload_cores(c, cores_host, ncore));
   HIP_TRY(c, hipEventRecord(c->ev[0][0], c->stream));
@@ -529,6 +530,25 @@ extern "C" int plfem_assemble_hfield(plfem_ctx* c, const double* cores_host, int
   HIP_TRY(c, hipEventRecord(c->ev[0][1], c->stream));
   c->ev_used[0] = true;
   TRY(check_launch(c, "assemble"));
+  c->assembled = true;
+  c->factored = false;
+  c->k0 = k0;
+  return PLFEM_OK;
+}
+
+extern "C" int plfem_assemble_scalar(plfem_ctx* c, const double* cores_host, int32_t ncore, double eps_core,
+                                     double eps_clad, double k0) {
+  if (!c) return PLFEM_EINVAL;
+  if (!(eps_core > 0) || !(eps_clad > 0)) { c->err = "permittivities must be positive"; return PLFEM_EINVAL; }
+  if (c->dpn != 1) { c->err = "plfem_assemble_scalar: the analysis of this context has two unknowns per node (plfem_symbolic_create_ex(..., 1, 0, ...))"; return PLFEM_EINVAL; }
+  HIP_TRY(c, hipSetDevice(c->device));
+  TRY(upload_cores(c, cores_host, ncore));
+  HIP_TRY(c, hipEventRecord(c->ev[0][0], c->stream));
+  plfem::launch_element_matrices_scalar(c, ncore, eps_core, eps_clad, k0);
+  plfem::launch_csr_gather(c);
+  HIP_TRY(c, hipEventRecord(c->ev[0][1], c->stream));
+  c->ev_used[0] = true;
+  TRY(check_launch(c, "assemble scalar"));
   c->assembled = true;
   c->factored = false;
   c->k0 = k0;
@@ -564,7 +584,7 @@ extern "C" int plfem_factor(plfem_ctx* c, double sigma) {
   HIP_TRY(c, hipMemsetAsync(c->d_fvec, 0, sizeof(double) * 2 * c->fnodes_total * plfem::BLOCK_P, c->stream));   // (see plfem_create)
   plfem::launch_factor(c, sigma);
   if (c->debug_perturb != 0.0)   // test hook (plfem_set_option "debug_perturb"): a slightly wrong factor
-    plfem::launch_scale(c, (int64_t)2 * c->S->fs[0], 1.0 + c->debug_perturb, c->d_delta);
+    plfem::launch_scale(c, (int64_t)c->dpn * c->S->fs[0], 1.0 + c->debug_perturb, c->d_delta);
   HIP_TRY(c, hipEventRecord(c->ev[1][1], c->stream));
   c->ev_used[1] = true;
   TRY(check_launch(c, "factor"));
@@ -873,7 +893,7 @@ extern "C" int plfem_lanczos_shift_invert(plfem_ctx* c, int32_t k, int32_t ncv, 
   if (!c || !evals_host || !evecs_dev) return PLFEM_EINVAL;
   if (!c->factored || c->sigma != sigma) { c->err = "plfem_lanczos_shift_invert: call plfem_factor(sigma) first"; return PLFEM_ESTATE; }
   const int64_t n = c->n2;
-  if (k < 1 || ncv <= k || ncv > c->max_ncv || ncv > 2 * c->nsolve) { c->err = "need 1 <= k < ncv <= max_ncv"; return PLFEM_EINVAL; }
+  if (k < 1 || ncv <= k || ncv > c->max_ncv || ncv > c->dpn * c->nsolve) { c->err = "need 1 <= k < ncv <= max_ncv"; return PLFEM_EINVAL; }
   if (tol <= 0) tol = 2.2e-16;
   HIP_TRY(c, hipSetDevice(c->device));
   HIP_TRY(c, hipMemsetAsync(c->d_counters + 2, 0, sizeof(int32_t), c->stream));
@@ -885,7 +905,7 @@ extern "C" int plfem_lanczos_shift_invert(plfem_ctx* c, int32_t k, int32_t ncv, 
     int mblk = ((ncv + plfem::BLOCK_P - 1) / plfem::BLOCK_P) * plfem::BLOCK_P;
     if (mblk > c->max_ncv) mblk = (c->max_ncv / plfem::BLOCK_P) * plfem::BLOCK_P;   // round down instead
     if (allow && c->max_block_p >= plfem::BLOCK_P && k >= plfem::BLOCK_P && mblk >= k + 3 * plfem::BLOCK_P &&
-        2 * (int64_t)c->nsolve >= 16 * (int64_t)(mblk + plfem::BLOCK_P))
+        c->dpn * (int64_t)c->nsolve >= 16 * (int64_t)(mblk + plfem::BLOCK_P))
       return lanczos_block(c, k, ncv, tol, maxiter, sigma, evals_host, evecs_dev, stats_host);
   }
   hipStream_t st = c->stream;

@@ -23,10 +23,20 @@ static void set_err(char* err, int32_t errlen, const std::string& msg) {
 extern "C" int plfem_symbolic_create(int32_t nv, int32_t ne, const double* p_host, const int32_t* t_host,
                                      int32_t leaf_elems, int32_t nthreads, plfem_symbolic** out,
                                      char* err, int32_t errlen) {
+  return plfem_symbolic_create_ex(nv, ne, p_host, t_host, leaf_elems, nthreads, 2, 1, out, err, errlen);
+}
+
+extern "C" int plfem_symbolic_create_ex(int32_t nv, int32_t ne, const double* p_host, const int32_t* t_host,
+                                        int32_t leaf_elems, int32_t nthreads, int32_t dofs_per_node, int32_t dirichlet,
+                                        plfem_symbolic** out, char* err, int32_t errlen) {
   if (!out) return PLFEM_EINVAL;
   *out = nullptr;
   if (!p_host || !t_host || nv < 3 || ne < 1) {
     set_err(err, errlen, "plfem_symbolic_create: empty mesh or null pointer");
+    return PLFEM_EINVAL;
+  }
+  if (dofs_per_node != 1 && dofs_per_node != 2) {
+    set_err(err, errlen, "plfem_symbolic_create_ex: dofs_per_node must be 1 (scalar) or 2 (vectorial)");
     return PLFEM_EINVAL;
   }
   plfem_symbolic* h = new (std::nothrow) plfem_symbolic();
@@ -34,7 +44,7 @@ extern "C" int plfem_symbolic_create(int32_t nv, int32_t ne, const double* p_hos
   std::string msg;
   try {
     msg = plfem::build_symbolic(nv, ne, p_host, t_host, leaf_elems <= 0 ? 24 : leaf_elems,
-                                nthreads <= 0 ? 1 : nthreads, h->S);
+                                nthreads <= 0 ? 1 : nthreads, h->S, dofs_per_node, dirichlet != 0);
   } catch (const std::exception& e) {
     msg = std::string("exception in symbolic analysis: ") + e.what();
   }
@@ -68,6 +78,7 @@ extern "C" int plfem_symbolic_info(const plfem_symbolic* sym, int64_t* info) {
   info[PLFEM_INFO_T_PATTERN_US] = (int64_t)(S.t_pattern * 1e6);
   info[PLFEM_INFO_T_TREE_US] = (int64_t)(S.t_tree * 1e6);
   info[PLFEM_INFO_T_FRONTS_US] = (int64_t)(S.t_fronts * 1e6);
+  info[PLFEM_INFO_DOFS_PER_NODE] = S.dpn;
   return PLFEM_OK;
 }
 

@@ -50,8 +50,9 @@ struct plfem_ctx {
   std::string err;
   // sizes
   int nv = 0, ne = 0, N = 0, nnz = 0, nsolve = 0, L = 0, nfronts = 0, max_ncv = 0;
+  int dpn = 2, sh = 1;            // unknowns per node (2: Hx, Hy; 1: scalar Helmholtz) and sh = dpn - 1: node = dof >> sh, component = dof & sh
   int64_t fnodes_total = 0;       // sum over fronts of (padded) nodes = fnode_ptr[nfronts]
-  int64_t n2 = 0;   // 2N
+  int64_t n2 = 0;   // dpn N: length of every global vector (component-major blocks of N)
   std::vector<plfem::LevelInfo> levels;
   // ---- index structures on the device
   int32_t* d_forder = nullptr;    // [nfronts] per level: front ids in order of decreasing s2 (factorisation launches)
@@ -77,7 +78,7 @@ struct plfem_ctx {
   double* d_fvec = nullptr;       // per-front solve vectors in front order, offset 2*fnode_ptr[f]: right-hand side (owned rows)
   double *d_u0 = nullptr, *d_u1 = nullptr;   // updates pushed into a front's rows by its left / right child (forward sweep)
   double* d_xl = nullptr;         // complete local solution of every front (backward sweep)
-  int32_t* d_npos = nullptr;      // [N] node -> front-order node position fnode_ptr[owner] + local index, -1 = Dirichlet
+  int32_t* d_npos = nullptr;      // [N] node -> front-order offset of its component 0: 2 fnode_ptr[owner] + dpn * local index, -1 = Dirichlet
   int32_t* d_prow = nullptr;      // per local node of a front: local node index in the PARENT front, -1 = none / padding
   double *d_wbuf = nullptr, *d_rbuf = nullptr;   // per-front panels m x NB, offset 2*fnode_ptr[f]*NB
   double* d_dinv = nullptr;       // per-front NB x NB (inverse of the current unit-lower pivot block)
@@ -146,6 +147,7 @@ inline void prof_close(plfem_ctx* c, int id) {
 
 // kernels_assembly.hip
 void launch_element_matrices(plfem_ctx* c, int ncore, double eps_core, double eps_clad, double k0, double alpha_p);
+void launch_element_matrices_scalar(plfem_ctx* c, int ncore, double eps_core, double eps_clad, double k0);
 void launch_csr_gather(plfem_ctx* c);
 void launch_pattern_fill(plfem_ctx* c);   // colind / slot_row from the node -> element adjacency (once per context)
 void launch_spmv(plfem_ctx* c, int which, const double* x, double* y);

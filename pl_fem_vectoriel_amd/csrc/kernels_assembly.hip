@@ -26,7 +26,7 @@ constexpr int EPB = 7;   // elements per 256-thread block: 7*36 = 252 (i,j) pair
 __global__ __launch_bounds__(256) void k_element_matrices(
     int ne, int N, const int32_t* __restrict__ tsorted, const double* __restrict__ doflocs,
     const double* __restrict__ cores, int ncore, double inv_eps_core, double inv_eps_clad, double k0sq,
-    double alpha_p, double* __restrict__ elem) {
+    double alpha_p, int scalar, double* __restrict__ elem) {
   __shared__ double s_phi[6][6];            // [basis][qp]
   __shared__ double s_gx[EPB][6][6];        // [el][basis][qp]
   __shared__ double s_gy[EPB][6][6];
@@ -106,6 +106,19 @@ __global__ __launch_bounds__(256) void k_element_matrices(
         xxe += txx * we; yye += tyy * we; xye += txy * we; yxe += tyx * we;
       }
       double* o = elem + (size_t)e * ELEM_STRIDE + ab;
+      if (scalar) {
+        // scalar Helmholtz pencil of the reference's ScalarHelmholtzSolver (solver_fem.py:252-259): the second weight is
+        // eps (not 1/eps) here, so me = eps_m;  AXX slot <- stiff - k0^2 eps_m,  MINV slot <- mass
+        o[PLFEM_BLK_AXX * 36] = (xx1 + yy1) - k0sq * me;
+        o[PLFEM_BLK_AXY * 36] = 0.0;
+        o[PLFEM_BLK_AYX * 36] = 0.0;
+        o[PLFEM_BLK_AYY * 36] = 0.0;
+        o[PLFEM_BLK_MINV * 36] = m1;
+        o[PLFEM_BLK_DXX * 36] = xx1;
+        o[PLFEM_BLK_DXY * 36] = xy1;
+        o[PLFEM_BLK_DYY * 36] = yy1;
+        return;
+      }
       // kxx = e^-1 u_y v_y, kyy = e^-1 u_x v_x, kxy = -e^-1 u_y v_x, kyx = -e^-1 u_x v_y  (solver_fem.py:132-138)
       // div_xx = u_x v_x, div_yy = u_y v_y, div_xy = u_x v_y                                (solver_fem.py:141-145)
       o[PLFEM_BLK_AXX * 36] = yye + alpha_p * xx1 - k0sq * m1;     // Kxx + a Dxx - k0^2 M
@@ -254,7 +267,7 @@ __global__ __launch_bounds__(256) void k_csr_gather(int nnz, int ne, const int32
 // y = A_int x (which = 0) or y = B_int x (which = 1) on 2N-vectors; Dirichlet rows forced to zero,
 // Dirichlet columns are zero in x by construction.  8 lanes per scalar row (avg 11.5 nnz / row),
 // both field components of the row computed in the same pass over the shared pattern.
-template <int WHICH>
+template <int WHICH, int DPN>
 __global__ __launch_bounds__(256) void k_spmv(int N, const int32_t* __restrict__ rowptr,
                                               const int32_t* __restrict__ colind, const uint8_t* __restrict__ bmask,
                                               const double* __restrict__ vxx, const double* __restrict__ vxy,
@@ -267,6 +280,10 @@ __global__ __launch_bounds__(256) void k_spmv(int N, const int32_t* __restrict__
     int q0 = rowptr[row], q1 = rowptr[row + 1];
     for (int q = q0 + sub; q < q1; q += 8) {
       int c = colind[q];
+      if (DPN == 1) {                       // scalar pencil: one block (A: the AXX slot, B: the MINV slot)
+        sx += vxx[q] * x[c];
+        continue;
+      }
       double xx = x[c], xy = x[N + c];
       if (WHICH == 0) {
         sx += vxx[q] * xx + vxy[q] * xy;
@@ -285,13 +302,13 @@ __global__ __launch_bounds__(256) void k_spmv(int N, const int32_t* __restrict__
   }
   if (row < N && sub == 0) {
     y[row] = sx;
-    y[N + row] = sy;
+    if (DPN == 2) y[N + row] = sy;
   }
 }
 
 // y_q = B_int x_q for the P vectors of a block (column q at offset q*ld): the pattern and the Minv
 // values are read once for all P vectors.
-template <int P>
+template <int P, int DPN>
 __global__ __launch_bounds__(256) void k_spmv_b_block(int N, int64_t ld, const int32_t* __restrict__ rowptr,
                                                       const int32_t* __restrict__ colind,
                                                       const uint8_t* __restrict__ bmask, const double* __restrict__ vm,
@@ -309,7 +326,7 @@ __global__ __launch_bounds__(256) void k_spmv_b_block(int N, int64_t ld, const i
 #pragma unroll
       for (int q = 0; q < P; ++q) {
         sx[q] += mv * x[(int64_t)q * ld + c];
-        sy[q] += mv * x[(int64_t)q * ld + N + c];
+        if (DPN == 2) sy[q] += mv * x[(int64_t)q * ld + N + c];
       }
     }
   }
@@ -325,7 +342,7 @@ __global__ __launch_bounds__(256) void k_spmv_b_block(int N, int64_t ld, const i
 #pragma unroll
     for (int q = 0; q < P; ++q) {
       y[(int64_t)q * ld + row] = sx[q];
-      y[(int64_t)q * ld + N + row] = sy[q];
+      if (DPN == 2) y[(int64_t)q * ld + N + row] = sy[q];
     }
   }
 }
@@ -377,6 +394,11 @@ __global__ __launch_bounds__(256) void k_spmv_a_block(int N, int64_t ld, const i
 void launch_spmv_a_block(plfem_ctx* c, const double* x, double* y, int64_t ld) {
   int64_t threads = (int64_t)c->N * 8;
   int grid = (int)((threads + 255) / 256);
+  if (c->dpn == 1) {       // scalar pencil: A is one block (the AXX slot)
+    hipLaunchKernelGGL((k_spmv_b_block<BLOCK_P, 1>), dim3(grid), dim3(256), 0, c->stream, c->N, ld, c->d_rowptr, c->d_colind,
+                       c->d_bmask, c->d_vals[PLFEM_BLK_AXX], x, y);
+    return;
+  }
   hipLaunchKernelGGL(k_spmv_a_block<BLOCK_P>, dim3(grid), dim3(256), 0, c->stream, c->N, ld, c->d_rowptr, c->d_colind,
                      c->d_bmask, c->d_vals[PLFEM_BLK_AXX], c->d_vals[PLFEM_BLK_AXY], c->d_vals[PLFEM_BLK_AYX],
                      c->d_vals[PLFEM_BLK_AYY], x, y);
@@ -385,7 +407,13 @@ void launch_spmv_a_block(plfem_ctx* c, const double* x, double* y, int64_t ld) {
 void launch_element_matrices(plfem_ctx* c, int ncore, double eps_core, double eps_clad, double k0, double alpha_p) {
   int grid = (c->ne + EPB - 1) / EPB;
   hipLaunchKernelGGL(k_element_matrices, dim3(grid), dim3(256), 0, c->stream, c->ne, c->N, c->d_tsorted,
-                     c->d_doflocs, c->d_cores, ncore, 1.0 / eps_core, 1.0 / eps_clad, k0 * k0, alpha_p, c->d_elem);
+                     c->d_doflocs, c->d_cores, ncore, 1.0 / eps_core, 1.0 / eps_clad, k0 * k0, alpha_p, 0, c->d_elem);
+}
+
+void launch_element_matrices_scalar(plfem_ctx* c, int ncore, double eps_core, double eps_clad, double k0) {
+  int grid = (c->ne + EPB - 1) / EPB;
+  hipLaunchKernelGGL(k_element_matrices, dim3(grid), dim3(256), 0, c->stream, c->ne, c->N, c->d_tsorted,
+                     c->d_doflocs, c->d_cores, ncore, eps_core, eps_clad, k0 * k0, 0.0, 1, c->d_elem);
 }
 
 void launch_pattern_fill(plfem_ctx* c) {
@@ -404,19 +432,28 @@ void launch_csr_gather(plfem_ctx* c) {
 void launch_spmv_b_block(plfem_ctx* c, const double* x, double* y, int64_t ld) {
   int64_t threads = (int64_t)c->N * 8;
   int grid = (int)((threads + 255) / 256);
-  hipLaunchKernelGGL(k_spmv_b_block<BLOCK_P>, dim3(grid), dim3(256), 0, c->stream, c->N, ld, c->d_rowptr, c->d_colind,
-                     c->d_bmask, c->d_vals[PLFEM_BLK_MINV], x, y);
+  if (c->dpn == 1)
+    hipLaunchKernelGGL((k_spmv_b_block<BLOCK_P, 1>), dim3(grid), dim3(256), 0, c->stream, c->N, ld, c->d_rowptr, c->d_colind,
+                       c->d_bmask, c->d_vals[PLFEM_BLK_MINV], x, y);
+  else
+    hipLaunchKernelGGL((k_spmv_b_block<BLOCK_P, 2>), dim3(grid), dim3(256), 0, c->stream, c->N, ld, c->d_rowptr, c->d_colind,
+                       c->d_bmask, c->d_vals[PLFEM_BLK_MINV], x, y);
 }
 
 void launch_spmv(plfem_ctx* c, int which, const double* x, double* y) {
   int64_t threads = (int64_t)c->N * 8;
   int grid = (int)((threads + 255) / 256);
+  if (c->dpn == 1) {
+    hipLaunchKernelGGL((k_spmv<1, 1>), dim3(grid), dim3(256), 0, c->stream, c->N, c->d_rowptr, c->d_colind, c->d_bmask,
+                       c->d_vals[which == 0 ? PLFEM_BLK_AXX : PLFEM_BLK_MINV], nullptr, nullptr, nullptr, x, y);
+    return;
+  }
   if (which == 0)
-    hipLaunchKernelGGL(k_spmv<0>, dim3(grid), dim3(256), 0, c->stream, c->N, c->d_rowptr, c->d_colind, c->d_bmask,
+    hipLaunchKernelGGL((k_spmv<0, 2>), dim3(grid), dim3(256), 0, c->stream, c->N, c->d_rowptr, c->d_colind, c->d_bmask,
                        c->d_vals[PLFEM_BLK_AXX], c->d_vals[PLFEM_BLK_AXY], c->d_vals[PLFEM_BLK_AYX],
                        c->d_vals[PLFEM_BLK_AYY], x, y);
   else
-    hipLaunchKernelGGL(k_spmv<1>, dim3(grid), dim3(256), 0, c->stream, c->N, c->d_rowptr, c->d_colind, c->d_bmask,
+    hipLaunchKernelGGL((k_spmv<1, 2>), dim3(grid), dim3(256), 0, c->stream, c->N, c->d_rowptr, c->d_colind, c->d_bmask,
                        c->d_vals[PLFEM_BLK_MINV], nullptr, nullptr, nullptr, x, y);
 }
 

@@ -29,6 +29,7 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 // ------------------------------------------------------------------------------------------------
 // Leaf fronts: K_e = A_e - sigma B_e of the leaf's own elements, added element by element (fixed
 // order, one block per front, 144 lanes per element) -- element-based multifrontal assembly.
+template <int sh>
 __global__ __launch_bounds__(256) void k_leaf_assemble(
     int first_front, int ne, double sigma, const int32_t* __restrict__ fm, const int64_t* __restrict__ foff,
     const int64_t* __restrict__ fnode_ptr, const int32_t* __restrict__ fnodes,
@@ -37,19 +38,21 @@ __global__ __launch_bounds__(256) void k_leaf_assemble(
   const int lf = blockIdx.x;
   const int f = first_front + lf;
   const int m = fm[f];
+  constexpr int dpn = sh + 1;                // unknowns per node: local DOF i of a front = (node i >> sh, component i & sh)
   double* F = front + foff[f];
   const int tid = threadIdx.x;
   // (the leaf fronts are contiguous in memory and were zeroed by one memset before this launch)
   const int32_t* fn = fnodes + fnode_ptr[f];
-  for (int q = tid; q < m / 2; q += 256)
+  for (int q = tid; q < (m >> sh); q += 256)
     if (fn[q] < 0) {   // padding node: unit pivot, no coupling
-      F[(int64_t)(2 * q) * m + 2 * q] = 1.0;
-      F[(int64_t)(2 * q + 1) * m + 2 * q + 1] = 1.0;
+      for (int cc = 0; cc < dpn; ++cc) F[(int64_t)(dpn * q + cc) * m + dpn * q + cc] = 1.0;
     }
   __syncthreads();
-  const int adof = tid / 12, bdof = tid % 12;
-  const int a = adof >> 1, ca = adof & 1, b = bdof >> 1, cb = bdof & 1;
-  const bool worker = tid < 144;
+  constexpr int nd = 6 * dpn;                // DOFs of one element: 12 (Hx, Hy) or 6 (scalar)
+  const int adof = tid / nd, bdof = tid % nd;
+  const int a = adof >> sh, ca = adof & sh, b = bdof >> sh, cb = bdof & sh;
+  const bool worker = tid < nd * nd;
+  // scalar pencil: the AXX slot holds K - k0^2 M_eps and the MINV slot M (launch_element_matrices_scalar)
   const int blk_a = (ca == 0 && cb == 0) ? PLFEM_BLK_AXX : (ca == 0) ? PLFEM_BLK_AXY : (cb == 0) ? PLFEM_BLK_AYX : PLFEM_BLK_AYY;
   const bool diag_blk = ca == cb;
   // positions and values of EB elements are fetched together (they do not depend on F); only the additions into
@@ -69,7 +72,7 @@ __global__ __launch_bounds__(256) void k_leaf_assemble(
         const double* em = elem + (size_t)e * ELEM_STRIDE + a * 6 + b;
         double v = em[blk_a * 36];
         if (diag_blk) v -= sigma * em[PLFEM_BLK_MINV * 36];
-        if (pa >= 0 && pb >= 0) { dst[t] = (int64_t)(2 * pb + cb) * m + (2 * pa + ca); val[t] = v; }
+        if (pa >= 0 && pb >= 0) { dst[t] = (int64_t)(dpn * pb + cb) * m + (dpn * pa + ca); val[t] = v; }
       }
     }
 #pragma unroll
@@ -84,6 +87,7 @@ __global__ __launch_bounds__(256) void k_leaf_assemble(
 
 // Internal fronts: gather formulation of the extend-add.  F[i,j] = S_child0[.,.] + S_child1[.,.]
 // through the inverse index maps; every entry written exactly once (no zero fill, no atomics).
+template <int sh>
 __global__ __launch_bounds__(256) void k_front_gather(
     const int2* __restrict__ tiles, const int32_t* __restrict__ fs2, const int32_t* __restrict__ fm,
     const int64_t* __restrict__ foff, const int64_t* __restrict__ fnode_ptr, const int32_t* __restrict__ fnodes,
@@ -91,11 +95,12 @@ __global__ __launch_bounds__(256) void k_front_gather(
   const int2 job = tiles[blockIdx.x];                    // (front, tx | ty << 16): 64 x 64 entries
   const int f = job.x;
   const int m = fm[f];
+  constexpr int dpn = sh + 1;
   const int i = (job.y & 0xffff) * 64 + (threadIdx.x & 63);
   const int j0 = ((job.y >> 16) * 4 + (threadIdx.x >> 6)) * 16;
   if (i >= m || j0 >= m) return;
   const int64_t np = fnode_ptr[f];
-  const int qi = i >> 1, ci = i & 1;
+  const int qi = i >> sh, ci = i & sh;
   const int c0i = cinv0[np + qi], c1i = cinv1[np + qi];
   const bool dummy_i = fnodes[np + qi] < 0;
   const int ch0 = 2 * f + 1, ch1 = 2 * f + 2;
@@ -103,25 +108,26 @@ __global__ __launch_bounds__(256) void k_front_gather(
   const double* F0 = front + foff[ch0];
   const double* F1 = front + foff[ch1];
   double* F = front + foff[f];
-  // the 8 column-node index pairs first, then all 32 child entries: two memory round trips for 16 columns
-  int c0j[8], c1j[8];
+  // the column-node index pairs first (8 nodes at two DOFs per node, 16 at one), then all 32 child entries: two
+  // memory round trips for 16 columns
+  int c0j[16 >> sh], c1j[16 >> sh];
 #pragma unroll
-  for (int q = 0; q < 8; ++q) {
-    c0j[q] = cinv0[np + (j0 >> 1) + q];
-    c1j[q] = cinv1[np + (j0 >> 1) + q];
+  for (int q = 0; q < (16 >> sh); ++q) {
+    c0j[q] = cinv0[np + (j0 >> sh) + q];
+    c1j[q] = cinv1[np + (j0 >> sh) + q];
   }
   double v[16];
 #pragma unroll
   for (int jj = 0; jj < 16; ++jj) {
-    const int cj = jj & 1, q = jj >> 1;
+    const int cj = jj & sh, q = jj >> sh;
     double a = 0.0, b = 0.0;
     // (row, column) = (larger, smaller) local index: only the lower triangle of a Schur complement is maintained
     if (c0i >= 0 && c0j[q] >= 0) {
-      const int bi = s0 + 2 * c0i + ci, bj = s0 + 2 * c0j[q] + cj;
+      const int bi = s0 + dpn * c0i + ci, bj = s0 + dpn * c0j[q] + cj;
       a = F0[(int64_t)min(bi, bj) * m0 + max(bi, bj)];
     }
     if (c1i >= 0 && c1j[q] >= 0) {
-      const int bi = s1 + 2 * c1i + ci, bj = s1 + 2 * c1j[q] + cj;
+      const int bi = s1 + dpn * c1i + ci, bj = s1 + dpn * c1j[q] + cj;
       b = F1[(int64_t)min(bi, bj) * m1 + max(bi, bj)];
     }
     v[jj] = a + b;
@@ -587,12 +593,18 @@ void launch_factor(plfem_ctx* c, double sigma, int stop_level, int stop_step, in
     if (lev == c->L) {
       const int64_t lo = c->S->foff[li.first], hi = c->S->foff[li.first + li.count];
       (void)hipMemsetAsync(c->d_front + lo, 0, sizeof(double) * (size_t)(hi - lo), st);
-      hipLaunchKernelGGL(k_leaf_assemble, dim3(li.count), dim3(256), 0, st, li.first, c->ne, sigma, c->d_fm, c->d_foff,
-                         c->d_fnode_ptr, c->d_fnodes, c->d_leaf_elem_ptr, c->d_leaf_elems, c->d_epos, c->d_elem,
-                         c->d_front);
-    } else {
-      if (li.gather_n > 0)
-        hipLaunchKernelGGL(k_front_gather, dim3(li.gather_n), dim3(256), 0, st, c->d_tiles + li.gather_off, c->d_fs2, c->d_fm,
+      if (c->sh)
+        hipLaunchKernelGGL(k_leaf_assemble<1>, dim3(li.count), dim3(256), 0, st, li.first, c->ne, sigma, c->d_fm, c->d_foff,
+                           c->d_fnode_ptr, c->d_fnodes, c->d_leaf_elem_ptr, c->d_leaf_elems, c->d_epos, c->d_elem, c->d_front);
+      else
+        hipLaunchKernelGGL(k_leaf_assemble<0>, dim3(li.count), dim3(256), 0, st, li.first, c->ne, sigma, c->d_fm, c->d_foff,
+                           c->d_fnode_ptr, c->d_fnodes, c->d_leaf_elem_ptr, c->d_leaf_elems, c->d_epos, c->d_elem, c->d_front);
+    } else if (li.gather_n > 0) {
+      if (c->sh)
+        hipLaunchKernelGGL(k_front_gather<1>, dim3(li.gather_n), dim3(256), 0, st, c->d_tiles + li.gather_off, c->d_fs2, c->d_fm,
+                           c->d_foff, c->d_fnode_ptr, c->d_fnodes, c->d_cinv0, c->d_cinv1, c->d_front);
+      else
+        hipLaunchKernelGGL(k_front_gather<0>, dim3(li.gather_n), dim3(256), 0, st, c->d_tiles + li.gather_off, c->d_fs2, c->d_fm,
                            c->d_foff, c->d_fnode_ptr, c->d_fnodes, c->d_cinv0, c->d_cinv1, c->d_front);
     }
     if (lev == stop_level && stop_stage == 0) return;

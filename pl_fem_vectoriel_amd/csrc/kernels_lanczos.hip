@@ -275,7 +275,7 @@ __global__ __launch_bounds__(256) void k_block_scale(int64_t n, const double* __
   if (bv_front) {
     const int c = i >= N;
     const int pos = npos[(int)(i - (int64_t)c * N)];
-    if (pos >= 0) fo = (2 * (int64_t)pos + c) * P;
+    if (pos >= 0) fo = ((int64_t)pos + c) * P;
   }
 #pragma unroll
   for (int q = 0; q < P; ++q) {
@@ -346,14 +346,16 @@ __global__ __launch_bounds__(256) void k_core_mask(int N, const double* __restri
 // per (row chunk, mode) partial sums: [0] sum vx^2, [1] sum vy^2, [2] core vx^2, [3] core vy^2,
 // [4] vx.Dxx vx + 2 vx.Dxy vy + vy.Dyy vy.   8 lanes per row.
 constexpr int POST_ROWS = 256;   // rows per block
+// DPN = 1 (scalar solver, solver_fem.py:268-271): [0] sum v^2, [2] core v^2, [4] v.M v with M in the dxx argument
+template <int DPN>
 __global__ __launch_bounds__(256) void k_post_sums(int N, int nblocks, const int32_t* __restrict__ rowptr,
                                                    const int32_t* __restrict__ colind, const double* __restrict__ dxx,
                                                    const double* __restrict__ dxy, const double* __restrict__ dyy,
                                                    const uint8_t* __restrict__ mask, const double* __restrict__ evecs,
                                                    double* __restrict__ partial) {
   const int mode = blockIdx.y;
-  const double* vx = evecs + (int64_t)mode * 2 * N;
-  const double* vy = vx + N;
+  const double* vx = evecs + (int64_t)mode * DPN * N;
+  const double* vy = vx + (DPN == 2 ? N : 0);
   __shared__ double red[4][5];
   double acc[5] = {0, 0, 0, 0, 0};
   const int sub = threadIdx.x & 7;
@@ -364,11 +366,12 @@ __global__ __launch_bounds__(256) void k_post_sums(int N, int nblocks, const int
     int q1 = rowptr[row + 1];
     for (int q = rowptr[row] + sub; q < q1; q += 8) {
       int c = colind[q];
+      if (DPN == 1) { px += dxx[q] * vx[c]; continue; }
       double ux = vx[c], uy = vy[c];
       px += dxx[q] * ux + 2.0 * dxy[q] * uy;
       py += dyy[q] * uy;
     }
-    double x = vx[row], y = vy[row];
+    double x = vx[row], y = DPN == 2 ? vy[row] : 0.0;
     acc[4] += x * px + y * py;
     if (sub == 0) {
       acc[0] += x * x;
@@ -400,28 +403,31 @@ __global__ __launch_bounds__(64) void k_post_finish(int k, int nblocks, const do
 }
 
 // normalise each mode in place (solver_fem.py:213)
-__global__ __launch_bounds__(256) void k_post_scale(int N, const double* __restrict__ sums, double* __restrict__ evecs) {
+// dpn = 1: M-normalisation v / (sqrt(v.M v) + 1e-30) as solver_fem.py:268
+__global__ __launch_bounds__(256) void k_post_scale(int N, int dpn, const double* __restrict__ sums, double* __restrict__ evecs) {
   const int mode = blockIdx.y;
-  const double nrm = sqrt(sums[mode * 5 + 0] + sums[mode * 5 + 1]) + 1e-30;
+  const double n2 = dpn == 2 ? sums[mode * 5 + 0] + sums[mode * 5 + 1] : sums[mode * 5 + 4];
+  const double nrm = sqrt(n2) + 1e-30;
   const double inv = 1.0 / nrm;
-  double* v = evecs + (int64_t)mode * 2 * N;
+  double* v = evecs + (int64_t)mode * dpn * N;
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i < 2 * (int64_t)N) v[i] *= inv;
+  if (i < dpn * (int64_t)N) v[i] *= inv;
 }
 
-__global__ __launch_bounds__(256) void k_gather_interior(int N, int nsolve, const int32_t* __restrict__ interior,
+__global__ __launch_bounds__(256) void k_gather_interior(int N, int nsolve, int dpn, const int32_t* __restrict__ interior,
                                                          const double* __restrict__ evecs,
                                                          double* __restrict__ modes_int) {
   const int mode = blockIdx.y;
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= 2 * (int64_t)nsolve) return;
+  if (i >= dpn * (int64_t)nsolve) return;
   int comp = i >= nsolve ? 1 : 0;
   int q = (int)(i - (int64_t)comp * nsolve);
-  modes_int[(int64_t)mode * 2 * nsolve + i] = evecs[(int64_t)mode * 2 * N + (int64_t)comp * N + interior[q]];
+  modes_int[(int64_t)mode * dpn * nsolve + i] = evecs[(int64_t)mode * dpn * N + (int64_t)comp * N + interior[q]];
 }
 
 // ---- a-posteriori residuals: per (row chunk, vector) partial sums [0] sum |A v - lambda B v|^2, [1] sum |A v|^2
 // over the interior rows; 8 lanes per scalar row, both field components in one pass over the shared pattern.
+template <int DPN>
 __global__ __launch_bounds__(256) void k_resid_sums(int N, int nblocks, const int32_t* __restrict__ rowptr,
                                                     const int32_t* __restrict__ colind, const uint8_t* __restrict__ bmask,
                                                     const double* __restrict__ vxx, const double* __restrict__ vxy,
@@ -429,8 +435,8 @@ __global__ __launch_bounds__(256) void k_resid_sums(int N, int nblocks, const in
                                                     const double* __restrict__ vm, const double* __restrict__ lam,
                                                     const double* __restrict__ evecs, double* __restrict__ partial) {
   const int mode = blockIdx.y;
-  const double* vx = evecs + (int64_t)mode * 2 * N;
-  const double* vy = vx + N;
+  const double* vx = evecs + (int64_t)mode * DPN * N;
+  const double* vy = vx + (DPN == 2 ? N : 0);
   const double l = lam[mode];
   __shared__ double red[4][2];
   double r2 = 0.0, a2 = 0.0;
@@ -443,6 +449,7 @@ __global__ __launch_bounds__(256) void k_resid_sums(int N, int nblocks, const in
     const int q1 = rowptr[row + 1];
     for (int q = rowptr[row] + sub; q < q1; q += 8) {
       const int c = colind[q];
+      if (DPN == 1) { ax += vxx[q] * vx[c]; bx += vm[q] * vx[c]; continue; }
       const double ux = vx[c], uy = vy[c], m = vm[q];
       ax += vxx[q] * ux + vxy[q] * uy;
       ay += vyx[q] * ux + vyy[q] * uy;
@@ -488,9 +495,14 @@ void launch_residuals(plfem_ctx* c, int k, const double* lam_host, const double*
   (void)hipMemcpyAsync(c->d_hacc, hs, sizeof(double) * k, hipMemcpyHostToDevice, st);
   double* partial = c->d_post;                       // [k][nblocks][2]
   double* sums = c->d_post + (int64_t)k * nblocks * 2;
-  hipLaunchKernelGGL(k_resid_sums, dim3(nblocks, k), dim3(256), 0, st, N, nblocks, c->d_rowptr, c->d_colind, c->d_bmask,
-                     c->d_vals[PLFEM_BLK_AXX], c->d_vals[PLFEM_BLK_AXY], c->d_vals[PLFEM_BLK_AYX], c->d_vals[PLFEM_BLK_AYY],
-                     c->d_vals[PLFEM_BLK_MINV], c->d_hacc, evecs, partial);
+  if (c->dpn == 1)
+    hipLaunchKernelGGL(k_resid_sums<1>, dim3(nblocks, k), dim3(256), 0, st, N, nblocks, c->d_rowptr, c->d_colind, c->d_bmask,
+                       c->d_vals[PLFEM_BLK_AXX], c->d_vals[PLFEM_BLK_AXY], c->d_vals[PLFEM_BLK_AYX], c->d_vals[PLFEM_BLK_AYY],
+                       c->d_vals[PLFEM_BLK_MINV], c->d_hacc, evecs, partial);
+  else
+    hipLaunchKernelGGL(k_resid_sums<2>, dim3(nblocks, k), dim3(256), 0, st, N, nblocks, c->d_rowptr, c->d_colind, c->d_bmask,
+                       c->d_vals[PLFEM_BLK_AXX], c->d_vals[PLFEM_BLK_AXY], c->d_vals[PLFEM_BLK_AYX], c->d_vals[PLFEM_BLK_AYY],
+                       c->d_vals[PLFEM_BLK_MINV], c->d_hacc, evecs, partial);
   hipLaunchKernelGGL(k_resid_finish, dim3(2 * k), dim3(64), 0, st, nblocks, partial, sums);
   (void)hipMemcpyAsync(hs + k, sums, sizeof(double) * 2 * k, hipMemcpyDeviceToHost, st);
   (void)hipStreamSynchronize(st);
@@ -582,10 +594,10 @@ void launch_block_scale(plfem_ctx* c, const double* W, const double* BW, int64_t
 // stream = state after e + 1 updates, values in [-1, 1)), written straight into the padded vectors.  Every thread
 // jumps the generator to its own element (a^k and the matching increment by binary powering), so the field is the
 // same as a sequential host loop over (vector, component, interior DOF) and costs no host time or upload.
-__global__ __launch_bounds__(256) void k_start_field(int nsolve, int N, int64_t ld, int nvec,
+__global__ __launch_bounds__(256) void k_start_field(int nsolve, int N, int dpn, int64_t ld, int nvec,
                                                      const int32_t* __restrict__ interior, double* __restrict__ out) {
   const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (e >= (int64_t)nvec * 2 * nsolve) return;
+  if (e >= (int64_t)nvec * dpn * nsolve) return;
   uint64_t k = (uint64_t)e + 1, am = 1, ap = 0, cm = 6364136223846793005ull, cp = 1442695040888963407ull;
   while (k) {
     if (k & 1) { am *= cm; ap = ap * cm + cp; }
@@ -594,16 +606,16 @@ __global__ __launch_bounds__(256) void k_start_field(int nsolve, int N, int64_t 
     k >>= 1;
   }
   const uint64_t s = am * 0x9E3779B97F4A7C15ull + ap;
-  const int q = (int)(e / (2 * (int64_t)nsolve));
-  const int r = (int)(e - (int64_t)q * 2 * nsolve);
+  const int q = (int)(e / (dpn * (int64_t)nsolve));
+  const int r = (int)(e - (int64_t)q * dpn * nsolve);
   const int comp = r >= nsolve, i = r - comp * nsolve;
   out[(int64_t)q * ld + (int64_t)comp * N + interior[i]] = ((double)(s >> 11) / 9007199254740992.0) * 2.0 - 1.0;
 }
 
 void launch_start_field(plfem_ctx* c, int nvec, double* out) {
   (void)hipMemsetAsync(out, 0, sizeof(double) * c->n2 * nvec, c->stream);
-  const int64_t total = (int64_t)nvec * 2 * c->nsolve;
-  hipLaunchKernelGGL(k_start_field, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, c->nsolve, c->N,
+  const int64_t total = (int64_t)nvec * c->dpn * c->nsolve;
+  hipLaunchKernelGGL(k_start_field, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, c->nsolve, c->N, c->dpn,
                      c->n2, nvec, c->d_interior, out);
 }
 
@@ -631,14 +643,19 @@ void launch_post(plfem_ctx* c, int k, double* evecs, int ncore, double* out_host
   const int nblocks = (N + POST_ROWS - 1) / POST_ROWS;
   double* partial = c->d_post;                       // [k][nblocks][5]
   double* sums = c->d_post + (int64_t)k * nblocks * 5;   // [k][5]
-  hipLaunchKernelGGL(k_post_sums, dim3(nblocks, k), dim3(256), 0, st, N, nblocks, c->d_rowptr, c->d_colind,
-                     c->d_vals[PLFEM_BLK_DXX], c->d_vals[PLFEM_BLK_DXY], c->d_vals[PLFEM_BLK_DYY], c->d_coremask, evecs,
-                     partial);
+  if (c->dpn == 1)      // scalar solver: v.M v with M = the MINV slot
+    hipLaunchKernelGGL(k_post_sums<1>, dim3(nblocks, k), dim3(256), 0, st, N, nblocks, c->d_rowptr, c->d_colind,
+                       c->d_vals[PLFEM_BLK_MINV], c->d_vals[PLFEM_BLK_DXY], c->d_vals[PLFEM_BLK_DYY], c->d_coremask, evecs,
+                       partial);
+  else
+    hipLaunchKernelGGL(k_post_sums<2>, dim3(nblocks, k), dim3(256), 0, st, N, nblocks, c->d_rowptr, c->d_colind,
+                       c->d_vals[PLFEM_BLK_DXX], c->d_vals[PLFEM_BLK_DXY], c->d_vals[PLFEM_BLK_DYY], c->d_coremask, evecs,
+                       partial);
   hipLaunchKernelGGL(k_post_finish, dim3(k * 5), dim3(64), 0, st, k, nblocks, partial, sums);
-  hipLaunchKernelGGL(k_post_scale, dim3((unsigned)((2 * (int64_t)N + 255) / 256), k), dim3(256), 0, st, N, sums, evecs);
+  hipLaunchKernelGGL(k_post_scale, dim3((unsigned)((c->n2 + 255) / 256), k), dim3(256), 0, st, N, c->dpn, sums, evecs);
   if (modes_int)
-    hipLaunchKernelGGL(k_gather_interior, dim3((unsigned)((2 * (int64_t)c->nsolve + 255) / 256), k), dim3(256), 0, st,
-                       N, c->nsolve, c->d_interior, evecs, modes_int);
+    hipLaunchKernelGGL(k_gather_interior, dim3((unsigned)((c->dpn * (int64_t)c->nsolve + 255) / 256), k), dim3(256), 0, st,
+                       N, c->nsolve, c->dpn, c->d_interior, evecs, modes_int);
   // results to the host
   double* hs = c->h_pinned;
   (void)hipMemcpyAsync(hs, sums, sizeof(double) * k * 5, hipMemcpyDeviceToHost, st);
@@ -647,7 +664,7 @@ void launch_post(plfem_ctx* c, int k, double* evecs, int ncore, double* out_host
   (void)hipStreamSynchronize(st);
   for (int mode = 0; mode < k; ++mode) {
     const double* s = hs + mode * 5;
-    double nrm2 = s[0] + s[1];
+    double nrm2 = c->dpn == 2 ? s[0] + s[1] : s[4];      // scalar solver: M-norm (solver_fem.py:268)
     double nrm = std::sqrt(nrm2) + 1e-30;
     double inv2 = 1.0 / (nrm * nrm);
     double* o = out_host + (size_t)mode * PLFEM_POST_COUNT;

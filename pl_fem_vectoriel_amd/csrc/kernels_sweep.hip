@@ -26,12 +26,20 @@
 
 #include "device.h"
 
+#ifndef PLFEM_SWEEP_TB
+#define PLFEM_SWEEP_TB 8
+#endif
+#ifndef PLFEM_SWEEP_ROWLOADS
+#define PLFEM_SWEEP_ROWLOADS 8
+#endif
+
 namespace plfem {
 namespace {
 
 struct SweepArgs {
   const int2* blk;
   int leaf_level;
+  int sh;                          // unknowns per node - 1: node of a local DOF = i >> sh, component = i & sh
   const int32_t *fs2, *fm;
   const int64_t *foff, *fnode_ptr;
   const int32_t *cinv0, *cinv1, *prow;
@@ -81,8 +89,8 @@ struct FwdStage {
 #pragma unroll
     for (int u = 0; u < P; ++u) a[u] = A.fr[e + u];
     if (!A.leaf_level) {
-      c0 = A.cinv0[np + (i >> 1)];
-      c1 = A.cinv1[np + (i >> 1)];
+      c0 = A.cinv0[np + (i >> A.sh)];
+      c1 = A.cinv1[np + (i >> A.sh)];
 #pragma unroll
       for (int u = 0; u < P; ++u) { b0[u] = A.u0[e + u]; b1[u] = A.u1[e + u]; }   // unconditional: no dependent load
     }
@@ -119,21 +127,21 @@ struct FwdOut {
     for (int u = 0; u < P; ++u) { w0[u] = 0.0; w1[u] = 0.0; }
     if (r >= m) return;
     if (r < s2) { dl = A.delta[2 * np + r]; return; }
-    const int pr = A.prow[np + (r >> 1)];
+    const int pr = A.prow[np + (r >> A.sh)];
     if (!A.leaf_level) {
-      c0 = A.cinv0[np + (r >> 1)];
-      c1 = A.cinv1[np + (r >> 1)];
+      c0 = A.cinv0[np + (r >> A.sh)];
+      c1 = A.cinv1[np + (r >> A.sh)];
       const int64_t e = (2 * np + r) * P;
 #pragma unroll
       for (int u = 0; u < P; ++u) { w0[u] = A.u0[e + u]; w1[u] = A.u1[e + u]; }
     }
-    if (pr >= 0) dst = (2 * A.fnode_ptr[(f - 1) >> 1] + 2 * pr + (r & 1)) * P;
+    if (pr >= 0) dst = (2 * A.fnode_ptr[(f - 1) >> 1] + (pr << A.sh) + (r & A.sh)) * P;
   }
   __device__ __forceinline__ double w(int u) const { return (c0 >= 0 ? w0[u] : 0.0) + (c1 >= 0 ? w1[u] : 0.0); }
 };
 
 // ---- forward, tile form ------------------------------------------------------------------------------------------
-constexpr int TB = 8;      // matrix loads in flight per lane and trip
+constexpr int TB = PLFEM_SWEEP_TB;      // matrix loads in flight per lane and trip (a long front is a chain of such trips)
 template <int P, int NW>
 __global__ __launch_bounds__(NW * 64) void k_fwd(SweepArgs A) {
   extern __shared__ double sv[];
@@ -213,7 +221,7 @@ __global__ __launch_bounds__(NW * 64) void k_fwd(SweepArgs A) {
 template <int P, int NW, int R>
 __global__ __launch_bounds__(NW * 64) void k_fwd_rows(SweepArgs A) {
   extern __shared__ double sv[];
-  constexpr int RB = NW * R, UNR = 8 / R, V = R * P;
+  constexpr int RB = NW * R, UNR = PLFEM_SWEEP_ROWLOADS / R, V = R * P;
   const int2 job = A.blk[blockIdx.x];
   const int f = job.x;
   const int m = A.fm[f], s2 = A.fs2[f];
@@ -312,7 +320,7 @@ struct BwdStage {
     on = on_;
     own = i < s2;
     pr = -1;
-    if (on && !own) pr = A.prow[np + (i >> 1)];
+    if (on && !own) pr = A.prow[np + (i >> A.sh)];
     if (on && own) {
 #pragma unroll
       for (int u = 0; u < P; ++u) v[u] = A.ys[(2 * np + i) * P + u];
@@ -321,7 +329,7 @@ struct BwdStage {
   __device__ __forceinline__ void request_value(const SweepArgs& A, int64_t npp) {
     if (on && !own) {
 #pragma unroll
-      for (int u = 0; u < P; ++u) v[u] = pr >= 0 ? -A.xl[(2 * npp + 2 * pr + (i & 1)) * P + u] : 0.0;
+      for (int u = 0; u < P; ++u) v[u] = pr >= 0 ? -A.xl[(2 * npp + (pr << A.sh) + (i & A.sh)) * P + u] : 0.0;
     }
   }
   __device__ __forceinline__ void finish(const SweepArgs& A, double* sv, int64_t np, bool publish) const {
@@ -416,7 +424,7 @@ __global__ __launch_bounds__(NW * 64) void k_bwd(SweepArgs A) {
 template <int P, int NW, int R>
 __global__ __launch_bounds__(NW * 64) void k_bwd_rows(SweepArgs A) {
   extern __shared__ double sv[];
-  constexpr int RB = NW * R, UNR = 8 / R, V = R * P;
+  constexpr int RB = NW * R, UNR = PLFEM_SWEEP_ROWLOADS / R, V = R * P;
   const int2 job = A.blk[blockIdx.x];
   const int f = job.x;
   const int m = A.fm[f], s2 = A.fs2[f];
@@ -490,7 +498,8 @@ __global__ __launch_bounds__(NW * 64) void k_bwd_rows(SweepArgs A) {
 }
 
 // ---- global order <-> front order ---------------------------------------------------------------------------------
-// fr[(2 npos[node] + c) P + u] = rhs[u ldx + c N + node]  (Dirichlet nodes: npos = -1, nothing to do)
+// fr[(npos[node] + c) P + u] = rhs[u ldx + c N + node]  (npos = front-order offset of the node's component 0;
+// Dirichlet nodes: npos = -1, nothing to do)
 template <int P>
 __global__ __launch_bounds__(256) void k_permute_in(int64_t n2, int N, const int32_t* __restrict__ npos,
                                                     const double* __restrict__ rhs, int64_t ldx, double* __restrict__ fr) {
@@ -500,10 +509,10 @@ __global__ __launch_bounds__(256) void k_permute_in(int64_t n2, int N, const int
   const int pos = npos[node];
   if (pos < 0) return;
 #pragma unroll
-  for (int u = 0; u < P; ++u) fr[(2 * (int64_t)pos + c) * P + u] = rhs[(int64_t)u * ldx + g];
+  for (int u = 0; u < P; ++u) fr[((int64_t)pos + c) * P + u] = rhs[(int64_t)u * ldx + g];
 }
 
-// x[u ldx + g] = xl[(2 npos[node] + c) P + u], Dirichlet entries = 0 (the result needs no memset)
+// x[u ldx + g] = xl[(npos[node] + c) P + u], Dirichlet entries = 0 (the result needs no memset)
 template <int P>
 __global__ __launch_bounds__(256) void k_permute_out(int64_t n2, int N, const int32_t* __restrict__ npos,
                                                      const double* __restrict__ xl, double* __restrict__ x, int64_t ldx) {
@@ -512,13 +521,14 @@ __global__ __launch_bounds__(256) void k_permute_out(int64_t n2, int N, const in
   const int c = g >= N, node = (int)(g - (int64_t)c * N);
   const int pos = npos[node];
 #pragma unroll
-  for (int u = 0; u < P; ++u) x[(int64_t)u * ldx + g] = pos >= 0 ? xl[(2 * (int64_t)pos + c) * P + u] : 0.0;
+  for (int u = 0; u < P; ++u) x[(int64_t)u * ldx + g] = pos >= 0 ? xl[((int64_t)pos + c) * P + u] : 0.0;
 }
 
 template <int P>
 void sweeps(plfem_ctx* c) {
   hipStream_t st = c->stream;
   SweepArgs A;
+  A.sh = c->sh;
   A.fs2 = c->d_fs2; A.fm = c->d_fm; A.foff = c->d_foff; A.fnode_ptr = c->d_fnode_ptr;
   A.cinv0 = c->d_cinv0; A.cinv1 = c->d_cinv1; A.prow = c->d_prow;
   A.front = c->d_front; A.delta = c->d_delta;

@@ -94,7 +94,8 @@ void parallel_tasks(int ntasks, int nthreads, F f) {
   });
 }
 
-inline int pad8(int x) { return (x + 7) & ~7; }
+// fronts are padded to multiples of 16 DOFs (the MFMA tile): 8 nodes at two DOFs per node, 16 at one
+inline int pad_nodes(int x, int dpn) { const int q = 16 / dpn; return (x + q - 1) / q * q; }
 
 // PLFEM_SYM_TRACE=1: sub-phase wall times of the analysis on stderr (tuning aid)
 struct Trace {
@@ -229,7 +230,7 @@ std::string p2_numbering(int nv, int ne, const double* p, const int32_t* t, Symb
   // one writer value (1), so the edge loop can run on the pool
   S.bmask.assign(N, 0);
   uint8_t* bm = S.bmask.data();
-  parallel_for(S.nedges, nth, [&](int64_t k0, int64_t k1, int) {
+  if (S.dirichlet) parallel_for(S.nedges, nth, [&](int64_t k0, int64_t k1, int) {
     for (int64_t k = k0; k < k1; ++k)
       if (mult[k] == 1) {   // several edges may mark the same vertex: relaxed atomic stores of the same value
         __atomic_store_n(&bm[ea[k]], (uint8_t)1, __ATOMIC_RELAXED);
@@ -709,7 +710,7 @@ std::string build_fronts(Symbolic& S, int nthreads) {
           } else {
             const int32_t p = c[2 * lf + 1]++;
             lb.bnd[lb.off[lf] + p] = (int32_t)i;
-            pos[k] = pad8(S.fs_true[leaf0 + lf]) + p;
+            pos[k] = pad_nodes(S.fs_true[leaf0 + lf], S.dpn) + p;
           }
         }
         for (int32_t q = nptr[i]; q < nptr[i + 1]; ++q) {
@@ -763,16 +764,16 @@ std::string build_fronts(Symbolic& S, int nthreads) {
     for (int f = 0; f < nf; ++f) tot += S.fs_true[f];
     if (tot != S.nsolve) return "internal error: owned nodes do not partition the interior DOFs";
   }
-  // flatten with padding to multiples of 8 nodes (16 DOFs)
+  // flatten with padding to multiples of 16 DOFs
   S.fnode_ptr.assign((size_t)nf + 1, 0);
   S.foff.assign((size_t)nf + 1, 0);
   S.factor_flops = 0; S.solve_entries = 0; S.max_m = 0;
   for (int f = 0; f < nf; ++f) {
-    S.fs[f] = pad8(S.fs_true[f]);
-    S.fb[f] = pad8(S.fb_true[f]);
+    S.fs[f] = pad_nodes(S.fs_true[f], S.dpn);
+    S.fb[f] = pad_nodes(S.fb_true[f], S.dpn);
     int64_t mn = S.fs[f] + S.fb[f];
     S.fnode_ptr[f + 1] = S.fnode_ptr[f] + mn;
-    int64_t m = 2 * mn, s2 = 2 * (int64_t)S.fs[f];
+    int64_t m = S.dpn * mn, s2 = S.dpn * (int64_t)S.fs[f];
     S.foff[f + 1] = S.foff[f] + m * m;
     S.factor_flops += (double)s2 * (double)m * (double)m;     // ~ block LDL^T + triangular inverse
     S.solve_entries += s2 * (m + (m - s2));
@@ -819,8 +820,11 @@ std::string numbering_only(int nv, int ne, const double* p, const int32_t* t, Sy
 }
 
 std::string build_symbolic(int nv, int ne, const double* p, const int32_t* t, int leaf_elems,
-                           int nthreads, Symbolic& S) {
+                           int nthreads, Symbolic& S, int dofs_per_node, bool dirichlet) {
   if (nv < 3 || ne < 1) return "empty mesh";
+  if (dofs_per_node != 1 && dofs_per_node != 2) return "dofs_per_node must be 1 or 2";
+  S.dpn = dofs_per_node;
+  S.dirichlet = dirichlet;
   if (leaf_elems < 1) leaf_elems = 16;
   if (nthreads < 1) nthreads = 1;
   std::unique_ptr<Pool> pool;

@@ -33,6 +33,8 @@ using rawvec_i32 = std::vector<int32_t, default_init_allocator<int32_t>>;
 struct Symbolic {
   // ---- mesh / P2 numbering (scikit-fem compatible) ------------------------------------------
   int nv = 0, ne = 0, nedges = 0, N = 0, nsolve = 0;
+  int dpn = 2;                     // unknowns per P2 node: 2 = vectorial H-field (Hx, Hy), 1 = scalar Helmholtz
+  bool dirichlet = true;           // eliminate the outer-boundary nodes (H = 0); false = natural boundary, all nodes kept
   std::vector<int32_t> tsorted;    // [3][ne]  vertex ids, each column ascending
   std::vector<int32_t> edof;       // [6][ne]  element_dofs: rows 0-2 vertices, 3-5 edges (0,1),(1,2),(0,2)
   std::vector<int32_t> edges;      // [2][nedges] sorted vertex pairs in lexicographic order
@@ -57,12 +59,12 @@ struct Symbolic {
   std::vector<int32_t> leaf_elem_ptr;  // [2^L + 1]
   std::vector<int32_t> leaf_elems;     // [ne] element ids grouped by leaf
   rawvec_i32 epos;                     // [6][ne] local node index of each element node in its leaf front, -1 = Dirichlet
-  std::vector<int32_t> fs, fb;         // [nfronts] padded (multiple of 8) counts of owned / boundary nodes
+  std::vector<int32_t> fs, fb;         // [nfronts] padded (to 16 / dpn nodes = 16 DOFs) counts of owned / boundary nodes
   std::vector<int32_t> fs_true, fb_true;
   std::vector<int64_t> fnode_ptr;      // [nfronts+1] offsets into fnodes/cinv*
   rawvec_i32 fnodes;                   // node (scalar DOF) id per local node, -1 = padding
   rawvec_i32 cinv0, cinv1;             // per local node of an internal front: index in child's boundary list or -1
-  std::vector<int64_t> foff;           // [nfronts+1] offsets (in doubles) of the dense front matrices, m = 2(fs+fb)
+  std::vector<int64_t> foff;           // [nfronts+1] offsets (in doubles) of the dense front matrices, m = dpn (fs+fb)
   std::vector<int32_t> owner;          // [N] front that eliminates the node, -1 for Dirichlet nodes
   // statistics
   double factor_flops = 0.0;           // sum over fronts of 2 * s2 * m^2  (block Gauss-Jordan sweep)
@@ -74,7 +76,7 @@ struct Symbolic {
 // p: [2][nv] (x row then y row), t: [3][ne].  leaf_elems: target elements per leaf front.
 // Returns empty string on success, error message otherwise.
 std::string build_symbolic(int nv, int ne, const double* p, const int32_t* t, int leaf_elems,
-                           int nthreads, Symbolic& S);
+                           int nthreads, Symbolic& S, int dofs_per_node = 2, bool dirichlet = true);
 
 // Host copy of the CSR column lists (sorted union of the DOFs of the elements adjacent to each node); no-op
 // if already built.  Not thread-safe against concurrent first calls on the same Symbolic.

@@ -319,4 +319,98 @@ class TrueVectorialMaxwellSolver:
         return self.solve_vectorial_modes(mesh, n_modes_target=n)
 
 
-__all__ = ["TrueVectorialMaxwellSolver", "ModeDict", "P2BasisView", "shift_estimate", "TriMesh"]
+class ScalarHelmholtzSolver:
+    """Scalar P2 solver of the reference (``solver_fem.py:245-276``) on the same device machinery
+    with ONE unknown per node: ``(K - k0^2 M_eps) u = lambda M u`` on all P2 DOFs (natural boundary), ``lambda = -beta^2``,
+    ``sigma = -(k0 (n_core - 0.008))^2``, ``k = min(n_modes_target + 8, N - 4)``.
+
+    ``ScalarHelmholtzSolver(geometry).solve(mesh, n_modes_target=20)`` returns the reference's list of dicts
+    (``n_eff, beta, field_vector, confinement, core_overlap, PDL_dB = 0.0, polarization = 'scalar',
+    is_vectorial = False``), n_eff descending.  Optional keywords as for the vectorial class (``device``, ``eig_tol``:
+    the reference passes ``tol=1e-6`` to eigsh, the default here is tighter so that the vectors are not the limiting
+    error; ``leaf_elems``)."""
+
+    REF_TOL = 1e-6           # solver_fem.py:261
+    MAXITER = 6000           # solver_fem.py:261
+    OVERSAMPLE = 8           # solver_fem.py:261
+    RESIDUAL_TOL = 1e-7
+    BASIS_FACTOR, BASIS_MAX, BASIS_BYTES = TrueVectorialMaxwellSolver.BASIS_FACTOR, TrueVectorialMaxwellSolver.BASIS_MAX, TrueVectorialMaxwellSolver.BASIS_BYTES
+
+    def __init__(self, geometry, device: Optional[int] = None, eig_tol: float = 1e-10, leaf_elems: int = 0):
+        _native.load_library()
+        self.geometry = geometry
+        self.k0 = geometry.k0
+        self.device = device
+        self.eig_tol = float(eig_tol)
+        self.leaf_elems = int(leaf_elems)
+        self._cache = {}
+        self.last_stats: Dict = {}
+
+    _basis_size = TrueVectorialMaxwellSolver._basis_size
+
+    def clear_cache(self):
+        for ent in self._cache.values():
+            if ent["ctx"] is not None:
+                ent["ctx"].close()
+        self._cache.clear()
+
+    def solve(self, mesh, n_modes_target: int = 20) -> List[Dict]:
+        g = self.geometry
+        t_start = time.perf_counter()
+        key = (id(mesh), mesh.p.shape[1], mesh.t.shape[1])
+        ent = self._cache.get(key)
+        if ent is None:
+            self.clear_cache()
+            t0 = time.perf_counter()
+            sym = _native.Symbolic(mesh.p, mesh.t, leaf_elems=self.leaf_elems, dofs_per_node=1, dirichlet=False)
+            ent = self._cache[key] = {"sym": sym, "ctx": None, "mesh": mesh, "t_symbolic": time.perf_counter() - t0}
+        sym = ent["sym"]
+        N = sym.N
+        n_req = min(n_modes_target + self.OVERSAMPLE, N - 4)                 # solver_fem.py:261
+        if n_req < 1:
+            raise ValueError("mesh too small for the requested number of modes")
+        ncv = min(self._basis_size(n_req, N), N)
+        if ent["ctx"] is None or ent["ctx"].max_ncv < ncv:
+            if ent["ctx"] is not None:
+                ent["ctx"].close()
+            ent["ctx"] = _native.Context(sym, self.device, max_ncv=max(ncv, 65))
+        ctx = ent["ctx"]
+        cores = _core_table(g)
+        ctx.assemble_scalar(cores, g.n_core ** 2, g.n_clad ** 2, self.k0)
+        sigma = float(-(self.k0 * (g.n_core - 0.008)) ** 2)                  # solver_fem.py:260
+        ctx.factor(sigma)
+        evals, evecs, st = ctx.lanczos(n_req, ncv, self.eig_tol, self.MAXITER, sigma)
+        true_res = float(ctx.residuals(evals, evecs).max())
+        st = dict(st, true_residual=true_res, true_residual_first=true_res, refined=False)
+        if not (true_res <= self.RESIDUAL_TOL) or ctx.timings()["pivot_perturbations"] > 0:
+            logger.warning(f"scalar eigenpairs failed the a-posteriori check (residual {true_res:.2e}): re-running with refinement")
+            ctx.set_option("refine_steps", 1)
+            try:
+                evals, evecs, st2 = ctx.lanczos(n_req, ncv, self.eig_tol, self.MAXITER, sigma)
+            finally:
+                ctx.set_option("refine_steps", 0)
+            res2 = float(ctx.residuals(evals, evecs).max())
+            st = dict(st, **st2, true_residual=res2, refined=True)
+            if not (res2 <= self.RESIDUAL_TOL):
+                raise RuntimeError(f"shift-invert factorisation inaccurate on this mesh: eigen-residual {res2:.2e} after refinement")
+        post, _frac, fields = ctx.postprocess(evecs, cores, want_interior=True)   # M-normalised in place (solver_fem.py:268)
+        vecs = fields.cpu().numpy()
+        modes = []
+        for i in range(len(evals)):
+            lam = float(evals[i])
+            if lam >= 0:                                                     # solver_fem.py:265
+                continue
+            ne_ = np.sqrt(-lam) / self.k0
+            if ne_ <= g.n_clad or ne_ >= g.n_core * 1.005:                   # solver_fem.py:267
+                continue
+            conf = float(post[i, 2] / post[i, 4])                            # sum_core v^2 / sum v^2
+            modes.append(ModeDict({"n_eff": float(ne_), "beta": float(self.k0 * ne_), "field_vector": vecs[i],
+                                   "confinement": conf, "core_overlap": conf, "PDL_dB": 0.0, "polarization": "scalar",
+                                   "is_vectorial": False}))
+        modes.sort(key=lambda x: x["n_eff"], reverse=True)
+        self.last_stats = dict(st, sigma=sigma, n_req=n_req, ncv=ncv, N=N, t_symbolic=ent.get("t_symbolic", 0.0),
+                               t_total=time.perf_counter() - t_start, **ctx.timings())
+        return modes
+
+
+__all__ = ["TrueVectorialMaxwellSolver", "ScalarHelmholtzSolver", "ModeDict", "P2BasisView", "shift_estimate", "TriMesh"]
