@@ -365,7 +365,7 @@ def run_sweep_config(args, D: Dist):
     world = D.world
     if D.fake:
         def solve(item, cache):
-            time.sleep(0.002)
+            time.sleep(0.01)
             return 1.26 + 1e-3 * item.index - 1e-5 * np.arange(4)
         device = None
     else:

@@ -142,6 +142,18 @@ int plfem_assemble_hfield(plfem_ctx* ctx, const double* cores_host, int32_t ncor
 int plfem_assemble_scalar(plfem_ctx* ctx, const double* cores_host, int32_t ncore, double eps_core,
                           double eps_clad, double k0);
 
+/* Coupled-mode coupling integrals, scalar context only.
+ * Replaces: the epsilon_product form + asm() and the E_i^H M_eps E_j loop of
+ *           CoupledModeTheory._compute_rigorous_coupling                      reference config.py:296-320
+ * M_deps = asm((Re eps - mean) u v), mean = plain mean of Re eps over ALL quadrature points (config.py:297-300; the
+ * imaginary part is discarded by scikit-fem's float64 assembly); n real fields of length N each:
+ * raw_host[i + j n] = E_i^T M_deps F_j with E = fields_i_dev[n][N], F = fields_j_dev[n][N]; pi/pj_host[i] = E_i.E_i, F_i.F_i.
+ * The omega / 4 factor, the normalisation and the beta diagonal stay on the Python host as in the reference.
+ * Overwrites the MINV slot: plfem_assemble_scalar must be called again before the next eigen-solve (PLFEM_ESTATE otherwise). */
+int plfem_cmt_coupling(plfem_ctx* ctx, int32_t n, const double* fields_i_dev, const double* fields_j_dev,
+                       const double* cores_host, int32_t ncore, double eps_core, double eps_clad,
+                       double* raw_host, double* pi_host, double* pj_host, double* eps_mean_host);
+
 enum { PLFEM_BLK_AXX = 0, PLFEM_BLK_AXY, PLFEM_BLK_AYX, PLFEM_BLK_AYY, PLFEM_BLK_MINV,
        PLFEM_BLK_DXX, PLFEM_BLK_DXY, PLFEM_BLK_DYY, PLFEM_BLK_COUNT };
 /* device pointer of a block's CSR values (length nnz), valid until plfem_destroy */

@@ -32,7 +32,7 @@ EXPORTS = (
     "plfem_solve", "plfem_lanczos_shift_invert", "plfem_postprocess", "plfem_timings",
     "plfem_debug_factor_until", "plfem_debug_copy", "plfem_profile_begin", "plfem_profile_end",
     "plfem_mesh_edge_count", "plfem_mesh_refine", "plfem_debug_symeig", "plfem_debug_symeig_band",
-    "plfem_residuals", "plfem_set_option", "plfem_symbolic_create_ex", "plfem_assemble_scalar",
+    "plfem_residuals", "plfem_set_option", "plfem_symbolic_create_ex", "plfem_assemble_scalar", "plfem_cmt_coupling",
 )
 MAX_NCV = 320                       # PLFEM_MAX_NCV of include/plfem.h
 PROF_SLOTS = ("k_fwd", "fwd_sweep", "bwd_sweep", "spmv_b")
@@ -100,6 +100,9 @@ def load_library() -> ctypes.CDLL:
                                           ctypes.c_double, ctypes.c_double, ctypes.c_double]
     lib.plfem_assemble_scalar.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_double,
                                           ctypes.c_double, ctypes.c_double]
+    lib.plfem_cmt_coupling.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                       ctypes.c_int32, ctypes.c_double, ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p,
+                                       ctypes.c_void_p, ctypes.POINTER(ctypes.c_double)]
     lib.plfem_block_values_dev.argtypes = [ctypes.c_void_p, ctypes.c_int32, c_void_pp]
     lib.plfem_block_values_host.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p]
     lib.plfem_spmv.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]
@@ -306,6 +309,20 @@ class Context:
         c, n = self._cores(cores)
         self._check(self._lib.plfem_assemble_scalar(self._h, _ptr(c), n, float(eps_core), float(eps_clad), float(k0)),
                     "plfem_assemble_scalar")
+
+    def cmt_coupling(self, fields_i, fields_j, cores, eps_core, eps_clad):
+        """``plfem_cmt_coupling``: raw[i, j] = E_i^T M_deps F_j, the squared norms of both field sets, mean(eps)."""
+        n = fields_i.shape[0]
+        c, nc = self._cores(cores)
+        raw = np.zeros((n, n), dtype=np.float64)
+        pi = np.zeros(n, dtype=np.float64)
+        pj = np.zeros(n, dtype=np.float64)
+        mean = ctypes.c_double(0.0)
+        self._check(self._lib.plfem_cmt_coupling(self._h, int(n), ctypes.c_void_p(fields_i.data_ptr()),
+                                                 ctypes.c_void_p(fields_j.data_ptr()), _ptr(c), nc, float(eps_core),
+                                                 float(eps_clad), _ptr(raw), _ptr(pi), _ptr(pj), ctypes.byref(mean)),
+                    "plfem_cmt_coupling")
+        return raw.T.copy(), pi, pj, float(mean.value)      # C side is column major: raw_host[i + j n]
 
     def block_values(self, name: str) -> np.ndarray:
         out = np.empty(self.sym.nnz, dtype=np.float64)

@@ -555,6 +555,42 @@ extern "C" int plfem_assemble_scalar(plfem_ctx* c, const double* cores_host, int
   return PLFEM_OK;
 }
 
+// CMT coupling integrals: raw[i + j n] = E_i^T M_deps F_j, norms
+extern "C" int plfem_cmt_coupling(plfem_ctx* c, int32_t n, const double* fields_i_dev, const double* fields_j_dev,
+                                  const double* cores_host, int32_t ncore, double eps_core, double eps_clad,
+                                  double* raw_host, double* pi_host, double* pj_host, double* eps_mean_host) {
+  if (!c || !fields_i_dev || !fields_j_dev || !raw_host || !pi_host || !pj_host || n < 1) return PLFEM_EINVAL;
+  if (c->dpn != 1) { c->err = "plfem_cmt_coupling: needs a context with one unknown per node (scalar fields)"; return PLFEM_EINVAL; }
+  if (n > c->max_ncv) { c->err = "plfem_cmt_coupling: more fields than the context's max_ncv"; return PLFEM_EINVAL; }
+  HIP_TRY(c, hipSetDevice(c->device));
+  TRY(upload_cores(c, cores_host, ncore));
+  const double mean = plfem::launch_delta_eps_mass(c, ncore, eps_core, eps_clad);
+  c->assembled = true;                        // (plfem_spmv below reads the MINV slot)
+  const int64_t N = c->n2;
+  const int ld = n;
+  double* Hd = c->d_Hcols;                    // [n + 2][n]: columns of the raw matrix, then the two norm vectors
+  for (int j = 0; j < n; ++j) {
+    plfem::launch_spmv(c, 1, fields_j_dev + (size_t)j * N, c->d_w);                       // y = M_deps F_j
+    plfem::launch_panel_dot(c, fields_i_dev, n, c->d_w, Hd + (size_t)j * ld);            // column j: E_i^T y
+  }
+  for (int i = 0; i < n; ++i) {
+    plfem::launch_dot(c, fields_i_dev + (size_t)i * N, fields_i_dev + (size_t)i * N, Hd + (size_t)n * ld + i);
+    plfem::launch_dot(c, fields_j_dev + (size_t)i * N, fields_j_dev + (size_t)i * N, Hd + (size_t)(n + 1) * ld + i);
+  }
+  TRY(check_launch(c, "cmt coupling"));
+  double* hs = c->h_pinned + 8192;
+  HIP_TRY(c, hipMemcpyAsync(hs, Hd, sizeof(double) * (size_t)(n + 2) * ld, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  for (int j = 0; j < n; ++j)
+    for (int i = 0; i < n; ++i) raw_host[i + (size_t)j * n] = hs[(size_t)j * ld + i];
+  for (int i = 0; i < n; ++i) { pi_host[i] = hs[(size_t)n * ld + i]; pj_host[i] = hs[(size_t)(n + 1) * ld + i]; }
+  if (eps_mean_host) *eps_mean_host = mean;
+  // the MINV slot no longer holds the mass matrix of the eigenproblem: a new assembly is required before the next solve
+  c->assembled = false;
+  c->factored = false;
+  return PLFEM_OK;
+}
+
 extern "C" int plfem_block_values_dev(plfem_ctx* c, int32_t block, const double** values_dev) {
   if (!c || !values_dev || block < 0 || block >= PLFEM_BLK_COUNT) return PLFEM_EINVAL;
   *values_dev = c->d_vals[block];

@@ -148,6 +148,7 @@ inline void prof_close(plfem_ctx* c, int id) {
 // kernels_assembly.hip
 void launch_element_matrices(plfem_ctx* c, int ncore, double eps_core, double eps_clad, double k0, double alpha_p);
 void launch_element_matrices_scalar(plfem_ctx* c, int ncore, double eps_core, double eps_clad, double k0);
+double launch_delta_eps_mass(plfem_ctx* c, int ncore, double eps_core, double eps_clad);   // MINV slot <- asm((eps - mean eps) u v)
 void launch_csr_gather(plfem_ctx* c);
 void launch_pattern_fill(plfem_ctx* c);   // colind / slot_row from the node -> element adjacency (once per context)
 void launch_spmv(plfem_ctx* c, int which, const double* x, double* y);

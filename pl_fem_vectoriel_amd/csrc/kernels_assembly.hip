@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void k_element_matrices(
         o[PLFEM_BLK_AXY * 36] = 0.0;
         o[PLFEM_BLK_AYX * 36] = 0.0;
         o[PLFEM_BLK_AYY * 36] = 0.0;
-        o[PLFEM_BLK_MINV * 36] = m1;
+        o[PLFEM_BLK_MINV * 36] = scalar == 2 ? me : m1;        // 2: only the weighted mass is wanted (CMT coupling)
         o[PLFEM_BLK_DXX * 36] = xx1;
         o[PLFEM_BLK_DXY * 36] = xy1;
         o[PLFEM_BLK_DYY * 36] = yy1;
@@ -131,6 +131,31 @@ __global__ __launch_bounds__(256) void k_element_matrices(
       o[PLFEM_BLK_DYY * 36] = yy1;
     }
   }
+}
+
+// Number of quadrature points inside a core (same point and same closed-disc test as k_element_matrices): the
+// unweighted mean permittivity over all quadrature points that the reference's CMT form subtracts (config.py:297-300)
+// follows from it in closed form.  Integer atomics: order independent.
+__global__ __launch_bounds__(256) void k_count_core_qp(int ne, int N, const int32_t* __restrict__ tsorted,
+                                                       const double* __restrict__ doflocs, const double* __restrict__ cores,
+                                                       int ncore, unsigned long long* __restrict__ count) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  bool in_core = false;
+  if (t < (int64_t)ne * 6) {
+    const int e = (int)(t / 6), q = (int)(t % 6);
+    int v0 = tsorted[e], v1 = tsorted[ne + e], v2 = tsorted[2 * (size_t)ne + e];
+    double x0 = doflocs[v0], y0 = doflocs[N + v0];
+    double j00 = doflocs[v1] - x0, j10 = doflocs[N + v1] - y0;
+    double j01 = doflocs[v2] - x0, j11 = doflocs[N + v2] - y0;
+    double xi = c_qx[q], eta = c_qy[q];
+    double X = x0 + j00 * xi + j01 * eta, Y = y0 + j10 * xi + j11 * eta;
+    for (int c = 0; c < ncore; ++c) {
+      double dx = X - cores[3 * c], dy = Y - cores[3 * c + 1], r = cores[3 * c + 2];
+      in_core |= (dx * dx + dy * dy <= r * r);
+    }
+  }
+  const unsigned long long b = __ballot(in_core);
+  if ((threadIdx.x & 63) == 0 && b) atomicAdd(count, (unsigned long long)__popcll(b));
 }
 
 // CSR column lists of the scalar pattern: row i = ascending union of the DOFs of the elements adjacent to node i
@@ -414,6 +439,26 @@ void launch_element_matrices_scalar(plfem_ctx* c, int ncore, double eps_core, do
   int grid = (c->ne + EPB - 1) / EPB;
   hipLaunchKernelGGL(k_element_matrices, dim3(grid), dim3(256), 0, c->stream, c->ne, c->N, c->d_tsorted,
                      c->d_doflocs, c->d_cores, ncore, eps_core, eps_clad, k0 * k0, 0.0, 1, c->d_elem);
+}
+
+// M_deps = asm((eps - mean(eps)) u v) into the MINV slot (CMT coupling, config.py:296-303); returns mean(eps)
+double launch_delta_eps_mass(plfem_ctx* c, int ncore, double eps_core, double eps_clad) {
+  unsigned long long* cnt = reinterpret_cast<unsigned long long*>(c->d_counters + 2);   // 8-byte aligned pair of counters
+  (void)hipMemsetAsync(cnt, 0, sizeof(unsigned long long), c->stream);
+  const int64_t nq = (int64_t)c->ne * 6;
+  hipLaunchKernelGGL(k_count_core_qp, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, c->stream, c->ne, c->N, c->d_tsorted,
+                     c->d_doflocs, c->d_cores, ncore, cnt);
+  unsigned long long* h = reinterpret_cast<unsigned long long*>(c->h_pinned + 4000);
+  (void)hipMemcpyAsync(h, cnt, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream);
+  (void)hipStreamSynchronize(c->stream);
+  const double frac = (double)*h / (double)nq;
+  const double mean = eps_clad + (eps_core - eps_clad) * frac;
+  int grid = (c->ne + EPB - 1) / EPB;
+  hipLaunchKernelGGL(k_element_matrices, dim3(grid), dim3(256), 0, c->stream, c->ne, c->N, c->d_tsorted,
+                     c->d_doflocs, c->d_cores, ncore, eps_core - mean, eps_clad - mean, 0.0, 0.0, 2, c->d_elem);
+  launch_csr_gather(c);
+  (void)hipMemsetAsync(cnt, 0, sizeof(unsigned long long), c->stream);     // counters[2] is the Lanczos rank flag
+  return mean;
 }
 
 void launch_pattern_fill(plfem_ctx* c) {

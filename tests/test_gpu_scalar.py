@@ -101,3 +101,32 @@ def test_scalar_tiny_mesh_clamps_the_request(gpu_device, built_library):
     assert len(modes) == len(ref)
     for a, b in zip(modes, ref):
         assert abs(a["n_eff"] - b["n_eff"]) < N_EFF_TOL
+
+
+def test_cmt_rigorous_coupling_matches_oracle(c1_geometry, gpu_device, built_library):
+    """Row f4: CoupledModeTheory._compute_rigorous_coupling (reference config.py:274-322) from the scalar modes of a GPU
+    solve: H against the oracle's restatement on the same fields, plus the closed-form properties."""
+    from oracle import cmt as ocmt
+    from oracle.p2 import P2Basis
+    from pl_fem_vectoriel_amd.cmt import CoupledModeTheory
+    g = c1_geometry
+    mesh = generate_mesh(g, 0.5, 0)
+    solver = ScalarHelmholtzSolver(g, device=gpu_device)
+    modes = solver.solve(mesh, n_modes_target=6)
+    solver.clear_cache()
+    omega = 2 * np.pi * 2.99792458e14 / 1.55
+    theory = CoupledModeTheory(omega, "rigorous", device=gpu_device)
+    H = theory._compute_rigorous_coupling(modes, modes, g, mesh)
+    basis = P2Basis(MeshTriLite(mesh.p, mesh.t))
+    Href = ocmt.rigorous_coupling(modes, modes, g, basis, omega)
+    _, mean = ocmt.delta_eps_mass(g, basis)
+    assert abs(theory.last_stats["eps_mean"] - mean) < 1e-13
+    assert H.shape == Href.shape == (len(modes), len(modes)) and H.dtype == complex
+    assert np.array_equal(np.diag(H), [m["beta"] for m in modes])
+    assert np.abs(H - H.T).max() == 0.0
+    scale = np.abs(Href - np.diag(np.diag(Href))).max()
+    assert np.abs(H - Href).max() <= 1e-10 * scale
+    with pytest.raises(ValueError):
+        CoupledModeTheory(omega, "exact")
+    with pytest.raises(ValueError):
+        theory._compute_rigorous_coupling(modes, modes[:-1], g, mesh)
