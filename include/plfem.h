@@ -252,9 +252,9 @@ int plfem_profile_end(plfem_ctx* ctx, double* out_host /* [PLFEM_PROF_COUNT][3] 
 
 /* ---------------------------------------------------------------------------------------------
  * Debugging aids for the test-suite (no reference counterpart): run the factorisation only up to
- * a given (tree level, block step, stage: 0 assembled, 1 pivot block, 2 or 3 invrow + panel (one
- * launch), 4 trailing update, 5 level done), and copy a slice of a named device workspace
- * ("front","fvec","wbuf","rbuf","dinv","elem"; "colind","slot_row": the device-built CSR index
+ * a given (tree level, block step, stage: 0 assembled, 1 or 2 pivot block + panel (launch A), 3 or 4 trailing
+ * update + inverse row + pivot write-back (launch B), 5 level done), and copy a slice of a named device workspace
+ * ("front","fvec","fvec2","xl","wbuf","rbuf","dinv","delta","elem"; "colind","slot_row": the device-built CSR index
  * arrays, converted to double).
  * plfem_debug_symeig: the host eigensolver of the Lanczos drivers (projected matrices of order
  * <= ~200; needs no GPU).  a_host: n x n symmetric.  last_rows < 0: v_out[i*n + k] = component k of

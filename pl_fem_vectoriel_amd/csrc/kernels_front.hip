@@ -163,35 +163,12 @@ __device__ __forceinline__ double readlane_f64(double v, int src) {
   return __hiloint2double(hi, lo);
 }
 
-__global__ __launch_bounds__(64) void k_ldl_diag(const int32_t* __restrict__ forder, int kb, const int32_t* __restrict__ fs2,
-                                                 const int32_t* __restrict__ fm, const int64_t* __restrict__ foff,
-                                                 const int64_t* __restrict__ fnode_ptr, double* __restrict__ front,
-                                                 double* __restrict__ dinv, double* __restrict__ delta,
-                                                 double* __restrict__ tbuf, int32_t* __restrict__ counters) {
-  static_assert(NB == 32, "lane map of k_ldl_diag");
-  const int f = forder[blockIdx.x];
-  const int s2 = fs2[f];
-  const int k0 = kb * NB;
-  if (k0 >= s2) return;
-  const int nbk = min(NB, s2 - k0);
-  const int m = fm[f];
-  double* F = front + foff[f];
-  const int lane = threadIdx.x;
-  if (blockIdx.y > 0) {
-    // tbuf[q + j*NB] = L[k0+q, j] for the 64 columns j of this block
-    const int jb = (blockIdx.y - 1) * 64;
-    if (jb >= k0) return;
-    double* T = tbuf + 2 * fnode_ptr[f] * NB;
-    const int q = lane & 31, jh = lane >> 5;
-#pragma unroll 8
-    for (int jj = 0; jj < 64; jj += 2) {
-      const int j = jb + jj + jh;
-      if (j < k0) T[(int64_t)j * NB + q] = (q < nbk) ? F[(int64_t)j * m + (k0 + q)] : 0.0;
-    }
-    return;
-  }
-  __shared__ double srow[NB];
-  __shared__ double tile[NB][NB + 1];
+// The LDL^T of the NB x NB pivot block by ONE wave (64 lanes).  Inputs come straight from F; results go to LDS:
+// tile[i][c] = X[i][c] (X = L^-1, zero above the diagonal), sD[i] = D[i] (1 for the identity padding of a partial block).
+__device__ __forceinline__ void ldl_pivot_wave(const double* __restrict__ F, int m, int k0, int nbk, int lane,
+                                               double (*tile)[NB + 1], double* __restrict__ sD, double* __restrict__ srow,
+                                               int32_t* __restrict__ counters) {
+  static_assert(NB == 32, "lane map of ldl_pivot_wave");
   const int i = lane & 31, h = lane >> 5;
   double v[16];
   double amax = 0.0;
@@ -210,7 +187,7 @@ __global__ __launch_bounds__(64) void k_ldl_diag(const int32_t* __restrict__ for
     double dk = readlane_f64(v[kc], k + 32 * kh);              // a[k][k]
     if (!(fabs(dk) >= thr)) {
       dk = (dk < 0.0) ? -thr : thr;
-      if (lane == 0) atomicAdd(&counters[0], 1);
+      if (lane == 0 && counters) atomicAdd(&counters[0], 1);
     }
     if (i == k) dmine = dk;
     double colk = 0.0;
@@ -244,23 +221,99 @@ __global__ __launch_bounds__(64) void k_ldl_diag(const int32_t* __restrict__ for
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   }
   // x[i][c] = v for c <= i, 0 above the diagonal
-  double* D = dinv + (int64_t)f * NB * NB;
 #pragma unroll
   for (int cc = 0; cc < 16; ++cc) {
     const int c = 16 * h + cc;
-    const double xv = (c <= i) ? v[cc] : 0.0;
-    D[(int64_t)c * NB + i] = xv;
-    tile[i][c] = xv;
+    tile[i][c] = (c <= i) ? v[cc] : 0.0;
   }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  if (h == 0) sD[i] = dmine;
+}
+
+// Launch A of a block step: pivot block + panel.  Every panel workgroup (64 rows below the pivot block, 4 waves of 16
+// rows) factorises the pivot block ITSELF in its wave 0 -- the same arithmetic in every workgroup, so the same bits --
+// while its other waves' panel operands are in flight: no launch boundary between pivot and panel, and nobody writes
+// the pivot block in this launch (workgroup 0 of the front stores X and D in dinv / delta; the block is written back
+// into F by the next launch).  Panel: Y = R X^T (= R L^-T), W = Y D^-1 (= the L panel); W, Y are saved for the update
+// kernel and W replaces R in F (a workgroup reads and writes its own rows only).
+// blockIdx.y < n_tb: these workgroups save the block row L[k, <k] of L11 for the triangular-inverse update (tbuf).
+__global__ __launch_bounds__(256) void k_ldl_pivot_panel(int n_tb, const int32_t* __restrict__ forder, int kb,
+                                                         const int32_t* __restrict__ fs2, const int32_t* __restrict__ fm,
+                                                         const int64_t* __restrict__ foff, const int64_t* __restrict__ fnode_ptr,
+                                                         double* __restrict__ front, double* __restrict__ dinv,
+                                                         double* __restrict__ delta, double* __restrict__ tbuf,
+                                                         double* __restrict__ wbuf, double* __restrict__ rbuf,
+                                                         int32_t* __restrict__ counters) {
+  const int f = forder[blockIdx.x];
+  const int s2 = fs2[f];
+  const int k0 = kb * NB;
+  if (k0 >= s2) return;
+  const int nbk = min(NB, s2 - k0);
+  const int m = fm[f];
+  double* F = front + foff[f];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if ((int)blockIdx.y < n_tb) {
+    // tbuf[q + j*NB] = L[k0+q, j] for the 64 columns j of this block, 16 per wave
+    const int jb = blockIdx.y * 64 + 16 * wave;
+    if (jb >= k0) return;
+    double* T = tbuf + 2 * fnode_ptr[f] * NB;
+    const int q = lane & 31, jh = lane >> 5;
 #pragma unroll
-  for (int cc = 0; cc < 16; ++cc) {
-    const int c = 16 * h + cc;
-    if (i < nbk && c < nbk) F[(int64_t)(k0 + c) * m + (k0 + i)] = (i >= c) ? tile[i][c] : tile[c][i];
+    for (int jj = 0; jj < 16; jj += 2) {
+      const int j = jb + jj + jh;
+      if (j < k0) T[(int64_t)j * NB + q] = (q < nbk) ? F[(int64_t)j * m + (k0 + q)] : 0.0;
+    }
+    return;
   }
-  if (h == 0 && i < nbk) delta[2 * fnode_ptr[f] + k0 + i] = dmine;
+  const int bx = blockIdx.y - n_tb;
+  const int i0 = k0 + nbk + bx * 64;
+  if (bx > 0 && i0 >= m) return;
+  __shared__ double srow[NB];
+  __shared__ double tile[NB][NB + 1];
+  __shared__ double sD[NB];
+  // this wave's 16 panel rows: B operand R^T (k = pivot column j, col = row i), requested before the pivot work
+  const int lr = lane & 15, lk = lane >> 4;
+  const int ibase = i0 + 16 * wave;
+  const bool rows = ibase < m;                           // m is a multiple of 16: the wave's 16 rows are all valid
+  const int i = ibase + lr;
+  double b[NB / 4];
+#pragma unroll
+  for (int kk = 0; kk < NB / 4; ++kk) {
+    const int jx = 4 * kk + lk;
+    b[kk] = (rows && jx < nbk) ? F[(int64_t)(k0 + jx) * m + i] : 0.0;
+  }
+  if (wave == 0) ldl_pivot_wave(F, m, k0, nbk, lane, tile, sD, srow, bx == 0 ? counters : nullptr);
+  __syncthreads();
+  if (bx == 0) {
+    double* D = dinv + (int64_t)f * NB * NB;              // D[r + c*NB] = X[r][c]
+    for (int e = threadIdx.x; e < NB * NB; e += 256) D[e] = tile[e & (NB - 1)][e >> 5];
+    if (threadIdx.x < nbk) delta[2 * fnode_ptr[f] + k0 + threadIdx.x] = sD[threadIdx.x];
+  }
+  if (!rows) return;
+  // Y^T[c][i] = sum_j X[c][j] R[i][j] on v_mfma_f64_16x16x4_f64: A <- X (row c, k = j), B <- R^T; the accumulator
+  // register r of lane l is Y[i = ibase + (l & 15)][c = 16 tc + (l >> 4) + 4 r]: 128-B runs of W, Y and of the panel
+  // columns of F.
+  double* W = wbuf + 2 * fnode_ptr[f] * NB;
+  double* Y = rbuf + 2 * fnode_ptr[f] * NB;
+  v4d y0 = (v4d){0.0, 0.0, 0.0, 0.0}, y1 = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int kk = 0; kk < NB / 4; ++kk) {
+    const int jx = 4 * kk + lk;
+    y0 = __builtin_amdgcn_mfma_f64_16x16x4f64(tile[lr][jx], b[kk], y0, 0, 0, 0);
+    y1 = __builtin_amdgcn_mfma_f64_16x16x4f64(tile[16 + lr][jx], b[kk], y1, 0, 0, 0);
+  }
+#pragma unroll
+  for (int tc = 0; tc < 2; ++tc)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int c = 16 * tc + lk + 4 * r;
+      const double y = tc == 0 ? y0[r] : y1[r];
+      const double w = (c < nbk) ? y * fast_rcp(sD[c]) : 0.0;
+      W[(int64_t)c * m + i] = w;
+      Y[(int64_t)c * m + i] = y;
+      if (c < nbk) F[(int64_t)(k0 + c) * m + i] = w;
+    }
+  // (no mirrored copy L^T in the rows of the pivot block: those entries are overwritten -- by the triangular-inverse
+  // update inside F11, by Z^T in F12 -- before anything reads them)
 }
 
 // Triangular-inverse update: with X<k the inverse of the leading k0 x k0 block of L11,
@@ -269,11 +322,10 @@ __global__ __launch_bounds__(64) void k_ldl_diag(const int32_t* __restrict__ for
 //   T (32 x 16) = L[k, j>=c0] (A: tbuf, contiguous in q) * X<k[j, c] (B: upper mirror, contiguous in c);
 //   the accumulator register r of lane (lr, lk) holds T[lk + 4 r][lr], which is exactly the B operand
 //   of k-step r of the second product  Xnew = -X[k,k] * T  -- no cross-lane movement.
-__device__ __forceinline__ void ldl_invrow_block(int bx, const int32_t* __restrict__ forder, int kb, const int32_t* __restrict__ fs2,
+__device__ __forceinline__ void ldl_invrow_block(int f, int bx, int kb, const int32_t* __restrict__ fs2,
                                                  const int32_t* __restrict__ fm, const int64_t* __restrict__ foff,
                                                  const int64_t* __restrict__ fnode_ptr, double* __restrict__ front,
                                                  const double* __restrict__ dinv, const double* __restrict__ tbuf) {
-  const int f = forder[blockIdx.x];      // fronts along x (no 65535 limit), block index within the front along y
   const int s2 = fs2[f];
   const int k0 = kb * NB;
   if (k0 >= s2 || k0 == 0) return;
@@ -334,84 +386,6 @@ __device__ __forceinline__ void ldl_invrow_block(int bx, const int32_t* __restri
   }
 }
 
-// Panel below the pivot block: Y = R X^T (= R L^-T), W = Y D^-1 (= the L panel).  Saves W, Y for the
-// update kernel and writes W into F (columns of the pivot block).
-__device__ __forceinline__ void ldl_panel_block(int bx, const int32_t* __restrict__ forder, int kb, const int32_t* __restrict__ fs2,
-                                                const int32_t* __restrict__ fm, const int64_t* __restrict__ foff,
-                                                const int64_t* __restrict__ fnode_ptr, double* __restrict__ front,
-                                                const double* __restrict__ dinv, const double* __restrict__ delta,
-                                                double* __restrict__ wbuf, double* __restrict__ rbuf) {
-  const int f = forder[blockIdx.x];      // fronts along x (no 65535 limit), block index within the front along y
-  const int s2 = fs2[f];
-  const int k0 = kb * NB;
-  if (k0 >= s2) return;
-  const int m = fm[f];
-  const int nbk = min(NB, s2 - k0);
-  const int i0 = k0 + nbk + bx * 64;
-  if (i0 >= m) return;
-  double* F = front + foff[f];
-  const double* D = dinv + (int64_t)f * NB * NB;       // D[r + c*NB] = X[r][c]
-  const double* dl = delta + 2 * fnode_ptr[f] + k0;
-  double* W = wbuf + 2 * fnode_ptr[f] * NB;
-  double* Y = rbuf + 2 * fnode_ptr[f] * NB;
-  // Y^T[c][i] = sum_j X[c][j] R[i][j] on v_mfma_f64_16x16x4_f64: A <- X (row c, k = j: contiguous in c in dinv),
-  // B <- R^T (k = j, col i: the panel columns of F, contiguous in i); the accumulator register r of lane l is
-  // Y[i = ibase + (l & 15)][c = 16 tc + (l >> 4) + 4 r]: 128-B runs of W, Y and of the panel columns of F.
-  // One wave = 16 rows i x all 32 columns; every operand (24 loads) is requested before the first MFMA.
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int lr = lane & 15, lk = lane >> 4;
-  const int ibase = i0 + 16 * wave;
-  if (ibase >= m) return;                              // m is a multiple of 16: the wave's 16 rows are all valid
-  const int i = ibase + lr;
-  double a0[NB / 4], a1[NB / 4], b[NB / 4];
-#pragma unroll
-  for (int kk = 0; kk < NB / 4; ++kk) {
-    const int jx = 4 * kk + lk;
-    a0[kk] = D[lr + (int64_t)jx * NB];
-    a1[kk] = D[16 + lr + (int64_t)jx * NB];
-    b[kk] = (jx < nbk) ? F[(int64_t)(k0 + jx) * m + i] : 0.0;
-  }
-  double di[2][4];
-#pragma unroll
-  for (int tc = 0; tc < 2; ++tc)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int c = 16 * tc + lk + 4 * r;
-      di[tc][r] = (c < nbk) ? fast_rcp(dl[c]) : 0.0;
-    }
-  v4d y0 = (v4d){0.0, 0.0, 0.0, 0.0}, y1 = (v4d){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-  for (int kk = 0; kk < NB / 4; ++kk) {
-    y0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[kk], b[kk], y0, 0, 0, 0);
-    y1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[kk], b[kk], y1, 0, 0, 0);
-  }
-#pragma unroll
-  for (int tc = 0; tc < 2; ++tc)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int c = 16 * tc + lk + 4 * r;
-      const double y = tc == 0 ? y0[r] : y1[r];
-      const double w = y * di[tc][r];
-      W[(int64_t)c * m + i] = w;
-      Y[(int64_t)c * m + i] = y;
-      if (c < nbk) F[(int64_t)(k0 + c) * m + i] = w;
-    }
-  // (no mirrored copy L^T in the rows of the pivot block: those entries are overwritten -- by the triangular-inverse
-  // update inside F11, by Z^T in F12 -- before anything reads them)
-}
-
-// The triangular-inverse update and the panel only depend on the pivot kernel, so one launch runs both:
-// blocks [0, n_inv) of y are invrow blocks, the rest panel blocks.
-__global__ __launch_bounds__(256) void k_ldl_invrow_panel(int n_inv, const int32_t* __restrict__ forder, int kb, const int32_t* __restrict__ fs2,
-                                                          const int32_t* __restrict__ fm, const int64_t* __restrict__ foff,
-                                                          const int64_t* __restrict__ fnode_ptr, double* __restrict__ front,
-                                                          const double* __restrict__ dinv, const double* __restrict__ delta,
-                                                          const double* __restrict__ tbuf, double* __restrict__ wbuf,
-                                                          double* __restrict__ rbuf) {
-  if ((int)blockIdx.y < n_inv) ldl_invrow_block(blockIdx.y, forder, kb, fs2, fm, foff, fnode_ptr, front, dinv, tbuf);
-  else ldl_panel_block(blockIdx.y - n_inv, forder, kb, fs2, fm, foff, fnode_ptr, front, dinv, delta, wbuf, rbuf);
-}
-
 // Trailing update: F[i,j] -= sum_c W[i,c] Y[j,c] for i, j >= k0 + nbk, one 32x32 tile per wave as 2x2
 // v_mfma_f64_16x16x4_f64 tiles.  MFMA operand map (gfx950): A[row = l&15][k = l>>4],
 // B[k = l>>4][col = l&15], D[row = (l>>4) + 4 r][col = l&15].  With A <- Y rows (j) and B <- W rows
@@ -425,12 +399,12 @@ __global__ __launch_bounds__(256) void k_ldl_invrow_panel(int n_inv, const int32
 // The panel kernel stores all NB columns of W and Y (zeros past nbk): fixed trip counts, and every operand
 // of a rank-32 batch (32 loads) plus the 16 loads of the tile itself are requested before the first MFMA.
 template <int MODE>
-__global__ __launch_bounds__(256) void k_ldl_update(const int2* __restrict__ tiles, int kb, const int32_t* __restrict__ fs2,
-                                                    const int32_t* __restrict__ fm, const int64_t* __restrict__ foff,
-                                                    const int64_t* __restrict__ fnode_ptr, double* __restrict__ front,
-                                                    const double* __restrict__ wbuf, const double* __restrict__ rbuf,
-                                                    const double* __restrict__ wbuf_prev, const double* __restrict__ rbuf_prev) {
-  const int2 job = tiles[blockIdx.x];                    // (front, tx | ty << 16): a 64 x 64 block of the trailing matrix
+__device__ __forceinline__ void ldl_update_tile(const int2 job, int kb, const int32_t* __restrict__ fs2,
+                                                const int32_t* __restrict__ fm, const int64_t* __restrict__ foff,
+                                                const int64_t* __restrict__ fnode_ptr, double* __restrict__ front,
+                                                const double* __restrict__ wbuf, const double* __restrict__ rbuf,
+                                                const double* __restrict__ wbuf_prev, const double* __restrict__ rbuf_prev) {
+  // job = (front, tx | ty << 16): a 64 x 64 block of the trailing matrix
   const int f = job.x;
   const int s2 = fs2[f];
   const int k0 = kb * NB;
@@ -499,6 +473,42 @@ __global__ __launch_bounds__(256) void k_ldl_update(const int2* __restrict__ til
       for (int r = 0; r < 4; ++r)
         F[(int64_t)(j0 + 16 * tj + lk + 4 * r) * m + (i0 + 16 * ti + lr)] = fv[tj][ti][r] - acc[tj][ti][r];
     }
+  }
+}
+
+// Launch B of a block step: the trailing update (workgroups [0, un): the step's tile list) and, for every active
+// front, the triangular-inverse update of the block row (n_inv workgroups) plus one workgroup that writes the pivot
+// block of this step (lower X, upper X^T, from dinv) back into F -- all independent of one another: the update touches
+// rows / columns behind the pivot block, the inverse update rows of the pivot block in earlier columns.
+template <int MODE>
+__global__ __launch_bounds__(256) void k_ldl_update(int un, int n_inv, const int2* __restrict__ tiles,
+                                                    const int32_t* __restrict__ forder, int kb, const int32_t* __restrict__ fs2,
+                                                    const int32_t* __restrict__ fm, const int64_t* __restrict__ foff,
+                                                    const int64_t* __restrict__ fnode_ptr, double* __restrict__ front,
+                                                    const double* __restrict__ dinv, const double* __restrict__ tbuf,
+                                                    const double* __restrict__ wbuf, const double* __restrict__ rbuf,
+                                                    const double* __restrict__ wbuf_prev, const double* __restrict__ rbuf_prev) {
+  if ((int)blockIdx.x < un) {
+    ldl_update_tile<MODE>(tiles[blockIdx.x], kb, fs2, fm, foff, fnode_ptr, front, wbuf, rbuf, wbuf_prev, rbuf_prev);
+    return;
+  }
+  const int e = blockIdx.x - un;
+  const int f = forder[e / (n_inv + 1)];
+  const int sub = e % (n_inv + 1);
+  if (sub < n_inv) {
+    ldl_invrow_block(f, sub, kb, fs2, fm, foff, fnode_ptr, front, dinv, tbuf);
+    return;
+  }
+  const int s2 = fs2[f];
+  const int k0 = kb * NB;
+  if (k0 >= s2) return;
+  const int nbk = min(NB, s2 - k0);
+  const int m = fm[f];
+  double* F = front + foff[f];
+  const double* D = dinv + (int64_t)f * NB * NB;          // D[r + c*NB] = X[r][c], zero above the diagonal
+  for (int q = threadIdx.x; q < NB * NB; q += 256) {
+    const int i = q & (NB - 1), c = q >> 5;
+    if (i < nbk && c < nbk) F[(int64_t)(k0 + c) * m + (k0 + i)] = (i >= c) ? D[i + c * NB] : D[c + i * NB];
   }
 }
 
@@ -585,7 +595,7 @@ __global__ __launch_bounds__(256) void k_mirror_z(const int2* __restrict__ tiles
 
 void launch_factor(plfem_ctx* c, double sigma, int stop_level, int stop_step, int stop_stage) {
   // stop_*: debugging aid (plfem_debug_factor_until); stop_level < 0 = run to completion.
-  // stages: 0 assembled, 1 diag, 2 or 3 invrow + panel (one launch), 4 update, 5 level done
+  // stages: 0 assembled, 1 or 2 pivot + panel (launch A), 3 or 4 update + inverse row + pivot write-back (launch B), 5 level done
   hipStream_t st = c->stream;
   (void)hipMemsetAsync(c->d_counters, 0, 4 * sizeof(int32_t), st);
   for (int lev = c->L; lev >= 0; --lev) {
@@ -625,33 +635,28 @@ void launch_factor(plfem_ctx* c, double sigma, int stop_level, int stop_step, in
       }
       if (nact == 0) break;
       const int max_trail = hpm[nact - 1] - k0 - 16;   // upper bound of the trailing order after this step
-      hipLaunchKernelGGL(k_ldl_diag, dim3(nact, 1 + (k0 + 63) / 64), dim3(64), 0, st, ford, kb, c->d_fs2, c->d_fm, c->d_foff,
-                         c->d_fnode_ptr, c->d_front, c->d_dinv, c->d_delta, c->d_tbuf, c->d_counters);
-      if (stop_here && stop_stage == 1) return;
-      // W / Y of even and odd steps live in separate halves of wbuf / rbuf (see k_ldl_update)
+      // W / Y of even and odd steps live in separate halves of wbuf / rbuf (see ldl_update_tile)
       const size_t half = (size_t)2 * c->fnodes_total * NB;
       double* wb = c->d_wbuf + (kb & 1) * half;
       double* rb = c->d_rbuf + (kb & 1) * half;
-      {
-        const int n_inv = kb > 0 ? (k0 + 63) / 64 : 0;
-        const int n_pan = max_trail > 0 ? (max_trail + 63) / 64 : 0;
-        if (n_inv + n_pan > 0)
-          hipLaunchKernelGGL(k_ldl_invrow_panel, dim3(nact, n_inv + n_pan), dim3(256), 0, st, n_inv, ford, kb,
-                             c->d_fs2, c->d_fm, c->d_foff, c->d_fnode_ptr, c->d_front, c->d_dinv, c->d_delta, c->d_tbuf,
-                             wb, rb);
-      }
-      if (stop_here && (stop_stage == 2 || stop_stage == 3)) return;
+      // launch A: pivot block + panel (+ the copy of the block row of L11 for the triangular-inverse update)
+      const int n_tb = (k0 + 63) / 64;
+      const int n_pan = std::max(1, max_trail > 0 ? (max_trail + 63) / 64 : 0);   // workgroup 0 always: it owns the pivot results
+      hipLaunchKernelGGL(k_ldl_pivot_panel, dim3(nact, n_tb + n_pan), dim3(256), 0, st, n_tb, ford, kb, c->d_fs2, c->d_fm,
+                         c->d_foff, c->d_fnode_ptr, c->d_front, c->d_dinv, c->d_delta, c->d_tbuf, wb, rb, c->d_counters);
+      if (stop_here && stop_stage >= 1 && stop_stage <= 2) return;
+      // launch B: trailing update + triangular-inverse update + write-back of the pivot block
       const int un = c->upd_n[li.step0 + kb];                  // 64 x 64 blocks of this step's trailing updates
-      if (un > 0) {
-        const int2* ut = c->d_tiles + c->upd_off[li.step0 + kb];
-        if ((kb & 1) == 0)
-          hipLaunchKernelGGL(k_ldl_update<0>, dim3(un), dim3(256), 0, st, ut, kb, c->d_fs2, c->d_fm, c->d_foff,
-                             c->d_fnode_ptr, c->d_front, wb, rb, wb, rb);
-        else
-          hipLaunchKernelGGL(k_ldl_update<1>, dim3(un), dim3(256), 0, st, ut, kb, c->d_fs2, c->d_fm, c->d_foff,
-                             c->d_fnode_ptr, c->d_front, wb, rb, c->d_wbuf, c->d_rbuf);
-      }
-      if (stop_here && stop_stage == 4) return;
+      const int n_inv = kb > 0 ? (k0 + 63) / 64 : 0;
+      const int2* ut = c->d_tiles + c->upd_off[li.step0 + kb];
+      const unsigned gridB = (unsigned)(un + nact * (n_inv + 1));
+      if ((kb & 1) == 0)
+        hipLaunchKernelGGL(k_ldl_update<0>, dim3(gridB), dim3(256), 0, st, un, n_inv, ut, ford, kb, c->d_fs2, c->d_fm, c->d_foff,
+                           c->d_fnode_ptr, c->d_front, c->d_dinv, c->d_tbuf, wb, rb, wb, rb);
+      else
+        hipLaunchKernelGGL(k_ldl_update<1>, dim3(gridB), dim3(256), 0, st, un, n_inv, ut, ford, kb, c->d_fs2, c->d_fm, c->d_foff,
+                           c->d_fnode_ptr, c->d_front, c->d_dinv, c->d_tbuf, wb, rb, c->d_wbuf, c->d_rbuf);
+      if (stop_here && (stop_stage == 3 || stop_stage == 4)) return;
     }
     if (li.formz_n > 0) {
       const int2* zt = c->d_tiles + li.formz_off;

@@ -39,6 +39,7 @@ namespace {
 struct SweepArgs {
   const int2* blk;
   int leaf_level;
+  int ldv;                         // row forms: leading dimension of the staged vector in LDS (component-major [u][i])
   int sh;                          // unknowns per node - 1: node of a local DOF = i >> sh, component = i & sh
   const int32_t *fs2, *fm;
   const int64_t *foff, *fnode_ptr;
@@ -74,6 +75,12 @@ __device__ __forceinline__ void multi_reduce(double (&a)[V], int lane) {
   for (int off = V; off < 64; off <<= 1) a[0] += __shfl_xor(a[0], off);
 }
 
+// LDS layout of the staged vector: tile forms read one entry for all lanes (broadcast) and keep the P values of a DOF
+// together ([i][P]: two 16-byte reads); row forms read a different DOF per lane, where [i][P] is a 32-byte lane stride
+// (4-way bank conflicts: 60 % of the LDS cycles of those kernels) -- they use [u][i] (lane stride 8 bytes).
+template <int P, bool SOA>
+__device__ __forceinline__ int sidx(int i, int u, int ldv) { return SOA ? u * ldv + i : i * P + u; }
+
 // ---- staging -------------------------------------------------------------------------------------------------
 // forward: r_i = fr_i (owned rows) + the children's pushes (masked by the child maps)
 template <int P>
@@ -100,14 +107,14 @@ struct FwdStage {
   }
 };
 
-template <int P>
+template <int P, bool SOA>
 __device__ __forceinline__ void stage_fwd(const SweepArgs& A, double* sv, int64_t np, int need, int T, int tid,
                                           FwdStage<P>& first) {
   for (int i = tid + T; i < need; i += T) {            // (fronts with more than T owned DOFs only)
     FwdStage<P> s;
     s.request(A, np, i, true);
 #pragma unroll
-    for (int u = 0; u < P; ++u) sv[i * P + u] = s.value(u);
+    for (int u = 0; u < P; ++u) sv[sidx<P, SOA>(i, u, A.ldv)] = s.value(u);
   }
   first.request(A, np, tid, tid < need);
 }
@@ -160,7 +167,7 @@ __global__ __launch_bounds__(NW * 64) void k_fwd(SweepArgs A) {
   FwdOut<P> out;
   if (wave == 0) out.request(A, f, np, s2, m, r);
   FwdStage<P> st;
-  stage_fwd<P>(A, sv, np, need, NW * 64, tid, st);
+  stage_fwd<P, false>(A, sv, np, need, NW * 64, tid, st);
   // first batch of this wave's columns (c == wave mod NW), requested before the staged vector is complete
   double a0[TB];
 #pragma unroll
@@ -243,7 +250,7 @@ __global__ __launch_bounds__(NW * 64) void k_fwd_rows(SweepArgs A) {
   FwdOut<P> out;
   out.request(A, f, np, s2, m, lane < V ? orow : m);
   FwdStage<P> st;
-  stage_fwd<P>(A, sv, np, need, NW * 64, tid, st);
+  stage_fwd<P, true>(A, sv, np, need, NW * 64, tid, st);
   double a0[UNR][R];
 #pragma unroll
   for (int t = 0; t < UNR; ++t) {
@@ -253,7 +260,7 @@ __global__ __launch_bounds__(NW * 64) void k_fwd_rows(SweepArgs A) {
   }
   if (tid < need) {
 #pragma unroll
-    for (int u = 0; u < P; ++u) sv[tid * P + u] = st.value(u);
+    for (int u = 0; u < P; ++u) sv[u * A.ldv + tid] = st.value(u);
   }
   __syncthreads();
   double acc[V];
@@ -265,7 +272,7 @@ __global__ __launch_bounds__(NW * 64) void k_fwd_rows(SweepArgs A) {
     if (i < cmax) {
 #pragma unroll
       for (int u = 0; u < P; ++u) {
-        const double vi = sv[i * P + u];
+        const double vi = sv[u * A.ldv + i];
 #pragma unroll
         for (int q = 0; q < R; ++q) acc[q * P + u] += a0[t][q] * vi;
       }
@@ -285,7 +292,7 @@ __global__ __launch_bounds__(NW * 64) void k_fwd_rows(SweepArgs A) {
       if (i < cmax) {
 #pragma unroll
         for (int u = 0; u < P; ++u) {
-          const double vi = sv[i * P + u];
+          const double vi = sv[u * A.ldv + i];
 #pragma unroll
           for (int q = 0; q < R; ++q) acc[q * P + u] += a[t][q] * vi;
         }
@@ -332,10 +339,11 @@ struct BwdStage {
       for (int u = 0; u < P; ++u) v[u] = pr >= 0 ? -A.xl[(2 * npp + (pr << A.sh) + (i & A.sh)) * P + u] : 0.0;
     }
   }
+  template <bool SOA>
   __device__ __forceinline__ void finish(const SweepArgs& A, double* sv, int64_t np, bool publish) const {
     if (!on) return;
 #pragma unroll
-    for (int u = 0; u < P; ++u) sv[i * P + u] = v[u];
+    for (int u = 0; u < P; ++u) sv[sidx<P, SOA>(i, u, A.ldv)] = v[u];
     if (publish && !own) {
 #pragma unroll
       for (int u = 0; u < P; ++u) A.xl[(2 * np + i) * P + u] = -v[u];
@@ -343,14 +351,14 @@ struct BwdStage {
   }
 };
 
-template <int P>
+template <int P, bool SOA>
 __device__ __forceinline__ void stage_bwd_rest(const SweepArgs& A, double* sv, int lo, int m, int s2, int64_t np,
                                                int64_t npp, int T, int tid, bool publish) {
   for (int i = lo + tid + T; i < m; i += T) {             // (fronts with more than T DOFs behind lo only)
     BwdStage<P> s;
     s.request_index(A, np, s2, i, true);
     s.request_value(A, npp);
-    s.finish(A, sv, np, publish);
+    s.template finish<SOA>(A, sv, np, publish);
   }
 }
 
@@ -378,8 +386,8 @@ __global__ __launch_bounds__(NW * 64) void k_bwd(SweepArgs A) {
 #pragma unroll
   for (int t = 0; t < TB; ++t) a0[t] = (cstart + NW * t < ce) ? p[(int64_t)(cstart + NW * t) * m] : 0.0;
   st.request_value(A, npp);
-  stage_bwd_rest<P>(A, sv, r0, m, s2, np, npp, NW * 64, tid, publish);
-  st.finish(A, sv, np, publish);
+  stage_bwd_rest<P, false>(A, sv, r0, m, s2, np, npp, NW * 64, tid, publish);
+  st.template finish<false>(A, sv, np, publish);
   __syncthreads();
   double acc[P];
 #pragma unroll
@@ -452,8 +460,8 @@ __global__ __launch_bounds__(NW * 64) void k_bwd_rows(SweepArgs A) {
     for (int q = 0; q < R; ++q) a0[t][q] = (i < m && i >= jq[q]) ? F[i + (int64_t)jq[q] * m] : 0.0;
   }
   st.request_value(A, npp);
-  stage_bwd_rest<P>(A, sv, lo, m, s2, np, npp, NW * 64, tid, publish);
-  st.finish(A, sv, np, publish);
+  stage_bwd_rest<P, true>(A, sv, lo, m, s2, np, npp, NW * 64, tid, publish);
+  st.template finish<true>(A, sv, np, publish);
   __syncthreads();
   const int oidx = multi_reduce_index<V>(lane & (V - 1));
   const int oj = j0 + wave + NW * (oidx / P);
@@ -466,7 +474,7 @@ __global__ __launch_bounds__(NW * 64) void k_bwd_rows(SweepArgs A) {
     if (i < m) {
 #pragma unroll
       for (int u = 0; u < P; ++u) {
-        const double vi = sv[i * P + u];
+        const double vi = sv[u * A.ldv + i];
 #pragma unroll
         for (int q = 0; q < R; ++q) acc[q * P + u] += a0[t][q] * vi;
       }
@@ -486,7 +494,7 @@ __global__ __launch_bounds__(NW * 64) void k_bwd_rows(SweepArgs A) {
       if (i < m) {
 #pragma unroll
         for (int u = 0; u < P; ++u) {
-          const double vi = sv[i * P + u];
+          const double vi = sv[u * A.ldv + i];
 #pragma unroll
           for (int q = 0; q < R; ++q) acc[q * P + u] += a[t][q] * vi;
         }
@@ -544,6 +552,7 @@ void sweeps(plfem_ctx* c) {
     A.leaf_level = lev == c->L ? 1 : 0;
     A.blk = c->d_blk + li.fwd_off;
     const size_t lds = sizeof(double) * P * (li.max_s2 + 1);
+    A.ldv = li.max_s2 + 1;
     if (li.fwd_rows == 8)
       hipLaunchKernelGGL((k_fwd_rows<P, 8, 1>), dim3(li.fwd_n), dim3(512), lds, st, A);
     else if (li.fwd_rows == 16)
@@ -563,6 +572,7 @@ void sweeps(plfem_ctx* c) {
     A.leaf_level = lev == c->L ? 1 : 0;
     A.blk = c->d_blk + li.bwd_off;
     const size_t lds = sizeof(double) * P * (li.max_m + 1);
+    A.ldv = li.max_m + 1;
     if (li.bwd_rows == 64)    // leaf fronts (about as many owned rows as boundary columns): tile form
       hipLaunchKernelGGL((k_bwd<P, 8>), dim3(li.bwd_n), dim3(512), lds, st, A);
     else if (li.bwd_rows == 8)   // few large fronts: one row per wave, most blocks

@@ -580,3 +580,23 @@ def test_loss_consumer_takes_the_mode_records_of_a_real_solve(medium, gpu_device
             assert np.isfinite(got[key])
             assert abs(got[key] - ref[key]) <= 1e-6 * max(1.0, abs(ref[key])), (direction, key)
     assert 0.0 < got["IL_dB"] < 40.0 and -40.0 <= got["crosstalk_dB"] <= -15.0
+
+
+def test_mesh_generator_feeds_the_solver(gpu_device, built_library):
+    """Row f1 end to end: MeshGenerator.generate (reference mesh.py:82-340: point recipe, Delaunay, refinement loop
+    driven by SimulationConfig, class-level cache) -> (mesh, basis) -> solve on the GPU = the oracle on that mesh."""
+    from pl_fem_vectoriel_amd.mesh import MeshGenerator, SimulationConfig
+    MeshGenerator.clear_cache()
+    g = MCFGeometry(3, 8.0, 1.5, 1.535, 1.0, wavelength_um=1.55)
+    cfg = SimulationConfig(mesh_min_points=4000, mesh_target_points=12000)
+    mesh, basis = MeshGenerator.generate(g, refinement=0.4, config=cfg)
+    assert mesh.nvertices >= 4000 and basis.N == mesh.nvertices + mesh.edges()[0].shape[1]
+    again, _ = MeshGenerator.generate(g, refinement=0.4, config=cfg)
+    assert again is mesh and MeshGenerator.get_cache_stats()["hits"] == 1
+    solver = TrueVectorialMaxwellSolver(g, device=gpu_device)
+    modes = solver.solve_vectorial_modes(mesh, n_modes_target=6)
+    ref = hfield.solve_vectorial_modes(g, MeshTriLite(mesh.p, mesh.t), n_modes_target=6, fused=True)
+    assert len(modes) == len(ref) > 0 and solver.last_stats["N"] == basis.N
+    assert max(abs(a["n_eff"] - b["n_eff"]) for a, b in zip(modes, ref)) < N_EFF_TOL
+    assert mode_field_errors(modes, ref).max() < FIELD_TOL
+    MeshGenerator.clear_cache()

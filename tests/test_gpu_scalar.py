@@ -63,7 +63,7 @@ def test_scalar_modes_match_oracle(arrangement, gpu_device, built_library):
     modes = solver.solve(mesh, n_modes_target=10)
     ref, raw = scalar.solve(g, MeshTriLite(mesh.p, mesh.t), 10, return_raw=True)
     st = solver.last_stats
-    assert st["n_req"] == 18 and st["nconv"] == 18 and st["true_residual"] < 1e-8 and st["pivot_perturbations"] == 0
+    assert st["n_req"] == 18 and st["nconv"] == 18 and st["true_residual"] < ScalarHelmholtzSolver.RESIDUAL_TOL and st["refined"] is False and st["pivot_perturbations"] == 0
     assert len(modes) == len(ref) > 0
     assert [m["n_eff"] for m in modes] == sorted((m["n_eff"] for m in modes), reverse=True)
     for a, b in zip(modes, ref):
@@ -78,7 +78,7 @@ def test_scalar_modes_match_oracle(arrangement, gpu_device, built_library):
     assert np.abs(np.einsum("ij,ji->i", V, Mm @ V.T) - 1.0).max() < 1e-10           # v.M v = 1 (solver_fem.py:268)
     lam = -np.array([(m["beta"]) ** 2 for m in ref])
     nrm = np.linalg.norm(U, axis=0)
-    err = column_errors(V / np.linalg.norm(V, axis=1)[:, None], U / nrm, lam, 1e-5)
+    err = column_errors((V / np.linalg.norm(V, axis=1)[:, None]).T, U / nrm, lam, 1e-5)
     assert err.max() < FIELD_TOL
     gaps = np.abs(np.diff(lam)) / np.abs(lam[1:])
     iso = np.ones(len(lam), bool)
