@@ -266,6 +266,9 @@ int plfem_profile_end(plfem_ctx* ctx, double* out_host /* [PLFEM_PROF_COUNT][3] 
  * ------------------------------------------------------------------------------------------- */
 int plfem_debug_factor_until(plfem_ctx* ctx, double sigma, int32_t level, int32_t step, int32_t stage);
 int plfem_debug_copy(plfem_ctx* ctx, const char* name, int64_t offset, int64_t count, double* out_host);
+/* timing aid of scripts/: reps block solves of a zero right-hand side; filter != 0 leaves out a class of fronts (results
+ * are then wrong, only the kernel times mean something): 1 = skip fronts with more than 128 owned DOFs, 2 = only those */
+int plfem_debug_solve_block(plfem_ctx* ctx, int32_t reps, int32_t filter);
 int plfem_debug_symeig(int32_t n, const double* a_host, int32_t last_rows, double* w_out, double* v_out);
 int plfem_debug_symeig_band(int32_t n, int32_t b, const double* a_host, int32_t nsel, double* w_out, double* v_out);
 

@@ -33,6 +33,7 @@ EXPORTS = (
     "plfem_debug_factor_until", "plfem_debug_copy", "plfem_profile_begin", "plfem_profile_end",
     "plfem_mesh_edge_count", "plfem_mesh_refine", "plfem_debug_symeig", "plfem_debug_symeig_band",
     "plfem_residuals", "plfem_set_option", "plfem_symbolic_create_ex", "plfem_assemble_scalar", "plfem_cmt_coupling",
+    "plfem_debug_solve_block",
 )
 MAX_NCV = 320                       # PLFEM_MAX_NCV of include/plfem.h
 PROF_SLOTS = ("k_fwd", "fwd_sweep", "bwd_sweep", "spmv_b")
@@ -42,7 +43,7 @@ _ARRAY_DTYPES = {
     "interior": np.int32, "int_index": np.int32, "rowptr": np.int32, "colind": np.int32, "slot_row": np.int32,
     "nptr": np.int32, "nadj": np.int32, "nloc": np.uint8, "leaf_of_elem": np.int32, "leaf_elem_ptr": np.int32, "leaf_elems": np.int32, "epos": np.int32,
     "owner": np.int32, "fs": np.int32, "fb": np.int32, "fs_true": np.int32, "fb_true": np.int32,
-    "fnode_ptr": np.int64, "fnodes": np.int32, "cinv0": np.int32, "cinv1": np.int32, "foff": np.int64,
+    "fnode_ptr": np.int64, "fnodes": np.int32, "cinv0": np.int32, "cinv1": np.int32, "foff": np.int64, "prow": np.int32, "npos": np.int32,
 }
 
 
@@ -117,6 +118,7 @@ def load_library() -> ctypes.CDLL:
     lib.plfem_debug_factor_until.argtypes = [ctypes.c_void_p, ctypes.c_double, ctypes.c_int32, ctypes.c_int32,
                                              ctypes.c_int32]
     lib.plfem_debug_copy.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p]
+    lib.plfem_debug_solve_block.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32]
     lib.plfem_mesh_edge_count.argtypes = [ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p,
                                           ctypes.POINTER(ctypes.c_int32), ctypes.c_char_p, ctypes.c_int32]
     lib.plfem_mesh_refine.argtypes = [ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p,
@@ -384,6 +386,9 @@ class Context:
         self._check(self._lib.plfem_debug_copy(self._h, name.encode(), ctypes.c_int64(int(offset)),
                                                ctypes.c_int64(int(count)), _ptr(out)), "plfem_debug_copy")
         return out
+
+    def debug_solve_block(self, reps: int = 1, front_filter: int = 0):
+        self._check(self._lib.plfem_debug_solve_block(self._h, int(reps), int(front_filter)), "plfem_debug_solve_block")
 
     def profile_begin(self, max_launches: int = 4096):
         self._check(self._lib.plfem_profile_begin(self._h, int(max_launches)), "plfem_profile_begin")

@@ -313,28 +313,6 @@ int create_impl(plfem_ctx* c, const plfem_symbolic* sym, int device, void* strea
     }
     if (size_only) tiles.resize((size_t)ntiles);          // only its size matters to the placement pass
   }
-  // front order of the solve vectors: node -> position of its owned slot; local node -> local node in the parent front
-  std::vector<int32_t> npos, prow;
-  if (!size_only) {
-    npos.assign((size_t)S.N, -1);
-    prow.assign((size_t)S.fnode_ptr[S.nfronts], -1);
-    for (int f = 0; f < S.nfronts; ++f) {
-      const int64_t np = S.fnode_ptr[f];
-      for (int q = 0; q < S.fs_true[f]; ++q) npos[S.fnodes[np + q]] = (int32_t)(2 * np + S.dpn * q);
-      if (2 * f + 2 < S.nfronts) {
-        const int64_t n0 = S.fnode_ptr[2 * f + 1] + S.fs[2 * f + 1], n1 = S.fnode_ptr[2 * f + 2] + S.fs[2 * f + 2];
-        const int mn = S.fs[f] + S.fb[f];
-        for (int q = 0; q < mn; ++q) {
-          const int32_t c0 = S.cinv0[np + q], c1 = S.cinv1[np + q];
-          if (c0 >= 0) prow[n0 + c0] = q;
-          if (c1 >= 0) prow[n1 + c1] = q;
-        }
-      }
-    }
-  } else {
-    npos.resize((size_t)S.N);
-    prow.resize((size_t)S.fnode_ptr[S.nfronts]);
-  }
   const double tt1 = now_ms();
   std::vector<UploadItem> items;
   size_t upload_span = 0;
@@ -363,8 +341,8 @@ int create_impl(plfem_ctx* c, const plfem_symbolic* sym, int device, void* strea
   TRY(upload(c, items, &c->d_epos, S.epos));
   TRY(upload(c, items, &c->d_leaf_elem_ptr, S.leaf_elem_ptr));
   TRY(upload(c, items, &c->d_leaf_elems, S.leaf_elems));
-  TRY(upload(c, items, &c->d_npos, npos));
-  TRY(upload(c, items, &c->d_prow, prow));
+  TRY(upload(c, items, &c->d_npos, S.npos));
+  TRY(upload(c, items, &c->d_prow, S.prow));
   upload_span = c->slab_off;
   TRY(dalloc(c, &c->d_colind, (size_t)c->nnz));      // filled on the device by launch_pattern_fill below
   TRY(dalloc(c, &c->d_slot_row, (size_t)c->nnz));
@@ -1101,6 +1079,19 @@ extern "C" int plfem_debug_factor_until(plfem_ctx* c, double sigma, int32_t leve
   plfem::launch_factor(c, sigma, level, step, stage);
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   return check_launch(c, "debug factor");
+}
+
+// timing aid: reps block solves (BLOCK_P right-hand sides out of the Lanczos work buffers) with an optional front
+// filter (0 all fronts, 1 skip fronts with more than 128 owned DOFs, 2 only those: wrong results, kernel times only)
+extern "C" int plfem_debug_solve_block(plfem_ctx* c, int32_t reps, int32_t filter) {
+  if (!c || reps < 1) return PLFEM_EINVAL;
+  if (!c->factored) { c->err = "debug solve before factor"; return PLFEM_ESTATE; }
+  HIP_TRY(c, hipMemsetAsync(c->d_bw, 0, sizeof(double) * c->n2 * plfem::BLOCK_P, c->stream));
+  c->debug_sweep_filter = filter;
+  for (int r = 0; r < reps; ++r) plfem::launch_solve_block(c, c->d_bw, c->d_w, c->n2, false);
+  c->debug_sweep_filter = 0;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return check_launch(c, "debug solve block");
 }
 
 extern "C" int plfem_debug_copy(plfem_ctx* c, const char* name, int64_t offset, int64_t count, double* out_host) {

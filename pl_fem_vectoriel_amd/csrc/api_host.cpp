@@ -117,6 +117,8 @@ bool lookup(const Symbolic& S, const char* name, ArrayRef& r) {
   else if (n == "cinv0") r = aref(S.cinv0);
   else if (n == "cinv1") r = aref(S.cinv1);
   else if (n == "foff") r = aref(S.foff);
+  else if (n == "prow") r = aref(S.prow);
+  else if (n == "npos") r = aref(S.npos);
   else return false;
   return true;
 }

@@ -117,6 +117,7 @@ struct plfem_ctx {
   // options (plfem_set_option)
   int refine_steps = 0;           // iterative-refinement passes inside every OP application of the Lanczos drivers
   double debug_perturb = 0.0;     // test hook: relative perturbation of the root front's D after every factorisation
+  int debug_sweep_filter = 0;     // plfem_debug_solve_block: timing experiments (results are wrong when set)
   int max_block_p = plfem::BLOCK_P;   // right-hand sides per sweep the LDS budget allows (BLOCK_P or 1)
   int lds_limit = 0;              // bytes of LDS one workgroup may use on this device
   double sigma = 0.0, k0 = 0.0;

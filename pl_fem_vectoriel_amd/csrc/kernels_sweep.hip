@@ -39,6 +39,7 @@ namespace {
 struct SweepArgs {
   const int2* blk;
   int leaf_level;
+  int dbg;                         // timing experiments only (plfem_debug_solve_block): 1 skip fronts with s2 > 128, 2 only those
   int ldv;                         // row forms: leading dimension of the staged vector in LDS (component-major [u][i])
   int sh;                          // unknowns per node - 1: node of a local DOF = i >> sh, component = i & sh
   const int32_t *fs2, *fm;
@@ -156,6 +157,7 @@ __global__ __launch_bounds__(NW * 64) void k_fwd(SweepArgs A) {
   const int2 job = A.blk[blockIdx.x];
   const int f = job.x;
   const int m = A.fm[f], s2 = A.fs2[f];
+  if (A.dbg && ((A.dbg == 1) == (s2 > 128))) return;
   const int r0 = job.y * 64;
   const int64_t np = A.fnode_ptr[f];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -232,6 +234,7 @@ __global__ __launch_bounds__(NW * 64) void k_fwd_rows(SweepArgs A) {
   const int2 job = A.blk[blockIdx.x];
   const int f = job.x;
   const int m = A.fm[f], s2 = A.fs2[f];
+  if (A.dbg && ((A.dbg == 1) == (s2 > 128))) return;
   const int j0 = job.y * RB;
   const int64_t np = A.fnode_ptr[f];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -369,6 +372,7 @@ __global__ __launch_bounds__(NW * 64) void k_bwd(SweepArgs A) {
   const int2 job = A.blk[blockIdx.x];
   const int f = job.x;
   const int m = A.fm[f], s2 = A.fs2[f];
+  if (A.dbg && ((A.dbg == 1) == (s2 > 128))) return;
   const int r0 = job.y * 64;
   const int64_t np = A.fnode_ptr[f];
   const int64_t npp = f > 0 ? A.fnode_ptr[(f - 1) >> 1] : 0;
@@ -436,6 +440,7 @@ __global__ __launch_bounds__(NW * 64) void k_bwd_rows(SweepArgs A) {
   const int2 job = A.blk[blockIdx.x];
   const int f = job.x;
   const int m = A.fm[f], s2 = A.fs2[f];
+  if (A.dbg && ((A.dbg == 1) == (s2 > 128))) return;
   const int j0 = job.y * RB;
   const int64_t np = A.fnode_ptr[f];
   const int64_t npp = f > 0 ? A.fnode_ptr[(f - 1) >> 1] : 0;
@@ -537,6 +542,7 @@ void sweeps(plfem_ctx* c) {
   hipStream_t st = c->stream;
   SweepArgs A;
   A.sh = c->sh;
+  A.dbg = c->debug_sweep_filter;
   A.fs2 = c->d_fs2; A.fm = c->d_fm; A.foff = c->d_foff; A.fnode_ptr = c->d_fnode_ptr;
   A.cinv0 = c->d_cinv0; A.cinv1 = c->d_cinv1; A.prow = c->d_prow;
   A.front = c->d_front; A.delta = c->d_delta;

@@ -783,6 +783,8 @@ std::string build_fronts(Symbolic& S, int nthreads) {
   S.fnodes.resize(tot);                  // uninitialised: every entry (padding included) is written below
   S.cinv0.resize(tot);
   S.cinv1.resize(tot);
+  S.prow.resize(tot);
+  S.npos.assign((size_t)N, -1);          // Dirichlet nodes stay -1
   auto put = [](int32_t* dst, const int32_t* src, int count, int padded) {
     if (src) std::copy(src, src + count, dst);
     else std::fill(dst, dst + count, -1);
@@ -806,6 +808,23 @@ std::string build_fronts(Symbolic& S, int nthreads) {
       put(c0 + fs, leaf ? nullptr : b.c0.data() + o, nb, fb);
       put(c1, leaf ? nullptr : b.o1.data() + o, no, fs);
       put(c1 + fs, leaf ? nullptr : b.c1.data() + o, nb, fb);
+      // front order of the solve vectors: offset of the owned node's component 0, and (the inverse of the child maps)
+      // the local node index of every boundary node of a child in THIS front -- each child slot has one writer
+      const int64_t np = S.fnode_ptr[f];
+      for (int q = 0; q < no; ++q) S.npos[fn[q]] = (int32_t)(2 * np + S.dpn * q);
+      int32_t* pr = S.prow.data() + np;
+      std::fill(pr, pr + fs, -1);                            // owned nodes have no slot in the parent
+      if (f == 0) std::fill(pr + fs, pr + fs + fb, -1);      // (the root has no parent; its boundary list is empty)
+      if (!leaf) {
+        int32_t* p0 = S.prow.data() + S.fnode_ptr[2 * f + 1] + S.fs[2 * f + 1];
+        int32_t* p1 = S.prow.data() + S.fnode_ptr[2 * f + 2] + S.fs[2 * f + 2];
+        std::fill(p0, p0 + S.fb[2 * f + 1], -1);
+        std::fill(p1, p1 + S.fb[2 * f + 2], -1);
+        for (int q = 0; q < fs + fb; ++q) {
+          if (c0[q] >= 0) p0[c0[q]] = q;
+          if (c1[q] >= 0) p1[c1[q]] = q;
+        }
+      }
     }
   });
   tr.lap("fronts: flatten");

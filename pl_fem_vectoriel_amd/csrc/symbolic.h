@@ -64,6 +64,8 @@ struct Symbolic {
   std::vector<int64_t> fnode_ptr;      // [nfronts+1] offsets into fnodes/cinv*
   rawvec_i32 fnodes;                   // node (scalar DOF) id per local node, -1 = padding
   rawvec_i32 cinv0, cinv1;             // per local node of an internal front: index in child's boundary list or -1
+  rawvec_i32 prow;                     // per local node: local node index in the PARENT front (boundary nodes), -1 = none
+  std::vector<int32_t> npos;           // [N] node -> front-order offset of its component 0: 2 fnode_ptr[owner] + dpn q, -1 = Dirichlet
   std::vector<int64_t> foff;           // [nfronts+1] offsets (in doubles) of the dense front matrices, m = dpn (fs+fb)
   std::vector<int32_t> owner;          // [N] front that eliminates the node, -1 for Dirichlet nodes
   // statistics
