@@ -241,13 +241,23 @@ int create_impl(plfem_ctx* c, const plfem_symbolic* sym, int device, void* strea
       li.fwd_rows = plfem::fwd_block_rows(li.count);
       li.bwd_rows = plfem::bwd_block_rows(li.count, lev == S.L);
       li.fwd_off = (int64_t)blk.size();
-      for (int q = 0; q < li.count; ++q)
-        for (int t = 0; t * li.fwd_rows < fm[o[q]]; ++t) blk.push_back(make_int2(o[q], t));
+      for (int q = 0; q < li.count; ++q) {
+        const int f = o[q];
+        if (li.fwd_rows == 64 && fs2[f] > plfem::MIX_BIG_S2) {      // long front of a tile-form level: row-form workgroups
+          li.fwd_mixed = true;
+          for (int t = 0; t * 16 < fm[f]; ++t) blk.push_back(make_int2(f, t | plfem::SWEEP_ROW_JOB_FLAG));
+        }
+        else
+          for (int t = 0; t * li.fwd_rows < fm[f]; ++t) blk.push_back(make_int2(f, t));
+      }
       li.fwd_n = (int)(blk.size() - li.fwd_off);
       li.bwd_off = (int64_t)blk.size();
       // (a non-leaf front without owned DOFs still gets one workgroup: it republishes its boundary values for its children)
-      for (int q = 0; q < li.count; ++q)
-        for (int t = 0; t * li.bwd_rows < std::max(fs2[o[q]], lev < S.L ? 1 : 0); ++t) blk.push_back(make_int2(o[q], t));
+      for (int q = 0; q < li.count; ++q) {
+        const int f = o[q];
+        const int rows = std::max(fs2[f], lev < S.L ? 1 : 0);
+        for (int t = 0; t * li.bwd_rows < rows; ++t) blk.push_back(make_int2(f, t));
+      }
       li.bwd_n = (int)(blk.size() - li.bwd_off);
     }
   }

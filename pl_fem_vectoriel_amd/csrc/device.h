@@ -15,6 +15,10 @@ constexpr int NB = 32;          // pivot-block width of the block LDL^T
 constexpr int PANEL_CHUNK = 1024; // rows per partial sum of the tall-skinny panel products
 // sweep kernel forms by level (launch_solve_p and the launch lists must agree)
 constexpr int ROW_FORM_MAX_FRONTS = 32;   // levels with at most this many fronts use the row-form kernels in both sweeps
+// 8 / 16: pure row form with that many rows per workgroup; 64: tile form (backward: leaf level only; forward: mixed
+// launch -- tiles of 64 rows, row-form workgroups of 16 rows for the fronts with more than MIX_BIG_S2 owned DOFs)
+constexpr int MIX_BIG_S2 = 192;
+constexpr int SWEEP_ROW_JOB_FLAG = 1 << 30;
 inline int fwd_block_rows(int count) { return count <= 8 ? 8 : count <= ROW_FORM_MAX_FRONTS ? 16 : 64; }
 inline int bwd_block_rows(int count, bool leaf) { return leaf ? 64 : count <= ROW_FORM_MAX_FRONTS ? 8 : 16; }
 constexpr int BLOCK_P = 4;      // right-hand sides per block solve / block Lanczos step
@@ -34,6 +38,7 @@ struct LevelInfo {
   int64_t gather_off = 0, formz_off = 0;
   int gather_n = 0, formz_n = 0, step0 = 0;
   int fwd_rows = 0, bwd_rows = 0;      // rows per workgroup of the forward / backward kernel of this level
+  bool fwd_mixed = false;              // tile-form level with at least one long front (row-form workgroups in the same launch)
   int64_t fwd_off = 0, bwd_off = 0;    // first entry in d_blk
   int fwd_n = 0, bwd_n = 0;            // entries = workgroups
   double sweep_bytes = 0;   // algorithmic bytes one forward (or backward) sweep launch of this level moves (1 rhs)

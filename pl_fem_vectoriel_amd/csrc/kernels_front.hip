@@ -264,22 +264,27 @@ __global__ __launch_bounds__(256) void k_ldl_pivot_panel(int n_tb, const int32_t
     }
     return;
   }
+  // panel workgroup bx of this front takes the 64-row chunks bx, bx + n_pan, ... below the pivot block (n_pan workgroups
+  // per front: all chunks in parallel at the top of the tree, where the step is latency; at most two workgroups per
+  // front where a level has hundreds of fronts and every extra workgroup is one more redundant pivot factorisation)
   const int bx = blockIdx.y - n_tb;
-  const int i0 = k0 + nbk + bx * 64;
-  if (bx > 0 && i0 >= m) return;
+  const int n_pan = gridDim.y - n_tb;
+  const int t0 = k0 + nbk;
+  if (bx > 0 && t0 + bx * 64 >= m) return;
   __shared__ double srow[NB];
   __shared__ double tile[NB][NB + 1];
   __shared__ double sD[NB];
-  // this wave's 16 panel rows: B operand R^T (k = pivot column j, col = row i), requested before the pivot work
+  // this wave's 16 panel rows of the first chunk: B operand R^T (k = pivot column j, col = row i), requested before the
+  // pivot work
   const int lr = lane & 15, lk = lane >> 4;
-  const int ibase = i0 + 16 * wave;
-  const bool rows = ibase < m;                           // m is a multiple of 16: the wave's 16 rows are all valid
-  const int i = ibase + lr;
   double b[NB / 4];
+  {
+    const int ibase = t0 + bx * 64 + 16 * wave;
 #pragma unroll
-  for (int kk = 0; kk < NB / 4; ++kk) {
-    const int jx = 4 * kk + lk;
-    b[kk] = (rows && jx < nbk) ? F[(int64_t)(k0 + jx) * m + i] : 0.0;
+    for (int kk = 0; kk < NB / 4; ++kk) {
+      const int jx = 4 * kk + lk;
+      b[kk] = (ibase < m && jx < nbk) ? F[(int64_t)(k0 + jx) * m + ibase + lr] : 0.0;
+    }
   }
   if (wave == 0) ldl_pivot_wave(F, m, k0, nbk, lane, tile, sD, srow, bx == 0 ? counters : nullptr);
   __syncthreads();
@@ -288,30 +293,53 @@ __global__ __launch_bounds__(256) void k_ldl_pivot_panel(int n_tb, const int32_t
     for (int e = threadIdx.x; e < NB * NB; e += 256) D[e] = tile[e & (NB - 1)][e >> 5];
     if (threadIdx.x < nbk) delta[2 * fnode_ptr[f] + k0 + threadIdx.x] = sD[threadIdx.x];
   }
-  if (!rows) return;
   // Y^T[c][i] = sum_j X[c][j] R[i][j] on v_mfma_f64_16x16x4_f64: A <- X (row c, k = j), B <- R^T; the accumulator
   // register r of lane l is Y[i = ibase + (l & 15)][c = 16 tc + (l >> 4) + 4 r]: 128-B runs of W, Y and of the panel
   // columns of F.
   double* W = wbuf + 2 * fnode_ptr[f] * NB;
   double* Y = rbuf + 2 * fnode_ptr[f] * NB;
-  v4d y0 = (v4d){0.0, 0.0, 0.0, 0.0}, y1 = (v4d){0.0, 0.0, 0.0, 0.0};
+  double xa0[NB / 4], xa1[NB / 4], rd[2][4];
 #pragma unroll
   for (int kk = 0; kk < NB / 4; ++kk) {
-    const int jx = 4 * kk + lk;
-    y0 = __builtin_amdgcn_mfma_f64_16x16x4f64(tile[lr][jx], b[kk], y0, 0, 0, 0);
-    y1 = __builtin_amdgcn_mfma_f64_16x16x4f64(tile[16 + lr][jx], b[kk], y1, 0, 0, 0);
+    xa0[kk] = tile[lr][4 * kk + lk];
+    xa1[kk] = tile[16 + lr][4 * kk + lk];
   }
 #pragma unroll
   for (int tc = 0; tc < 2; ++tc)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int c = 16 * tc + lk + 4 * r;
-      const double y = tc == 0 ? y0[r] : y1[r];
-      const double w = (c < nbk) ? y * fast_rcp(sD[c]) : 0.0;
-      W[(int64_t)c * m + i] = w;
-      Y[(int64_t)c * m + i] = y;
-      if (c < nbk) F[(int64_t)(k0 + c) * m + i] = w;
+      rd[tc][r] = (c < nbk) ? fast_rcp(sD[c]) : 0.0;
     }
+  for (int ch = bx; t0 + ch * 64 < m; ch += n_pan) {
+    const int ibase = t0 + ch * 64 + 16 * wave;
+    if (ibase >= m) break;                                 // m is a multiple of 16: the wave's 16 rows are all valid
+    const int i = ibase + lr;
+    if (ch != bx) {
+#pragma unroll
+      for (int kk = 0; kk < NB / 4; ++kk) {
+        const int jx = 4 * kk + lk;
+        b[kk] = (jx < nbk) ? F[(int64_t)(k0 + jx) * m + i] : 0.0;
+      }
+    }
+    v4d y0 = (v4d){0.0, 0.0, 0.0, 0.0}, y1 = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int kk = 0; kk < NB / 4; ++kk) {
+      y0 = __builtin_amdgcn_mfma_f64_16x16x4f64(xa0[kk], b[kk], y0, 0, 0, 0);
+      y1 = __builtin_amdgcn_mfma_f64_16x16x4f64(xa1[kk], b[kk], y1, 0, 0, 0);
+    }
+#pragma unroll
+    for (int tc = 0; tc < 2; ++tc)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int c = 16 * tc + lk + 4 * r;
+        const double y = tc == 0 ? y0[r] : y1[r];
+        const double w = y * rd[tc][r];
+        W[(int64_t)c * m + i] = w;
+        Y[(int64_t)c * m + i] = y;
+        if (c < nbk) F[(int64_t)(k0 + c) * m + i] = w;
+      }
+  }
   // (no mirrored copy L^T in the rows of the pivot block: those entries are overwritten -- by the triangular-inverse
   // update inside F11, by Z^T in F12 -- before anything reads them)
 }
@@ -641,7 +669,11 @@ void launch_factor(plfem_ctx* c, double sigma, int stop_level, int stop_step, in
       double* rb = c->d_rbuf + (kb & 1) * half;
       // launch A: pivot block + panel (+ the copy of the block row of L11 for the triangular-inverse update)
       const int n_tb = (k0 + 63) / 64;
-      const int n_pan = std::max(1, max_trail > 0 ? (max_trail + 63) / 64 : 0);   // workgroup 0 always: it owns the pivot results
+      // panel workgroups per front: all 64-row chunks in parallel where the level is a latency chain (few fronts), at
+      // most two where it is throughput (hundreds of fronts, each workgroup a redundant pivot factorisation);
+      // workgroup 0 always exists: it owns the pivot results
+      int n_pan = std::max(1, max_trail > 0 ? (max_trail + 63) / 64 : 0);
+      if (li.count > 64) n_pan = std::min(n_pan, 2);
       hipLaunchKernelGGL(k_ldl_pivot_panel, dim3(nact, n_tb + n_pan), dim3(256), 0, st, n_tb, ford, kb, c->d_fs2, c->d_fm,
                          c->d_foff, c->d_fnode_ptr, c->d_front, c->d_dinv, c->d_delta, c->d_tbuf, wb, rb, c->d_counters);
       if (stop_here && stop_stage >= 1 && stop_stage <= 2) return;

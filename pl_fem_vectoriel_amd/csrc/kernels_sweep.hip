@@ -149,16 +149,13 @@ struct FwdOut {
 };
 
 // ---- forward, tile form ------------------------------------------------------------------------------------------
+constexpr int SWEEP_ROW_JOB = 1 << 30;   // job.y flag of the mixed kernels: row-form workgroup (16 rows) instead of a tile (64 rows)
 constexpr int TB = PLFEM_SWEEP_TB;      // matrix loads in flight per lane and trip (a long front is a chain of such trips)
 template <int P, int NW>
-__global__ __launch_bounds__(NW * 64) void k_fwd(SweepArgs A) {
-  extern __shared__ double sv[];
-  __shared__ double red[NW * P * 64];
-  const int2 job = A.blk[blockIdx.x];
-  const int f = job.x;
+__device__ __forceinline__ void fwd_tile_body(const SweepArgs& A, int f, int rb, double* __restrict__ sv, double* __restrict__ red) {
   const int m = A.fm[f], s2 = A.fs2[f];
   if (A.dbg && ((A.dbg == 1) == (s2 > 128))) return;
-  const int r0 = job.y * 64;
+  const int r0 = rb * 64;
   const int64_t np = A.fnode_ptr[f];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int need = (r0 + 64 <= s2) ? r0 + 64 : s2;
@@ -228,14 +225,11 @@ __global__ __launch_bounds__(NW * 64) void k_fwd(SweepArgs A) {
 
 // ---- forward, row form -------------------------------------------------------------------------------------------
 template <int P, int NW, int R>
-__global__ __launch_bounds__(NW * 64) void k_fwd_rows(SweepArgs A) {
-  extern __shared__ double sv[];
+__device__ __forceinline__ void fwd_rows_body(const SweepArgs& A, int f, int rb, double* __restrict__ sv) {
   constexpr int RB = NW * R, UNR = PLFEM_SWEEP_ROWLOADS / R, V = R * P;
-  const int2 job = A.blk[blockIdx.x];
-  const int f = job.x;
   const int m = A.fm[f], s2 = A.fs2[f];
   if (A.dbg && ((A.dbg == 1) == (s2 > 128))) return;
-  const int j0 = job.y * RB;
+  const int j0 = rb * RB;
   const int64_t np = A.fnode_ptr[f];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int need = min(s2, j0 + RB);                      // rows < s2 only read r[0 .. row]
@@ -366,18 +360,14 @@ __device__ __forceinline__ void stage_bwd_rest(const SweepArgs& A, double* sv, i
 }
 
 template <int P, int NW>
-__global__ __launch_bounds__(NW * 64) void k_bwd(SweepArgs A) {
-  extern __shared__ double sv[];
-  __shared__ double red[NW * P * 64];
-  const int2 job = A.blk[blockIdx.x];
-  const int f = job.x;
+__device__ __forceinline__ void bwd_tile_body(const SweepArgs& A, int f, int rb, double* __restrict__ sv, double* __restrict__ red) {
   const int m = A.fm[f], s2 = A.fs2[f];
   if (A.dbg && ((A.dbg == 1) == (s2 > 128))) return;
-  const int r0 = job.y * 64;
+  const int r0 = rb * 64;
   const int64_t np = A.fnode_ptr[f];
   const int64_t npp = f > 0 ? A.fnode_ptr[(f - 1) >> 1] : 0;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const bool publish = job.y == 0 && !A.leaf_level;
+  const bool publish = rb == 0 && !A.leaf_level;
   BwdStage<P> st;
   st.request_index(A, np, s2, r0 + tid, r0 + tid < m);
   const int r = r0 + lane;
@@ -434,18 +424,15 @@ __global__ __launch_bounds__(NW * 64) void k_bwd(SweepArgs A) {
 // Column j of the lower storage is contiguous in i, so a wave reads 512-byte runs; a wave owns R rows
 // (j0 + wave + NW q) and keeps R x 8/R loads in flight; a block (NW waves) shares one staged vector for NW R rows.
 template <int P, int NW, int R>
-__global__ __launch_bounds__(NW * 64) void k_bwd_rows(SweepArgs A) {
-  extern __shared__ double sv[];
+__device__ __forceinline__ void bwd_rows_body(const SweepArgs& A, int f, int rb, double* __restrict__ sv) {
   constexpr int RB = NW * R, UNR = PLFEM_SWEEP_ROWLOADS / R, V = R * P;
-  const int2 job = A.blk[blockIdx.x];
-  const int f = job.x;
   const int m = A.fm[f], s2 = A.fs2[f];
   if (A.dbg && ((A.dbg == 1) == (s2 > 128))) return;
-  const int j0 = job.y * RB;
+  const int j0 = rb * RB;
   const int64_t np = A.fnode_ptr[f];
   const int64_t npp = f > 0 ? A.fnode_ptr[(f - 1) >> 1] : 0;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const bool publish = job.y == 0 && !A.leaf_level;
+  const bool publish = rb == 0 && !A.leaf_level;
   const int lo = j0 & ~63;
   BwdStage<P> st;
   st.request_index(A, np, s2, lo + tid, lo + tid < m);
@@ -510,6 +497,55 @@ __global__ __launch_bounds__(NW * 64) void k_bwd_rows(SweepArgs A) {
   if (lane < V && oj < s2) A.xl[(2 * np + oj) * P + oidx % P] = acc[0];
 }
 
+// ---- kernels --------------------------------------------------------------------------------------------------------
+// Levels with at most ROW_FORM_MAX_FRONTS fronts (all of them large): pure row form.  The other levels of the FORWARD
+// sweep mix the two forms in ONE launch, per front: a front with more than MIX_BIG_S2 owned DOFs gets row-form
+// workgroups (16 rows, 4 waves of 4 rows: four times the waves of the tile form, which is what a long front needs to
+// keep enough loads in flight -- a level's few long fronts set its time: at C1 the forward level 7 took 25 us, 20 of
+// them for 4 long fronts alone), every other front tile-form workgroups (64 rows, 4 waves splitting the columns).
+// Measured and dropped: 8-wave tiles in the mixed launch (the leaf level twice as slow), the tile form for the short
+// fronts of the backward mid levels (every level slower than the row form).
+template <int P, int R>
+__global__ __launch_bounds__(512) void k_fwd_rows(SweepArgs A) {
+  extern __shared__ double sv[];
+  const int2 job = A.blk[blockIdx.x];
+  fwd_rows_body<P, 8, R>(A, job.x, job.y, sv);
+}
+
+template <int P, int R>
+__global__ __launch_bounds__(512) void k_bwd_rows(SweepArgs A) {
+  extern __shared__ double sv[];
+  const int2 job = A.blk[blockIdx.x];
+  bwd_rows_body<P, 8, R>(A, job.x, job.y, sv);
+}
+
+// forward, tile form only (levels without a long front: the mixed kernel's register budget costs occupancy there)
+template <int P>
+__global__ __launch_bounds__(256) void k_fwd(SweepArgs A) {
+  extern __shared__ double sv[];
+  __shared__ double red[4 * P * 64];
+  const int2 job = A.blk[blockIdx.x];
+  fwd_tile_body<P, 4>(A, job.x, job.y, sv, red);
+}
+
+template <int P>
+__global__ __launch_bounds__(256) void k_fwd_mix(SweepArgs A) {
+  extern __shared__ double sv[];
+  __shared__ double red[4 * P * 64];
+  const int2 job = A.blk[blockIdx.x];
+  if (job.y & SWEEP_ROW_JOB) fwd_rows_body<P, 4, 4>(A, job.x, job.y & ~SWEEP_ROW_JOB, sv);
+  else fwd_tile_body<P, 4>(A, job.x, job.y, sv, red);
+}
+
+// backward, leaf level: tile form (leaf fronts have about as many owned rows as boundary columns)
+template <int P>
+__global__ __launch_bounds__(512) void k_bwd(SweepArgs A) {
+  extern __shared__ double sv[];
+  __shared__ double red[8 * P * 64];
+  const int2 job = A.blk[blockIdx.x];
+  bwd_tile_body<P, 8>(A, job.x, job.y, sv, red);
+}
+
 // ---- global order <-> front order ---------------------------------------------------------------------------------
 // fr[(npos[node] + c) P + u] = rhs[u ldx + c N + node]  (npos = front-order offset of the node's component 0;
 // Dirichlet nodes: npos = -1, nothing to do)
@@ -560,13 +596,14 @@ void sweeps(plfem_ctx* c) {
     const size_t lds = sizeof(double) * P * (li.max_s2 + 1);
     A.ldv = li.max_s2 + 1;
     if (li.fwd_rows == 8)
-      hipLaunchKernelGGL((k_fwd_rows<P, 8, 1>), dim3(li.fwd_n), dim3(512), lds, st, A);
+      hipLaunchKernelGGL((k_fwd_rows<P, 1>), dim3(li.fwd_n), dim3(512), lds, st, A);
     else if (li.fwd_rows == 16)
-      hipLaunchKernelGGL((k_fwd_rows<P, 8, 2>), dim3(li.fwd_n), dim3(512), lds, st, A);
+      hipLaunchKernelGGL((k_fwd_rows<P, 2>), dim3(li.fwd_n), dim3(512), lds, st, A);
     else {
       // optional live timing of this kernel (bench.py roofline): HIP events on the launch stream
       const int pid = prof_open(c, PLFEM_PROF_KFWD, li.sweep_bytes + 8.0 * (P - 1) * li.sweep_vec_doubles);
-      hipLaunchKernelGGL((k_fwd<P, 4>), dim3(li.fwd_n), dim3(256), lds, st, A);
+      if (li.fwd_mixed) hipLaunchKernelGGL((k_fwd_mix<P>), dim3(li.fwd_n), dim3(256), lds, st, A);
+      else hipLaunchKernelGGL((k_fwd<P>), dim3(li.fwd_n), dim3(256), lds, st, A);
       prof_close(c, pid);
     }
   }
@@ -579,12 +616,12 @@ void sweeps(plfem_ctx* c) {
     A.blk = c->d_blk + li.bwd_off;
     const size_t lds = sizeof(double) * P * (li.max_m + 1);
     A.ldv = li.max_m + 1;
-    if (li.bwd_rows == 64)    // leaf fronts (about as many owned rows as boundary columns): tile form
-      hipLaunchKernelGGL((k_bwd<P, 8>), dim3(li.bwd_n), dim3(512), lds, st, A);
-    else if (li.bwd_rows == 8)   // few large fronts: one row per wave, most blocks
-      hipLaunchKernelGGL((k_bwd_rows<P, 8, 1>), dim3(li.bwd_n), dim3(512), lds, st, A);
-    else
-      hipLaunchKernelGGL((k_bwd_rows<P, 8, 2>), dim3(li.bwd_n), dim3(512), lds, st, A);
+    if (li.bwd_rows == 8)          // few large fronts: one row per wave, most blocks
+      hipLaunchKernelGGL((k_bwd_rows<P, 1>), dim3(li.bwd_n), dim3(512), lds, st, A);
+    else if (li.bwd_rows == 16)
+      hipLaunchKernelGGL((k_bwd_rows<P, 2>), dim3(li.bwd_n), dim3(512), lds, st, A);
+    else                           // leaf level: tile form
+      hipLaunchKernelGGL((k_bwd<P>), dim3(li.bwd_n), dim3(512), lds, st, A);
   }
   prof_close(c, pid_bwd);
 }

@@ -31,20 +31,25 @@ for L in range(nlev):
     vec[L] = 8.0 * (m + s).sum()
     cnt[L] = (lev == L).sum()
 
-# workgroups per level of each sweep (the compact launch lists of the context; rules of csrc/device.h)
+# workgroups per level of each sweep (the compact launch lists of the context; rules of csrc/device.h + create_impl:
+# pure row form up to 32 fronts, otherwise a mixed launch -- tiles of 64 rows, row-form workgroups of 16 rows for the
+# fronts with more than 192 owned DOFs in the forward sweep)
 def fwd_rows(count): return 8 if count <= 8 else 16 if count <= 32 else 64
 def bwd_rows(count, leaf): return 64 if leaf else 8 if count <= 32 else 16
 nblk = {}
 for L in range(nlev):
     s_, m_ = fs[lev == L], fs[lev == L] + fb[lev == L]
-    nblk[("fwd", int(np.ceil(m_ / fwd_rows(cnt[L])).sum()))] = L
-    # (a non-leaf front without owned DOFs still gets one backward workgroup: it republishes its boundary values)
-    nblk[("bwd", int(np.ceil(np.maximum(s_, 0 if L == nlev - 1 else 1) / bwd_rows(cnt[L], L == nlev - 1)).sum()))] = L
+    leaf = L == nlev - 1
+    fr, br = fwd_rows(cnt[L]), bwd_rows(cnt[L], leaf)
+    big = (s_ > 192) & (fr == 64)
+    nblk[("fwd", int(np.where(big, np.ceil(m_ / 16), np.ceil(m_ / fr)).sum()))] = L
+    rows_b = np.maximum(s_, 0 if leaf else 1)
+    nblk[("bwd", int(np.ceil(rows_b / br).sum()))] = L
 
 rows = list(csv.DictReader(open(sys.argv[1])))
 agg = {}
 for r in rows:
-    m = re.search(r"(k_(?:fwd|bwd)(?:_dot|_rows|_split|_rt)?)<(\d+)", r["Kernel_Name"])
+    m = re.search(r"(k_(?:fwd|bwd)(?:_mix|_rows)?)<(\d+)", r["Kernel_Name"])
     if not m:
         continue
     name, P = m.group(1), int(m.group(2))
