@@ -374,57 +374,77 @@ void nd_tree(Symbolic& S, int leaf_elems, int nthreads) {
   S.L = L;
   S.nfronts = (1 << (L + 1)) - 1;
   Trace tr;
+  // Two element-record buffers: every bisection SCATTERS its subdomain from one into the other (stable, left part
+  // first), so a level costs no copy back and the children's bounding boxes come out of the same pass.
   // (default-initialised storage: a value-initialising vector would zero 2 x 64 B x ne on one thread first)
-  std::vector<ElemGeo, default_init_allocator<ElemGeo>> G(ne), scratch(nthreads > 1 ? ne : 0);
+  std::vector<ElemGeo, default_init_allocator<ElemGeo>> bufA(ne), bufB(ne);
+  ElemGeo* const buf[2] = {bufA.data(), bufB.data()};
+  struct Box {
+    double x0 = 1e300, x1 = -1e300, y0 = 1e300, y1 = -1e300;      // of the element CENTROIDS of a subdomain
+    void add(const ElemGeo& g) {
+      x0 = std::min(x0, g.c[0]); x1 = std::max(x1, g.c[0]);
+      y0 = std::min(y0, g.c[1]); y1 = std::max(y1, g.c[1]);
+    }
+    void merge(const Box& o) {
+      x0 = std::min(x0, o.x0); x1 = std::max(x1, o.x1);
+      y0 = std::min(y0, o.y0); y1 = std::max(y1, o.y1);
+    }
+  };
   const double* X = S.doflocs.data();
   const double* Y = X + N;
-  parallel_for(ne, nthreads, [&](int64_t b_, int64_t e_, int) {
-    for (int64_t e = b_; e < e_; ++e) {
-      int32_t a = S.tsorted[e], b = S.tsorted[(size_t)ne + e], c = S.tsorted[(size_t)2 * ne + e];
-      ElemGeo& g = G[e];
-      g.c[0] = (X[a] + X[b] + X[c]) / 3.0;
-      g.c[1] = (Y[a] + Y[b] + Y[c]) / 3.0;
-      g.lo[0] = std::min(X[a], std::min(X[b], X[c])); g.hi[0] = std::max(X[a], std::max(X[b], X[c]));
-      g.lo[1] = std::min(Y[a], std::min(Y[b], Y[c])); g.hi[1] = std::max(Y[a], std::max(Y[b], Y[c]));
-      g.id = (int32_t)e;
-    }
-  });
+  Box root_box;
+  {
+    const int nt0 = (nthreads > 1 && g_pool) ? g_pool->nt : 1;
+    std::vector<Box> tb(nt0);
+    parallel_for(ne, nthreads, [&](int64_t b_, int64_t e_, int tid) {
+      Box bx;
+      for (int64_t e = b_; e < e_; ++e) {
+        int32_t a = S.tsorted[e], b = S.tsorted[(size_t)ne + e], c = S.tsorted[(size_t)2 * ne + e];
+        ElemGeo& g = buf[0][e];
+        g.c[0] = (X[a] + X[b] + X[c]) / 3.0;
+        g.c[1] = (Y[a] + Y[b] + Y[c]) / 3.0;
+        g.lo[0] = std::min(X[a], std::min(X[b], X[c])); g.hi[0] = std::max(X[a], std::max(X[b], X[c]));
+        g.lo[1] = std::min(Y[a], std::min(Y[b], Y[c])); g.hi[1] = std::max(Y[a], std::max(Y[b], Y[c]));
+        g.id = (int32_t)e;
+        bx.add(g);
+      }
+      tb[tid].merge(bx);
+    });
+    for (const Box& b : tb) root_box.merge(b);       // (min / max: the same for any thread count)
+  }
   tr.lap("tree: centroids");
   S.leaf_of_elem.resize(ne);
   S.leaf_elem_ptr.assign((size_t)(1 << L) + 1, 0);
   S.leaf_elems.resize(ne);
   constexpr int NBIN = 512;
   struct Hist {
-    double x0 = 1e300, x1 = -1e300, y0 = 1e300, y1 = -1e300;
     int32_t cnt[3][NBIN + 1];      // "axis" 2 = distance from the subdomain's median point (circular cuts)
     int32_t diff[3][NBIN + 2];
+    Box left, right;
   };
-  // Bisection of G[lo, hi).  Large subdomains: the cut is an axis-parallel line chosen among NBIN-1
-  // candidates per axis to minimise the number of straddled elements (~ separator size) subject to
-  // a balance window; small subdomains: plain median split along the longer extent.  par: the passes
-  // over the elements run on the pool (top of the tree, where there are fewer nodes than threads).
-  // The result (which elements go left) does not depend on par or on the order inside [lo, hi).
-  auto bisect = [&](int lo, int hi, int level, bool par) -> int {
+  struct Cut {
+    int mid;
+    Box left, right;
+  };
+  // Bisection of src[lo, hi) into dst[lo, mid) + dst[mid, hi).  Large subdomains: the cut is chosen among NBIN-1
+  // candidates of three families -- lines parallel to either axis, circles around the median point -- to minimise
+  // the number of straddled elements (~ separator size) subject to a balance window; small subdomains: plain median
+  // split along the longer extent.  A candidate is a BIN boundary of the centroid histogram and an element goes left
+  // iff its bin lies below it: the sizes of both parts (per thread chunk, for the stable parallel scatter) then come
+  // out of the histograms, no counting pass.  par: the passes over the elements run on the pool (top of the tree,
+  // where there are fewer nodes than threads).  The result does not depend on par or on the thread count.
+  auto bisect = [&](const ElemGeo* src, ElemGeo* dst, int lo, int hi, int level, bool par, const Box& box) -> Cut {
     const int n = hi - lo;
     const int nt = (par && g_pool) ? g_pool->nt : 1;
     std::vector<Hist> hs(nt);
-    const ElemGeo* Gl = G.data() + lo;
-    auto bbox = [&](int64_t b, int64_t e_, int tid) {
-      Hist& h = hs[tid];
-      for (int64_t q = b; q < e_; ++q) {
-        h.x0 = std::min(h.x0, Gl[q].c[0]); h.x1 = std::max(h.x1, Gl[q].c[0]);
-        h.y0 = std::min(h.y0, Gl[q].c[1]); h.y1 = std::max(h.y1, Gl[q].c[1]);
-      }
-    };
-    if (nt > 1) parallel_for(n, nt, bbox, 1); else bbox(0, n, 0);
-    double x0 = 1e300, x1 = -1e300, y0 = 1e300, y1 = -1e300;
-    for (const Hist& h : hs) {
-      x0 = std::min(x0, h.x0); x1 = std::max(x1, h.x1);
-      y0 = std::min(y0, h.y0); y1 = std::max(y1, h.y1);
-    }
-    int mid = -1;
+    const ElemGeo* Gl = src + lo;
+    ElemGeo* Dl = dst + lo;
+    const double x0 = box.x0, x1 = box.x1, y0 = box.y0, y1 = box.y1;
+    Cut cut;
+    cut.mid = -1;
     const int remaining = L - level;            // every leaf below must stay non-empty
     const int min_side = std::max(1 << (remaining - 1), 1);
+    auto chunk_ran = [&](int t) { return t == 0 || (int64_t)t * ((n + nt - 1) / nt) < n; };   // else its arrays are stale
     if (n >= 192 && n >= 4 * min_side) {
       // both children must stay within a factor RHO of the ideal size ne / 2^(level+1): bounds the
       // leaf-size spread by RHO overall (no compounding), so batched front kernels stay balanced
@@ -433,6 +453,9 @@ void nd_tree(Symbolic& S, int leaf_elems, int nthreads) {
       const double clo = ideal / RHO, chi = ideal * RHO;
       const double a0s[2] = {x0, y0};
       const double scales[2] = {x1 > x0 ? NBIN / (x1 - x0) : 0.0, y1 > y0 ? NBIN / (y1 - y0) : 0.0};
+      auto axis_bin = [&](const ElemGeo& g, int axis) {
+        return std::min(NBIN - 1, std::max(0, (int)((g.c[axis] - a0s[axis]) * scales[axis])));
+      };
       auto hist = [&](int64_t b, int64_t e_, int tid) {
         Hist& h = hs[tid];
         std::memset(h.cnt, 0, sizeof(h.cnt));
@@ -442,8 +465,7 @@ void nd_tree(Symbolic& S, int leaf_elems, int nthreads) {
           for (int axis = 0; axis < 2; ++axis) {
             const double a0 = a0s[axis], scale = scales[axis];
             if (!(scale > 0.0)) continue;
-            int bc = std::min(NBIN - 1, std::max(0, (int)((g.c[axis] - a0) * scale)));
-            h.cnt[axis][bc]++;
+            h.cnt[axis][axis_bin(g, axis)]++;
             // thresholds t_j = a0 + j/scale, j = 1..NBIN-1; the element touches the cut line iff
             // elo <= t_j <= ehi (closed: a line running along mesh edges still costs its nodes)
             // ceil / floor by truncation + correction (the baseline x86-64 target has no rounding instruction,
@@ -458,7 +480,6 @@ void nd_tree(Symbolic& S, int leaf_elems, int nthreads) {
         }
       };
       if (nt > 1) parallel_for(n, nt, hist, 1); else hist(0, n, 0);
-      auto chunk_ran = [&](int t) { return t == 0 || (int64_t)t * ((n + nt - 1) / nt) < n; };   // else its arrays are stale
       // Third family of cuts: circles around the median point O of the element centroids (from the two histograms,
       // integer counts: independent of the thread count).  The lantern meshes are polar inside every core -- a
       // straight cut through a core crosses every ring twice, a circle between two rings crosses one ring's worth
@@ -478,16 +499,16 @@ void nd_tree(Symbolic& S, int leaf_elems, int nthreads) {
         const double rmax = std::sqrt(ex * ex + ey * ey);
         rscale = rmax > 0.0 ? NBIN / rmax : 0.0;
       }
+      auto radial_bin = [&](const ElemGeo& g) {
+        const double cx = g.c[0] - O[0], cy = g.c[1] - O[1];
+        return std::min(NBIN - 1, std::max(0, (int)(std::sqrt(cx * cx + cy * cy) * rscale)));
+      };
       if (rscale > 0.0) {
         auto rhist = [&](int64_t b, int64_t e_, int tid) {
           Hist& h = hs[tid];
-          std::memset(h.cnt[2], 0, sizeof(h.cnt[2]));
-          std::memset(h.diff[2], 0, sizeof(h.diff[2]));
           for (int64_t q = b; q < e_; ++q) {
             const ElemGeo& g = Gl[q];
-            const double cx = g.c[0] - O[0], cy = g.c[1] - O[1];
-            int bc = std::min(NBIN - 1, std::max(0, (int)(std::sqrt(cx * cx + cy * cy) * rscale)));
-            h.cnt[2][bc]++;
+            h.cnt[2][radial_bin(g)]++;
             // radial extent of the element's bounding box (a superset of the element: cost estimate only)
             const double nx = std::max(std::max(g.lo[0] - O[0], O[0] - g.hi[0]), 0.0);
             const double ny = std::max(std::max(g.lo[1] - O[1], O[1] - g.hi[1]), 0.0);
@@ -503,10 +524,10 @@ void nd_tree(Symbolic& S, int leaf_elems, int nthreads) {
         };
         if (nt > 1) parallel_for(n, nt, rhist, 1); else rhist(0, n, 0);
       }
-      const double a0s3[3] = {x0, y0, 0.0};
       const double scales3[3] = {scales[0], scales[1], rscale};
-      double best_cost = 1e300, best_thr = 0;
-      int best_axis = -1;
+      double best_cost = 1e300;
+      int best_axis = -1, best_j = 0;
+      int64_t best_below = 0;
       for (int axis = 0; axis < 3; ++axis) {
         if (!(scales3[axis] > 0.0)) continue;
         int64_t below = 0, strad = 0;
@@ -520,70 +541,69 @@ void nd_tree(Symbolic& S, int leaf_elems, int nthreads) {
           if (below < clo || below > chi || n - below < clo || n - below > chi) continue;
           if (below < min_side || n - below < min_side) continue;
           double cost = (double)strad * (1.0 + 0.5 * std::fabs(f - 0.5));
-          if (cost < best_cost) { best_cost = cost; best_thr = a0s3[axis] + j / scales3[axis]; best_axis = axis; }
+          if (cost < best_cost) { best_cost = cost; best_axis = axis; best_j = j; best_below = below; }
         }
       }
       if (best_axis >= 0) {
         const int ax = best_axis;
-        const double thr2 = best_thr * best_thr;
-        auto left = [&](const ElemGeo& g) {
-          if (ax < 2) return g.c[ax] < best_thr;
-          const double cx = g.c[0] - O[0], cy = g.c[1] - O[1];
-          return cx * cx + cy * cy < thr2;
-        };
-        if (nt > 1) {
-          // stable two-pass partition through scratch
-          std::vector<int64_t> nl(nt + 1, 0);
-          parallel_for(n, nt, [&](int64_t b, int64_t e_, int tid) {
-            int64_t k = 0;
-            for (int64_t q = b; q < e_; ++q) k += left(Gl[q]);
-            nl[tid + 1] = k;
-          }, 1);
-          for (int t = 0; t < nt; ++t) nl[t + 1] += nl[t];
-          const int64_t nleft = nl[nt];
-          ElemGeo* Sc = scratch.data() + lo;
-          parallel_for(n, nt, [&](int64_t b, int64_t e_, int tid) {
-            int64_t wl = nl[tid], wr = nleft + (b - nl[tid]);
-            for (int64_t q = b; q < e_; ++q) {
-              if (left(Gl[q])) Sc[wl++] = Gl[q]; else Sc[wr++] = Gl[q];
-            }
-          }, 1);
-          parallel_for(n, nt, [&](int64_t b, int64_t e_, int) {
-            std::memcpy((void*)(G.data() + lo + b), (const void*)(Sc + b), sizeof(ElemGeo) * (size_t)(e_ - b));
-          }, 1);
-          mid = lo + (int)nleft;
-        } else {
-          auto it = std::partition(G.begin() + lo, G.begin() + hi, left);
-          mid = (int)(it - G.begin());
+        auto left = [&](const ElemGeo& g) { return (ax < 2 ? axis_bin(g, ax) : radial_bin(g)) < best_j; };
+        // stable scatter: chunk t writes its left elements behind those of the chunks before it, its right elements
+        // likewise behind the left part; the offsets are prefix sums of the chunks' histograms
+        std::vector<int64_t> nl(nt + 1, 0);
+        for (int t = 0; t < nt; ++t) {
+          int64_t k = 0;
+          if (chunk_ran(t))
+            for (int j = 0; j < best_j; ++j) k += hs[t].cnt[ax][j];
+          nl[t + 1] = nl[t] + k;
         }
-        if (mid - lo < min_side || hi - mid < min_side) mid = -1;
+        const int64_t nleft = nl[nt];
+        auto scatter = [&](int64_t b, int64_t e_, int tid) {
+          int64_t wl = nl[tid], wr = nleft + (b - nl[tid]);
+          Box bl, br;
+          for (int64_t q = b; q < e_; ++q) {
+            const ElemGeo& g = Gl[q];
+            if (left(g)) { Dl[wl++] = g; bl.add(g); } else { Dl[wr++] = g; br.add(g); }
+          }
+          hs[tid].left = bl;
+          hs[tid].right = br;
+        };
+        if (nt > 1) parallel_for(n, nt, scatter, 1); else scatter(0, n, 0);
+        for (int t = 0; t < nt; ++t)
+          if (chunk_ran(t)) { cut.left.merge(hs[t].left); cut.right.merge(hs[t].right); }
+        cut.mid = lo + (int)nleft;
+        (void)best_below;
       }
     }
-    if (mid < 0) {
+    if (cut.mid < 0) {
+      // median split along the longer extent (small subdomains, or no admissible cut): order a copy in dst
       const int ax = (x1 - x0 >= y1 - y0) ? 0 : 1;
-      mid = lo + n / 2;
-      std::nth_element(G.begin() + lo, G.begin() + mid, G.begin() + hi, [&](const ElemGeo& a, const ElemGeo& b) {
+      std::memcpy((void*)Dl, (const void*)Gl, sizeof(ElemGeo) * (size_t)n);
+      cut.mid = lo + n / 2;
+      std::nth_element(Dl, Dl + n / 2, Dl + n, [&](const ElemGeo& a, const ElemGeo& b) {
         return a.c[ax] < b.c[ax] || (a.c[ax] == b.c[ax] && a.id < b.id);
       });
+      for (int q = 0; q < n / 2; ++q) cut.left.add(Dl[q]);
+      for (int q = n / 2; q < n; ++q) cut.right.add(Dl[q]);
     }
-    return mid;
+    return cut;
   };
-  std::function<void(int, int, int, int)> subtree = [&](int lo, int hi, int level, int idx) {
+  // src = index of the buffer that holds [lo, hi)
+  std::function<void(int, int, int, int, int, const Box&)> subtree = [&](int lo, int hi, int level, int idx, int src, const Box& box) {
     if (level == L) {
       S.leaf_elem_ptr[idx] = lo;
       // element ids ascending inside every leaf (deterministic assembly order)
-      for (int q = lo; q < hi; ++q) S.leaf_elems[q] = G[q].id;
+      for (int q = lo; q < hi; ++q) S.leaf_elems[q] = buf[src][q].id;
       std::sort(S.leaf_elems.begin() + lo, S.leaf_elems.begin() + hi);
       for (int q = lo; q < hi; ++q) S.leaf_of_elem[S.leaf_elems[q]] = idx;
       return;
     }
-    const int mid = bisect(lo, hi, level, false);
-    subtree(lo, mid, level + 1, 2 * idx);
-    subtree(mid, hi, level + 1, 2 * idx + 1);
+    const Cut c = bisect(buf[src], buf[src ^ 1], lo, hi, level, false, box);
+    subtree(lo, c.mid, level + 1, 2 * idx, src ^ 1, c.left);
+    subtree(c.mid, hi, level + 1, 2 * idx + 1, src ^ 1, c.right);
   };
   // top of the tree breadth-first with pool-parallel passes, then one task per subtree
-  struct Node { int lo, hi, idx; };
-  std::vector<Node> cur{{0, ne, 0}};
+  struct Node { int lo, hi, idx; Box box; };
+  std::vector<Node> cur{{0, ne, 0, root_box}};
   int level = 0;
   if (nthreads > 1 && g_pool) {
     int top = 0;
@@ -592,15 +612,16 @@ void nd_tree(Symbolic& S, int leaf_elems, int nthreads) {
       std::vector<Node> next;
       next.reserve(2 * cur.size());
       for (const Node& nd : cur) {
-        const int mid = bisect(nd.lo, nd.hi, level, nd.hi - nd.lo >= 4096);
-        next.push_back({nd.lo, mid, 2 * nd.idx});
-        next.push_back({mid, nd.hi, 2 * nd.idx + 1});
+        const Cut c = bisect(buf[level & 1], buf[(level & 1) ^ 1], nd.lo, nd.hi, level, nd.hi - nd.lo >= 4096, nd.box);
+        next.push_back({nd.lo, c.mid, 2 * nd.idx, c.left});
+        next.push_back({c.mid, nd.hi, 2 * nd.idx + 1, c.right});
       }
       cur.swap(next);
     }
   }
   tr.lap("tree: top levels");
-  parallel_tasks((int)cur.size(), nthreads, [&](int q) { subtree(cur[q].lo, cur[q].hi, level, cur[q].idx); });
+  const int src0 = level & 1;
+  parallel_tasks((int)cur.size(), nthreads, [&](int q) { subtree(cur[q].lo, cur[q].hi, level, cur[q].idx, src0, cur[q].box); });
   tr.lap("tree: subtrees");
   S.leaf_elem_ptr[(size_t)1 << L] = ne;
 }
