@@ -868,6 +868,7 @@ static int lanczos_block(plfem_ctx* c, int k, int ncv, double tol, int maxiter, 
     HIP_TRY(c, hipMemcpyAsync(c->d_S, hH, sizeof(double) * mm * pk, hipMemcpyHostToDevice, st));
     plfem::launch_rotate(c, c->d_V, mm, c->d_S, mm, pk, c->d_V2);
     plfem::launch_rotate(c, c->d_BV, mm, c->d_S, mm, pk, c->d_BV2);
+    TRY(check_launch(c, "restart rotation"));
     HIP_TRY(c, hipMemcpyAsync(c->d_V2 + (size_t)pk * n, c->d_V + (size_t)mm * n, sizeof(double) * n * P, hipMemcpyDeviceToDevice, st));
     HIP_TRY(c, hipMemcpyAsync(c->d_BV2 + (size_t)pk * n, c->d_BV + (size_t)mm * n, sizeof(double) * n * P, hipMemcpyDeviceToDevice, st));
     HIP_TRY(c, hipStreamSynchronize(st));
@@ -1014,6 +1015,7 @@ extern "C" int plfem_lanczos_shift_invert(plfem_ctx* c, int32_t k, int32_t ncv, 
     HIP_TRY(c, hipMemcpyAsync(c->d_S, hH, sizeof(double) * m * p, hipMemcpyHostToDevice, st));
     plfem::launch_rotate(c, c->d_V, m, c->d_S, m, p, c->d_V2);
     plfem::launch_rotate(c, c->d_BV, m, c->d_S, m, p, c->d_BV2);
+    TRY(check_launch(c, "restart rotation"));
     HIP_TRY(c, hipMemcpyAsync(c->d_V2 + (size_t)p * n, c->d_V + (size_t)m * n, sizeof(double) * n, hipMemcpyDeviceToDevice, st));
     HIP_TRY(c, hipMemcpyAsync(c->d_BV2 + (size_t)p * n, c->d_BV + (size_t)m * n, sizeof(double) * n, hipMemcpyDeviceToDevice, st));
     HIP_TRY(c, hipStreamSynchronize(st));   // hH is reused below

@@ -346,19 +346,22 @@ __global__ __launch_bounds__(256) void k_ldl_pivot_panel(int n_tb, const int32_t
 
 // Triangular-inverse update: with X<k the inverse of the leading k0 x k0 block of L11,
 //   X[k, <k] = -X[k,k] * ( L[k, <k] * X<k ).
-// One wave per 16 columns c, both products on v_mfma_f64_16x16x4_f64:
+// One workgroup per 16 columns c, both products on v_mfma_f64_16x16x4_f64:
 //   T (32 x 16) = L[k, j>=c0] (A: tbuf, contiguous in q) * X<k[j, c] (B: upper mirror, contiguous in c);
 //   the accumulator register r of lane (lr, lk) holds T[lk + 4 r][lr], which is exactly the B operand
 //   of k-step r of the second product  Xnew = -X[k,k] * T  -- no cross-lane movement.
+// The 4 waves split the j range (late steps of a long front: k0 / 32 dependent memory round trips for one wave) and
+// their partial T meet in LDS in a fixed order; wave 0 finishes.
 __device__ __forceinline__ void ldl_invrow_block(int f, int bx, int kb, const int32_t* __restrict__ fs2,
                                                  const int32_t* __restrict__ fm, const int64_t* __restrict__ foff,
                                                  const int64_t* __restrict__ fnode_ptr, double* __restrict__ front,
-                                                 const double* __restrict__ dinv, const double* __restrict__ tbuf) {
+                                                 const double* __restrict__ dinv, const double* __restrict__ tbuf,
+                                                 double* __restrict__ part /* LDS [3][8][64] */) {
   const int s2 = fs2[f];
   const int k0 = kb * NB;
   if (k0 >= s2 || k0 == 0) return;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int c0 = (bx * 4 + wave) * 16;
+  const int c0 = bx * 16;
   if (c0 >= k0) return;
   const int nbk = min(NB, s2 - k0);
   const int m = fm[f];
@@ -387,9 +390,27 @@ __device__ __forceinline__ void ldl_invrow_block(int f, int bx, int kb, const in
       t1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[t], b[t], t1, 0, 0, 0);
     }
   };
-  int j0 = c0;
-  for (; j0 + 16 < k0; j0 += 32) groups(j0, std::integral_constant<int, 2>());
-  if (j0 < k0) groups(j0, std::integral_constant<int, 1>());
+  const int ngroups = (k0 - c0) / 16;                       // groups of 16 columns j; wave w takes [w G / 4, (w + 1) G / 4)
+  int j0 = c0 + 16 * (wave * ngroups / 4);
+  const int j_end = c0 + 16 * ((wave + 1) * ngroups / 4);
+  for (; j0 + 16 < j_end; j0 += 32) groups(j0, std::integral_constant<int, 2>());
+  if (j0 < j_end) groups(j0, std::integral_constant<int, 1>());
+  if (wave > 0) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      part[((wave - 1) * 8 + r) * 64 + lane] = t0[r];
+      part[((wave - 1) * 8 + 4 + r) * 64 + lane] = t1[r];
+    }
+  }
+  __syncthreads();
+  if (wave > 0) return;
+#pragma unroll
+  for (int w = 0; w < 3; ++w)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      t0[r] += part[(w * 8 + r) * 64 + lane];
+      t1[r] += part[(w * 8 + 4 + r) * 64 + lane];
+    }
   v4d x0 = (v4d){0.0, 0.0, 0.0, 0.0}, x1 = (v4d){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
   for (int kk = 0; kk < 8; ++kk) {
@@ -524,7 +545,8 @@ __global__ __launch_bounds__(256) void k_ldl_update(int un, int n_inv, const int
   const int f = forder[e / (n_inv + 1)];
   const int sub = e % (n_inv + 1);
   if (sub < n_inv) {
-    ldl_invrow_block(f, sub, kb, fs2, fm, foff, fnode_ptr, front, dinv, tbuf);
+    __shared__ double part[3 * 8 * 64];
+    ldl_invrow_block(f, sub, kb, fs2, fm, foff, fnode_ptr, front, dinv, tbuf, part);
     return;
   }
   const int s2 = fs2[f];
@@ -679,7 +701,7 @@ void launch_factor(plfem_ctx* c, double sigma, int stop_level, int stop_step, in
       if (stop_here && stop_stage >= 1 && stop_stage <= 2) return;
       // launch B: trailing update + triangular-inverse update + write-back of the pivot block
       const int un = c->upd_n[li.step0 + kb];                  // 64 x 64 blocks of this step's trailing updates
-      const int n_inv = kb > 0 ? (k0 + 63) / 64 : 0;
+      const int n_inv = kb > 0 ? (k0 + 15) / 16 : 0;        // one workgroup per 16 columns of the block row
       const int2* ut = c->d_tiles + c->upd_off[li.step0 + kb];
       const unsigned gridB = (unsigned)(un + nact * (n_inv + 1));
       if ((kb & 1) == 0)
