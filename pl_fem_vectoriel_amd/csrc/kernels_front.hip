@@ -181,41 +181,38 @@ __device__ __forceinline__ void ldl_pivot_wave(const double* __restrict__ F, int
   for (int off = 32; off >= 1; off >>= 1) amax = fmax(amax, __shfl_xor(amax, off));
   const double thr = fmax(1e-13 * amax, 1e-300);
   double dmine = 1.0;
+  int nperturbed = 0;                                          // (counted without a branch inside the 32 dependent steps)
 #pragma unroll
   for (int k = 0; k < NB; ++k) {
     const int kh = k >> 4, kc = k & 15;
     double dk = readlane_f64(v[kc], k + 32 * kh);              // a[k][k]
-    if (!(fabs(dk) >= thr)) {
-      dk = (dk < 0.0) ? -thr : thr;
-      if (lane == 0 && counters) atomicAdd(&counters[0], 1);
-    }
+    const bool vanishing = !(fabs(dk) >= thr);
+    dk = vanishing ? ((dk < 0.0) ? -thr : thr) : dk;
+    nperturbed += vanishing ? 1 : 0;
     if (i == k) dmine = dk;
     double colk = 0.0;
     if (h == kh) {                                            // column k leaves a and becomes a column of x
       colk = v[kc];
       v[kc] = (i == k) ? 1.0 : 0.0;
     }
-    // one LDS row: entries c <= k = row k of x (from lane row k), entries c > k = L[c][k] (from lane row c).
-    // The LDS queue of a wave is in order, so the second write wins where both touch.
+    // one LDS row: entries c <= k = row k of x (from lane row k), entries c > k = a[c][k], the RAW column below the
+    // pivot (from lane row c).  The LDS queue of a wave is in order, so the second write wins where both touch.
+    // Row i then loses l_i x (that row) with ONE multiplier l_i = a[i][k] / d_k for every column: behind the pivot it
+    // is a[i][c] -= l_i a[c][k], in front of it x[i][c] -= l_i x[k][c].  Storing the raw column keeps the reciprocal
+    // of the pivot (v_rcp_f64 + two Newton steps instead of the ~25-instruction IEEE division) out of the LDS round
+    // trip: it is computed while the row travels.
     if (i == k) {
 #pragma unroll
       for (int cc = 0; cc < 16; ++cc) srow[16 * h + cc] = v[cc];
     }
-    // (fast_rcp: the IEEE division sequence is 25 of the ~170 instructions of a pivot step, and this single wave is
-    // bound by instruction issue)
+    if (h == kh && i > k) srow[i] = colk;
     const double rdk = fast_rcp(dk);
-    if (h == kh && i > k) srow[i] = colk * rdk;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const double li = (i > k) ? srow[i] : 0.0;
-    const double t = li * dk;
-    // multiplier of column c = 16 h + cc: t where c > k, li where c <= k.  kc is a compile-time constant of the
-    // unrolled step, so per lane there are only two cases (cc > kc, cc <= kc): two selects instead of sixteen
-    const double m_hi = (h >= kh) ? t : li;
-    const double m_lo = (h > kh) ? t : li;
+    const double li = (i > k) ? srow[i] * rdk : 0.0;
 #pragma unroll
-    for (int cc = 0; cc < 16; ++cc) v[cc] -= ((cc > kc) ? m_hi : m_lo) * srow[16 * h + cc];
+    for (int cc = 0; cc < 16; ++cc) v[cc] -= li * srow[16 * h + cc];
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -227,6 +224,7 @@ __device__ __forceinline__ void ldl_pivot_wave(const double* __restrict__ F, int
     tile[i][c] = (c <= i) ? v[cc] : 0.0;
   }
   if (h == 0) sD[i] = dmine;
+  if (lane == 0 && nperturbed > 0 && counters) atomicAdd(&counters[0], nperturbed);
 }
 
 // Launch A of a block step: pivot block + panel.  Every panel workgroup (64 rows below the pivot block, 4 waves of 16
