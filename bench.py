@@ -187,7 +187,8 @@ def roofline_objects(kprof, stats, info, nv, ne):
                 traffic_src = f"profiles/{tag}_pmc_k_fwd.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of that round, not this run)"
                 break
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic, "traffic_source": traffic_src, "kernel": "k_fwd<4, 4>", "launches": kprof["launches"],
+                "traffic": traffic, "traffic_source": traffic_src, "kernel": "k_fwd<4> / k_fwd_mix<4> (tile-form forward sweep levels)",
+                "launches": kprof["launches"],
                 "avg_launch_us": kprof["total_us"] / kprof["launches"],
                 "algorithmic_bytes_per_launch": kprof["bytes"] / kprof["launches"],
                 "kernels": kernels}
