@@ -222,6 +222,7 @@ int create_impl(plfem_ctx* c, const plfem_symbolic* sym, int device, void* strea
   c->forder_s2.assign(S.nfronts, 0);
   c->forder_maxm.assign(S.nfronts, 0);
   std::vector<int2> blk;
+  const int mix_big_s2 = getenv("PLFEM_MIX_BIG_S2") ? atoi(getenv("PLFEM_MIX_BIG_S2")) : plfem::MIX_BIG_S2;   // (tuning aid)
   {
     std::vector<int32_t> bucket;
     for (int lev = 0; lev <= S.L; ++lev) {
@@ -243,7 +244,7 @@ int create_impl(plfem_ctx* c, const plfem_symbolic* sym, int device, void* strea
       li.fwd_off = (int64_t)blk.size();
       for (int q = 0; q < li.count; ++q) {
         const int f = o[q];
-        if (li.fwd_rows == 64 && fs2[f] > plfem::MIX_BIG_S2) {      // long front of a tile-form level: row-form workgroups
+        if (li.fwd_rows == 64 && fs2[f] > mix_big_s2) {      // long front of a tile-form level: row-form workgroups
           li.fwd_mixed = true;
           for (int t = 0; t * 16 < fm[f]; ++t) blk.push_back(make_int2(f, t | plfem::SWEEP_ROW_JOB_FLAG));
         }
