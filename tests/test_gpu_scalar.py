@@ -130,3 +130,19 @@ def test_cmt_rigorous_coupling_matches_oracle(c1_geometry, gpu_device, built_lib
         CoupledModeTheory(omega, "exact")
     with pytest.raises(ValueError):
         theory._compute_rigorous_coupling(modes, modes[:-1], g, mesh)
+
+
+def test_scalar_solver_at_north_star_size(c1_geometry, gpu_device, built_library):
+    """The scalar solver on the C1 mesh (N = 90 639 unknowns, 12 tree levels, long fronts -> every sweep kernel form
+    with one unknown per node): n_eff against the oracle, every pair an eigenpair of the assembled pencil."""
+    g = c1_geometry
+    mesh = generate_mesh(g, 1.0, 1)
+    solver = ScalarHelmholtzSolver(g, device=gpu_device)
+    modes = solver.solve(mesh, n_modes_target=10)
+    st = solver.last_stats
+    assert st["N"] == 90639 and st["nconv"] == 18 and st["refined"] is False and st["n_block_solves"] > 0
+    assert st["true_residual"] < ScalarHelmholtzSolver.RESIDUAL_TOL and st["pivot_perturbations"] == 0
+    ref = scalar.solve(g, MeshTriLite(mesh.p, mesh.t), 10)
+    assert len(modes) == len(ref) > 0
+    assert max(abs(a["n_eff"] - b["n_eff"]) for a, b in zip(modes, ref)) < N_EFF_TOL
+    solver.clear_cache()
