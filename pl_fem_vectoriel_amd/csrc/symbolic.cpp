@@ -112,7 +112,8 @@ struct Trace {
 // ------------------------------------------------------------------------------------------------
 // P2 numbering, scikit-fem compatible (MeshTri sort_t + build_entities + ElementTriP2 dof layout)
 // ------------------------------------------------------------------------------------------------
-std::string p2_numbering(int nv, int ne, const double* p, const int32_t* t, Symbolic& S) {
+// Part 1: validated, column-sorted element table (all the bisection tree needs besides the vertex coordinates).
+std::string p2_sort_columns(int nv, int ne, const int32_t* t, Symbolic& S) {
   Trace tr;
   S.nv = nv;
   S.ne = ne;
@@ -135,6 +136,15 @@ std::string p2_numbering(int nv, int ne, const double* p, const int32_t* t, Symb
   if (bad_t.load() == 1) return "mesh.t refers to a vertex outside mesh.p";
   if (bad_t.load() == 2) return "degenerate element (repeated vertex)";
   tr.lap("num: sort columns");
+  return "";
+}
+
+// Part 2: edges, element DOFs, DOF locations, boundary mask, interior list (reads tsorted, writes nothing the tree reads)
+std::string p2_edges_and_dofs(int nv, int ne, const double* p, Symbolic& S) {
+  Trace tr;
+  const int32_t* t0 = S.tsorted.data();
+  const int32_t* t1 = t0 + ne;
+  const int32_t* t2 = t1 + ne;
   // edges bucketed by their smaller vertex: local edges (0,1),(1,2),(0,2) -> (t0,t1),(t1,t2),(t0,t2)
   std::vector<int32_t> cnt((size_t)nv + 1, 0);
   for (int e = 0; e < ne; ++e) { cnt[t0[e] + 1] += 2; cnt[t1[e] + 1] += 1; }
@@ -366,8 +376,8 @@ struct alignas(64) ElemGeo {
   int32_t id;
 };
 
-void nd_tree(Symbolic& S, int leaf_elems, int nthreads) {
-  const int ne = S.ne, N = S.N;
+void nd_tree(Symbolic& S, const double* p, int leaf_elems, int nthreads) {
+  const int ne = S.ne;
   int L = 0;
   while (L < 24 && (((int64_t)ne + ((int64_t)1 << L) - 1) >> L) > leaf_elems) ++L;
   while (L > 0 && ((int64_t)1 << L) > ne) --L;
@@ -390,8 +400,8 @@ void nd_tree(Symbolic& S, int leaf_elems, int nthreads) {
       y0 = std::min(y0, o.y0); y1 = std::max(y1, o.y1);
     }
   };
-  const double* X = S.doflocs.data();
-  const double* Y = X + N;
+  const double* X = p;                 // vertex coordinates of the caller's mesh (the DOF table is built concurrently)
+  const double* Y = p + S.nv;
   Box root_box;
   {
     const int nt0 = (nthreads > 1 && g_pool) ? g_pool->nt : 1;
@@ -609,7 +619,10 @@ void nd_tree(Symbolic& S, int leaf_elems, int nthreads) {
   int level = 0;
   if (nthreads > 1 && g_pool) {
     int top = 0;
-    while ((1 << top) < 2 * nthreads) ++top;       // ~2 subtrees per thread, handed out dynamically
+    // ~2 subtrees per thread up to 8 threads, one per thread beyond (every extra top level is a round of short
+    // pool-parallel passes over small subdomains: synchronisation, not work); handed out dynamically
+    const int want = getenv("PLFEM_TREE_SUBTREES") ? atoi(getenv("PLFEM_TREE_SUBTREES")) : std::max(2 * std::min(nthreads, 8), nthreads);
+    while ((1 << top) < want) ++top;
     for (; level < std::min(top, L); ++level) {
       std::vector<Node> next;
       next.reserve(2 * cur.size());
@@ -858,7 +871,9 @@ std::string build_fronts(Symbolic& S, int nthreads) {
 
 std::string numbering_only(int nv, int ne, const double* p, const int32_t* t, Symbolic& S) {
   if (nv < 3 || ne < 1) return "empty mesh";
-  return p2_numbering(nv, ne, p, t, S);
+  std::string err = p2_sort_columns(nv, ne, t, S);
+  if (!err.empty()) return err;
+  return p2_edges_and_dofs(nv, ne, p, S);
 }
 
 std::string build_symbolic(int nv, int ne, const double* p, const int32_t* t, int leaf_elems,
@@ -874,34 +889,42 @@ std::string build_symbolic(int nv, int ne, const double* p, const int32_t* t, in
   g_pool = pool.get();
   struct Reset { ~Reset() { g_pool = nullptr; } } reset_guard;
   auto t0 = clk::now();
-  std::string err = p2_numbering(nv, ne, p, t, S);
+  std::string err = p2_sort_columns(nv, ne, t, S);
   if (!err.empty()) return err;
-  if (S.nsolve < 1) return "mesh has no interior DOF";
   auto t1 = clk::now();
-  // The node -> element adjacency / CSR row pointers (read edof, edges) and the bisection tree (reads tsorted,
-  // doflocs) touch disjoint data: with a pool, the former runs on a side thread (it does not scale anyway: its
-  // parallel form only trades one scan for eight filtered ones) while the pool builds the tree.
-  double t_side = 0.0;
+  // Two chains that touch disjoint data run side by side: the bisection tree (reads the sorted element table and the
+  // caller's vertex coordinates) on the pool, and -- on one side thread, serially: these loops are short and gain
+  // little from the pool -- the P2 numbering (edges, element DOFs, DOF locations, boundary) followed by the node ->
+  // element adjacency and the CSR row pointers.  The fronts need both.
+  double t_num = 0.0, t_side = 0.0;
+  std::string err_side;
   auto side = [&] {
     auto a = clk::now();
+    err_side = p2_edges_and_dofs(nv, ne, p, S);
+    auto b = clk::now();
+    t_num = secs(a, b);
+    if (!err_side.empty()) return;
     node_to_elem(S, 1);
     csr_rowptr(S, 1);
-    t_side = secs(a, clk::now());
+    t_side = secs(b, clk::now());
   };
-  if (nthreads > 1) {
+  static const bool chains_in_sequence = getenv("PLFEM_SYM_SEQUENTIAL") != nullptr;   // (A/B timing aid)
+  if (nthreads > 1 && !chains_in_sequence) {
     std::thread th(side);
-    nd_tree(S, leaf_elems, nthreads);
+    nd_tree(S, p, leaf_elems, nthreads);
     th.join();
   } else {
     side();
-    nd_tree(S, leaf_elems, nthreads);
+    if (err_side.empty()) nd_tree(S, p, leaf_elems, nthreads);
   }
+  if (!err_side.empty()) return err_side;
+  if (S.nsolve < 1) return "mesh has no interior DOF";
   auto t3 = clk::now();
   err = build_fronts(S, nthreads);
   auto t4 = clk::now();
-  S.t_numbering = secs(t0, t1);
-  S.t_pattern = t_side;                        // overlapped with the tree when nthreads > 1
-  S.t_tree = secs(t1, t3) - (nthreads > 1 ? 0.0 : t_side);
+  S.t_numbering = secs(t0, t1) + t_num;        // (with a pool: t_num and t_pattern overlap the tree)
+  S.t_pattern = t_side;
+  S.t_tree = secs(t1, t3) - (nthreads > 1 && !chains_in_sequence ? 0.0 : t_num + t_side);
   S.t_fronts = secs(t3, t4);
   return err;
 }
