@@ -487,7 +487,7 @@ def test_a_posteriori_guard_fires_on_a_bad_factor(small, gpu_device):
     solver = TrueVectorialMaxwellSolver(small.g, device=gpu_device)
     clean = solver.solve_vectorial_modes(small.mesh, 6)
     st = solver.last_stats
-    assert st["refined"] is False and st["true_residual"] < 1e-9
+    assert st["refined"] is False and st["true_residual"] < 1e-8
     ctx = next(iter(solver._cache.values()))["ctx"]
     ctx.set_option("debug_perturb", 1e-4)
     try:
