@@ -320,6 +320,16 @@ int create_impl(plfem_ctx* c, const plfem_symbolic* sym, int device, void* strea
         for (int q = 0; q < li.count; ++q) rect(o[q], cdiv(fm[o[q]] - fs2[o[q]], 64), cdiv(fs2[o[q]], 64));
         li.formz_n = (int)(pos - li.formz_off);
       }
+      // the same Z blocks once more as ONE list over all levels, root first: nothing in the factorisation reads Z, so
+      // a complete run forms it for every front in a single launch at the end (the per-level lists above serve
+      // plfem_debug_factor_until, which stops after a given level)
+      c->formz_all_off = pos;
+      for (int lev = 0; lev <= S.L; ++lev) {
+        const LevelInfo& li = c->levels[lev];
+        const int32_t* o = forder.data() + li.first;
+        for (int q = 0; q < li.count; ++q) rect(o[q], cdiv(fm[o[q]] - fs2[o[q]], 64), cdiv(fs2[o[q]], 64));
+      }
+      c->formz_all_n = (int)(pos - c->formz_all_off);
       ntiles = pos;
     }
     if (size_only) tiles.resize((size_t)ntiles);          // only its size matters to the placement pass

@@ -65,6 +65,8 @@ struct plfem_ctx {
   int2* d_tiles = nullptr;        // (front, tx | ty << 16) of every useful 64 x 64 workgroup of the factorisation
   std::vector<int64_t> upd_off;   // per (level, block step): first entry / entries of the trailing-update list
   std::vector<int> upd_n;
+  int64_t formz_all_off = 0;      // d_tiles: the Z blocks of every front in one list (root first)
+  int formz_all_n = 0;
   int2* d_blk = nullptr;          // (front, row block) of every sweep workgroup, level by level
   int32_t *d_tsorted = nullptr, *d_edof = nullptr, *d_rowptr = nullptr, *d_colind = nullptr;
   int32_t *d_slot_row = nullptr, *d_nptr = nullptr, *d_nadj = nullptr, *d_interior = nullptr;

@@ -710,12 +710,18 @@ void launch_factor(plfem_ctx* c, double sigma, int stop_level, int stop_step, in
                            c->d_fnode_ptr, c->d_front, c->d_dinv, c->d_tbuf, wb, rb, c->d_wbuf, c->d_rbuf);
       if (stop_here && (stop_stage == 3 || stop_stage == 4)) return;
     }
-    if (li.formz_n > 0) {
+    if (li.formz_n > 0 && stop_level >= 0) {          // (debug run that stops after a level: its Z now)
       const int2* zt = c->d_tiles + li.formz_off;
       hipLaunchKernelGGL(k_form_z, dim3(li.formz_n), dim3(256), 0, st, zt, c->d_fs2, c->d_fm, c->d_foff, c->d_front);
       hipLaunchKernelGGL(k_mirror_z, dim3(li.formz_n, 4), dim3(256), 0, st, zt, c->d_fs2, c->d_fm, c->d_foff, c->d_front);
     }
     if (lev == stop_level && stop_stage == 5) return;
+  }
+  // Z = L21 L11^-1 and its mirror for every front at once: only the solve sweeps read them
+  if (stop_level < 0 && c->formz_all_n > 0) {
+    const int2* zt = c->d_tiles + c->formz_all_off;
+    hipLaunchKernelGGL(k_form_z, dim3(c->formz_all_n), dim3(256), 0, st, zt, c->d_fs2, c->d_fm, c->d_foff, c->d_front);
+    hipLaunchKernelGGL(k_mirror_z, dim3(c->formz_all_n, 4), dim3(256), 0, st, zt, c->d_fs2, c->d_fm, c->d_foff, c->d_front);
   }
 }
 
