@@ -195,3 +195,46 @@ def test_closed_form_row_lengths_on_irregular_topology(built_library):
         np.testing.assert_array_equal(sym.array("rowptr"), P.indptr)
         np.testing.assert_array_equal(sym.array("colind"), P.indices)
         assert sym.info["nnz"] == P.nnz
+
+
+def test_analysis_is_identical_for_every_thread_count(built_library, c1_geometry):
+    """The tree runs on the pool while the numbering / adjacency chain runs on a side thread (nthreads > 1): every
+    array the device code or the tests can see must come out the same as from the sequential single-thread build."""
+    mesh = generate_mesh(c1_geometry, 0.6, 1)
+    ref = _native.Symbolic(mesh.p, mesh.t, nthreads=1)
+    names = ("edof", "tsorted", "edges", "doflocs", "bmask", "interior", "int_index", "rowptr", "colind", "nptr", "nadj",
+             "nloc", "leaf_of_elem", "leaf_elem_ptr", "leaf_elems", "owner", "fs", "fb", "fnode_ptr", "fnodes", "cinv0",
+             "cinv1", "foff", "prow", "npos")
+    for nt in (2, 5, 8, 16):
+        sym = _native.Symbolic(mesh.p, mesh.t, nthreads=nt)
+        for key in ("N", "nsolve", "nnz", "levels", "nfronts", "front_doubles", "max_front", "solve_entries", "factor_flops"):
+            assert sym.info[key] == ref.info[key], (nt, key)
+        for name in names:
+            np.testing.assert_array_equal(sym.array(name), ref.array(name), err_msg=f"{name} with {nt} threads")
+
+
+def test_malformed_mesh_is_reported_from_the_side_chain(built_library):
+    """A non-manifold mesh is detected by the edge numbering, which now runs beside the tree: the error must still come
+    back (and the tree thread must have been joined: no crash, no hang) for every thread count."""
+    p = np.array([[0.0, 1.0, 0.0, 1.0, 0.5], [0.0, 0.0, 1.0, 1.0, -1.0]])
+    t = np.array([[0, 1, 0, 0], [1, 3, 1, 1], [2, 2, 4, 3]], dtype=np.int32)      # edge (0, 1) in three triangles
+    for nt in (1, 4):
+        with pytest.raises(ValueError, match="non-manifold"):
+            _native.Symbolic(p, t, nthreads=nt)
+
+
+def test_allocator_tuning_can_be_switched_off(monkeypatch):
+    calls = []
+
+    class FakeLibc:
+        def mallopt(self, a, b):
+            calls.append((a, b))
+            return 1
+
+    monkeypatch.setattr(_native.ctypes, "CDLL", lambda name: FakeLibc())
+    monkeypatch.setenv("PLFEM_MALLOC_TUNE", "0")
+    _native._tune_host_allocator()
+    assert calls == []
+    monkeypatch.delenv("PLFEM_MALLOC_TUNE")
+    _native._tune_host_allocator()
+    assert calls == [(-3, 32 << 20), (-1, 512 << 20)]      # M_MMAP_THRESHOLD, M_TRIM_THRESHOLD
