@@ -189,6 +189,10 @@ int plfem_solve(plfem_ctx* ctx, const double* rhs_dev, double* x_dev, int32_t re
  * re-orthogonalisation; returns the k eigenvalues nearest sigma (largest |1/(lambda - sigma)|),
  * ascending, and B-orthonormal eigenvectors as 2N-vectors on the device.
  * Requires plfem_assemble_hfield + plfem_factor(sigma) before the call.
+ * tol: a pair counts as converged when its Ritz residual ||r|| <= tol |theta|, theta = 1 / (lambda - sigma), the
+ * criterion of ARPACK's dsaupd -- but tested after EVERY block step, and the iteration stops at the first step where
+ * all k pairs meet it, where ARPACK tests at its restarts and usually ends orders of magnitude below its tolerance:
+ * pass 1e-8 where the reference passes 1e-7 (measured agreement of the fields with eigsh: 3e-9 at 1e-8, 1e-7 at 1e-7).
  * evals_host[k]; evecs_dev[k][2N] (row c = vector c); stats_host[8] (may be NULL):
  *   [0] converged pairs, [1] OP applications, [2] restarts, [3] max relative Ritz residual.
  * stats_host[4] = passes over the factors (block solves; 0 = single-vector recurrence).
