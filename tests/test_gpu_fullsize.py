@@ -92,3 +92,29 @@ def test_c4_full_multiband_sweep_on_one_gpu(gpu_device, built_library):
         assert solver.last_stats["true_residual"] < 1e-8 and solver.last_stats["refined"] is False
         assert len(direct) == len(table[it.index]) and np.abs(direct - table[it.index]).max() < 1e-10
         solver.clear_cache()
+
+
+def test_guard_repairs_the_sweep_items_with_perturbed_pivots(gpu_device, built_library):
+    """Three cross-sections of the 64-item sweep meet a vanishing pivot pair in the static LDL^T order (DESIGN.md section
+    5: element growth ~1e9, first-pass eigen-residual 2e-7 .. 2e-6).  Whatever the tree does to them in the future:
+    the modes a caller gets must satisfy the a-posteriori bound, and when the first pass did not, the refined re-run
+    must have brought the residual down by orders of magnitude (not merely under the bar)."""
+    from pl_fem_vectoriel_amd.sweep import multiband_sweep_items
+    items = multiband_sweep_items()
+    tripped = 0
+    for idx in (13, 31, 41):
+        it = items[idx]
+        g = it.geometry()
+        mesh = generate_mesh(g, it.mesh_refinement, it.mesh_levels)
+        solver = TrueVectorialMaxwellSolver(g, device=gpu_device)
+        modes = solver.solve_vectorial_modes(mesh, it.n_modes)
+        st = solver.last_stats
+        assert 0 < len(modes) <= 22
+        assert st["true_residual"] <= solver.RESIDUAL_TOL
+        if st["refined"]:
+            tripped += 1
+            assert st["true_residual"] < 1e-2 * st["true_residual_first"], (idx, st["true_residual_first"], st["true_residual"])
+        else:
+            assert st["pivot_perturbations"] == 0
+        solver.clear_cache()
+    print(f"guard tripped on {tripped} of 3 items")
