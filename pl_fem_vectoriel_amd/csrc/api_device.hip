@@ -725,10 +725,11 @@ static int lanczos_block(plfem_ctx* c, int k, int ncv, double tol, int maxiter, 
     plfem::launch_panel_dot_block(c, c->d_BV + (size_t)lo * n, nc - lo, c->d_w, n, Hblk + lo, ld);
     plfem::launch_panel_axpy_block(c, c->d_V + (size_t)lo * n, nc - lo, Hblk + lo, ld, c->d_w, n);
     plfem::launch_panel_dot_block(c, c->d_BV, nc, c->d_w, n, c->d_hblk, ld, Hblk, ld);  // second pass, T += h2
-    plfem::launch_panel_axpy_block(c, c->d_V, nc, c->d_hblk, ld, c->d_w, n);
+    // (the second pass also leaves the block interleaved in d_t1 -- idle in this driver -- for the SpMV's gathers)
+    plfem::launch_panel_axpy_block(c, c->d_V, nc, c->d_hblk, ld, c->d_w, n, c->d_t1);
     {
       const int pid = plfem::prof_open(c, PLFEM_PROF_SPMV_B, 12.0 * c->nnz + 4.0 * (c->N + 1) + 2.0 * 8.0 * P * (double)n);
-      plfem::launch_spmv_b_block(c, c->d_w, c->d_bw, n);
+      plfem::launch_spmv_b_block_il(c, c->d_t1, c->d_bw, n);
       plfem::prof_close(c, pid);
     }
     plfem::launch_gram_chol_block(c, c->d_w, c->d_bw, n, Hblk + nc, ld, c->d_Rinv);   // W^T B W = R^T R, R -> T[nc:nc+P, c0:c0+P]

@@ -161,6 +161,7 @@ void launch_csr_gather(plfem_ctx* c);
 void launch_pattern_fill(plfem_ctx* c);   // colind / slot_row from the node -> element adjacency (once per context)
 void launch_spmv(plfem_ctx* c, int which, const double* x, double* y);
 void launch_spmv_b_block(plfem_ctx* c, const double* x, double* y, int64_t ld);   // y_q = B x_q, BLOCK_P vectors
+void launch_spmv_b_block_il(plfem_ctx* c, const double* x_interleaved, double* y, int64_t ld);   // same, x as [node][component][q]
 void launch_spmv_a_block(plfem_ctx* c, const double* x, double* y, int64_t ld);   // y_q = A x_q, BLOCK_P vectors
 // out_host[i] = ||A v_i - lambda_i B v_i|| / ||A v_i||  (k vectors, row i of evecs; synchronises)
 void launch_residuals(plfem_ctx* c, int k, const double* lam_host, const double* evecs, double* out_host);
@@ -183,7 +184,8 @@ void launch_rotate(plfem_ctx* c, const double* V, int m, const double* Smat, int
 // h = Pm^T W (ncols x BLOCK_P); hacc (optional) += the same coefficients
 void launch_panel_dot_block(plfem_ctx* c, const double* Pm, int ncols, const double* W, int64_t ldw, double* h, int ldh,
                             double* hacc = nullptr, int ldacc = 0);
-void launch_panel_axpy_block(plfem_ctx* c, const double* Pm, int ncols, const double* H, int ldh, double* W, int64_t ldw);
+void launch_panel_axpy_block(plfem_ctx* c, const double* Pm, int ncols, const double* H, int ldh, double* W, int64_t ldw,
+                             double* w_interleaved = nullptr);   // w_interleaved: see k_spmv_b_block_il
 void launch_mat_add(plfem_ctx* c, int ncols, double* acc, int lda, const double* h, int ldh);
 void launch_gram_chol_block(plfem_ctx* c, const double* W, const double* BW, int64_t ldw, double* Tblk, int ldT, double* Rinv);
 void launch_chol_block(plfem_ctx* c, const double* G, int ldg, double* Tblk, int ldT, double* Rinv);

@@ -163,10 +163,12 @@ __global__ __launch_bounds__(64) void k_panel_dot_finish_p(int P, int nchunks, c
 }
 
 // W[i, q] -= sum_c Pm[i, c] H[c + q*ldh]
+// wil (may be null): a second copy of the updated block with the P values of every DOF together,
+// wil[(node dpn + component) P + q] -- what the block SpMV that follows gathers from (k_spmv_b_block_il)
 template <int P>
 __global__ __launch_bounds__(256) void k_panel_axpy_p(int64_t n, int ncols, const double* __restrict__ Pm,
                                                       const double* __restrict__ H, int ldh, double* __restrict__ W,
-                                                      int64_t ldw) {
+                                                      int64_t ldw, double* __restrict__ wil, int N, int dpn) {
   extern __shared__ double sh[];      // [c][P]
   for (int k = threadIdx.x; k < ncols * P; k += 256) sh[k] = H[(k / P) + (int64_t)(k % P) * ldh];
   __syncthreads();
@@ -180,8 +182,18 @@ __global__ __launch_bounds__(256) void k_panel_axpy_p(int64_t n, int ncols, cons
 #pragma unroll
     for (int q = 0; q < P; ++q) acc[q] += a * sh[c * P + q];
   }
+  double w[P];
 #pragma unroll
-  for (int q = 0; q < P; ++q) W[(int64_t)q * ldw + i] -= acc[q];
+  for (int q = 0; q < P; ++q) {
+    w[q] = W[(int64_t)q * ldw + i] - acc[q];
+    W[(int64_t)q * ldw + i] = w[q];
+  }
+  if (wil) {
+    const int comp = (int)(i / N), node = (int)(i - (int64_t)comp * N);
+    double* d = wil + ((int64_t)node * dpn + comp) * P;
+#pragma unroll
+    for (int q = 0; q < P; ++q) d[q] = w[q];
+  }
 }
 
 // acc[c + q*lda] += h[c + q*ldh]
@@ -558,10 +570,11 @@ void launch_panel_dot_block(plfem_ctx* c, const double* Pm, int ncols, const dou
                      hacc, ldacc);
 }
 
-void launch_panel_axpy_block(plfem_ctx* c, const double* Pm, int ncols, const double* H, int ldh, double* W, int64_t ldw) {
+void launch_panel_axpy_block(plfem_ctx* c, const double* Pm, int ncols, const double* H, int ldh, double* W, int64_t ldw,
+                             double* w_interleaved) {
   constexpr int P = BLOCK_P;
   hipLaunchKernelGGL(k_panel_axpy_p<P>, dim3((unsigned)((c->n2 + 255) / 256)), dim3(256), sizeof(double) * ncols * P,
-                     c->stream, c->n2, ncols, Pm, H, ldh, W, ldw);
+                     c->stream, c->n2, ncols, Pm, H, ldh, W, ldw, w_interleaved, c->N, c->dpn);
 }
 
 void launch_mat_add(plfem_ctx* c, int ncols, double* acc, int lda, const double* h, int ldh) {
