@@ -899,20 +899,26 @@ std::string build_symbolic(int nv, int ne, const double* p, const int32_t* t, in
   double t_num = 0.0, t_side = 0.0;
   std::string err_side;
   auto side = [&] {
-    auto a = clk::now();
-    err_side = p2_edges_and_dofs(nv, ne, p, S);
-    auto b = clk::now();
-    t_num = secs(a, b);
-    if (!err_side.empty()) return;
-    node_to_elem(S, 1);
-    csr_rowptr(S, 1);
-    t_side = secs(b, clk::now());
+    try {                                        // (an exception must not leave a thread body)
+      auto a = clk::now();
+      err_side = p2_edges_and_dofs(nv, ne, p, S);
+      auto b = clk::now();
+      t_num = secs(a, b);
+      if (!err_side.empty()) return;
+      node_to_elem(S, 1);
+      csr_rowptr(S, 1);
+      t_side = secs(b, clk::now());
+    } catch (const std::exception& e) {
+      err_side = std::string("exception in the numbering chain: ") + e.what();
+    }
   };
   static const bool chains_in_sequence = getenv("PLFEM_SYM_SEQUENTIAL") != nullptr;   // (A/B timing aid)
   if (nthreads > 1 && !chains_in_sequence) {
-    std::thread th(side);
+    struct Joined {                              // joins on every way out of the scope (an exception in the tree included)
+      std::thread th;
+      ~Joined() { if (th.joinable()) th.join(); }
+    } guard{std::thread(side)};
     nd_tree(S, p, leaf_elems, nthreads);
-    th.join();
   } else {
     side();
     if (err_side.empty()) nd_tree(S, p, leaf_elems, nthreads);
