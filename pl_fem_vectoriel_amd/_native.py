@@ -214,6 +214,21 @@ def debug_symeig_band(a, b: int, nsel: int):
     return w, v
 
 
+def default_host_threads() -> int:
+    """Workers of the symbolic analysis.  Measured on the MI355X host (256 logical CPUs, C1): 4.3 ms with 8 workers, 4.0
+    with 16, 5.5 with 24 -- so 16 at most, and no more than this process's share of the physical cores when several
+    ranks run on the node (``LOCAL_WORLD_SIZE``, set by torchrun and by ``bench.py --gpus N``): the ranks of a sweep
+    analyse their meshes at the same time."""
+    ncpu = os.cpu_count() or 1
+    if ncpu < 64:
+        return max(1, min(ncpu, 8))
+    try:
+        local_world = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))
+    except ValueError:
+        local_world = 1
+    return max(2, min(16, (ncpu // 2) // local_world))
+
+
 class Symbolic:
     """Mesh-only analysis (P2 numbering, CSR pattern, front tree).  Host only — needs no GPU."""
 
@@ -226,9 +241,7 @@ class Symbolic:
         h = ctypes.c_void_p()
         err = ctypes.create_string_buffer(512)
         if nthreads <= 0:
-            # measured on the MI355X host (256 logical CPUs, C1): 4.3 ms with 8 workers, 4.0 with 16, 5.5 with 24
-            ncpu = os.cpu_count() or 1
-            nthreads = int(os.environ.get("PLFEM_HOST_THREADS", 16 if ncpu >= 64 else min(ncpu, 8)))
+            nthreads = int(os.environ.get("PLFEM_HOST_THREADS", default_host_threads()))
         if leaf_elems <= 0:
             leaf_elems = int(os.environ.get("PLFEM_LEAF_ELEMS", 0))
         rc = lib.plfem_symbolic_create_ex(p.shape[1], t.shape[1], _ptr(p), _ptr(t), int(leaf_elems), int(nthreads),
