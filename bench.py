@@ -332,7 +332,7 @@ def run_solve_config(args, D: Dist, levels: int, with_cpu_baseline: bool):
     # and stream each) -- a single solve is a chain of latency-bound launches and leaves most of the GPU idle
     in_flight, per_lane = 4, 3
     conc = None
-    if world == 1 and levels <= 1:
+    if world == 1 and levels == 1 and with_cpu_baseline:    # (the extras of the default run; profiling runs pass --no-cpu-baseline)
         import threading
 
         def lane(n):
