@@ -377,7 +377,7 @@ int create_impl(plfem_ctx* c, const plfem_symbolic* sym, int device, void* strea
   TRY(dalloc(c, &c->d_wbuf, (size_t)4 * fnodes_total * plfem::NB));   // two halves: panels of even / odd block steps
   TRY(dalloc(c, &c->d_rbuf, (size_t)4 * fnodes_total * plfem::NB));
   TRY(dalloc(c, &c->d_dinv, (size_t)S.nfronts * plfem::NB * plfem::NB));
-  TRY(dalloc(c, &c->d_delta, (size_t)2 * fnodes_total));
+  TRY(dalloc(c, &c->d_delta, (size_t)4 * fnodes_total));   // D^-1: (diagonal, off-diagonal) per front row
   TRY(dalloc(c, &c->d_tbuf, (size_t)2 * fnodes_total * plfem::NB));
   TRY(dalloc(c, &c->d_fvec2, (size_t)2 * fnodes_total * plfem::BLOCK_P));
   TRY(dalloc(c, &c->d_u0, (size_t)2 * fnodes_total * plfem::BLOCK_P));
@@ -619,7 +619,7 @@ extern "C" int plfem_factor(plfem_ctx* c, double sigma) {
   HIP_TRY(c, hipMemsetAsync(c->d_fvec, 0, sizeof(double) * 2 * c->fnodes_total * plfem::BLOCK_P, c->stream));   // (see plfem_create)
   plfem::launch_factor(c, sigma);
   if (c->debug_perturb != 0.0)   // test hook (plfem_set_option "debug_perturb"): a slightly wrong factor
-    plfem::launch_scale(c, (int64_t)c->dpn * c->S->fs[0], 1.0 + c->debug_perturb, c->d_delta);
+    plfem::launch_scale(c, (int64_t)2 * c->dpn * c->S->fs[0], 1.0 + c->debug_perturb, c->d_delta);
   HIP_TRY(c, hipEventRecord(c->ev[1][1], c->stream));
   c->ev_used[1] = true;
   TRY(check_launch(c, "factor"));

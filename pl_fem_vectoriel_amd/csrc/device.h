@@ -89,9 +89,9 @@ struct plfem_ctx {
   int32_t* d_prow = nullptr;      // per local node of a front: local node index in the PARENT front, -1 = none / padding
   double *d_wbuf = nullptr, *d_rbuf = nullptr;   // per-front panels m x NB, offset 2*fnode_ptr[f]*NB
   double* d_dinv = nullptr;       // per-front NB x NB (inverse of the current unit-lower pivot block)
-  double* d_delta = nullptr;      // per-front D of the LDL^T (offset 2*fnode_ptr[f])
+  double* d_delta = nullptr;      // per-front D^-1 of the block LDL^T: (diagonal, off-diagonal of the node pair) per row, offset 2 * (2*fnode_ptr[f])
   double* d_tbuf = nullptr;       // per-front NB x s2 scratch (block row of L11), offset 2*fnode_ptr[f]*NB
-  double* d_fvec2 = nullptr;      // forward-sweep results of the owned rows (ys = D^-1 L11^-1 r), front order
+  double* d_fvec2 = nullptr;      // forward-sweep results of the owned rows (t = L11^-1 r; the backward sweep applies D^-1), front order
   int32_t* d_counters = nullptr;  // [0] pivot perturbations
   // ---- Lanczos workspace
   double *d_V = nullptr, *d_BV = nullptr, *d_V2 = nullptr, *d_BV2 = nullptr;   // n2 x (max_ncv+1), column major

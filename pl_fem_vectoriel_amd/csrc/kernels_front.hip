@@ -140,17 +140,19 @@ __global__ __launch_bounds__(256) void k_front_gather(
 }
 
 // ------------------------------------------------------------------------------------------------
-// block LDL^T, step kb of a level:  diag -> invrow -> panel -> update
+// block LDL^T, step kb of a level:  launch A (pivot block + panel) -> launch B (update + inverse row)
 // ------------------------------------------------------------------------------------------------
-// Pivot block: unpivoted LDL^T of the NB x NB block (static perturbation of vanishing pivots) with
-// X = L^-1 formed by applying the row operations to the identity at the same time.  Writes X (dinv),
-// D (delta), the block itself (lower X, upper X^T).  Workgroups of ONE wave, so the 32 dependent
-// elimination steps need no workgroup barrier: lane (i, h) keeps columns 16h .. 16h+15 of row i in
-// registers -- entry c is a[i][c] while c > k and x[i][c] once c <= k -- the pivot is broadcast with
-// v_readlane and row k of x / column k of L travel through one LDS row.  blockIdx.y >= 1: the other
-// waves save the block row L[k, <k] of L11 for the triangular-inverse update (tbuf), 64 columns each.
+// The pivots are 2 x 2 NODE blocks: local DOFs (2q, 2q+1) of a front are the two field components of one P2 node
+// (scalar pencil: two neighbouring nodes), and the LDL^T eliminates such a pair at a time,
+//     K = L D L^T,   D = blockdiag(E_q), E_q = [[a, b], [b, c]],   L unit lower triangular with L[2q+1, 2q] = 0.
+// This is Bunch-Kaufman's 2 x 2 pivot taken at every node and without any permutation: the pencil A - sigma B is
+// indefinite (mid-spectrum shift), so the Schur complement of a single DOF vanishes by chance now and then -- in every
+// case met so far its partner was the other component of the same node -- while E_q is singular
+// only if the whole node is.  L^-1 keeps its unit lower triangular form (what lower(F11) / upper(F11) store), D^-1 is
+// kept as its diagonal plus ONE off-diagonal entry per DOF (the partner of local DOF i is i ^ 1).  It also halves the
+// chain of dependent elimination steps of a 32 x 32 pivot block (16 pair steps).
 // 1 / d by v_rcp_f64 + two Newton steps: full precision (~1 ulp, not correctly rounded), 5 instructions instead of
-// the ~25 of the IEEE division sequence; for finite, normal d (pivots are perturbed away from zero)
+// the ~25 of the IEEE division sequence; for finite, normal d
 __device__ __forceinline__ double fast_rcp(double d) {
   double r = __builtin_amdgcn_rcp(d);
   r = fma(fma(-d, r, 1.0), r, r);
@@ -163,59 +165,193 @@ __device__ __forceinline__ double readlane_f64(double v, int src) {
   return __hiloint2double(hi, lo);
 }
 
-// The LDL^T of the NB x NB pivot block by ONE wave (64 lanes).  Inputs come straight from F; results go to LDS:
-// tile[i][c] = X[i][c] (X = L^-1, zero above the diagonal), sD[i] = D[i] (1 for the identity padding of a partial block).
+// value of the same register in lane ^ 16 (v_permlane16_swap: rows 1 / 3 of the first operand trade places with rows
+// 0 / 2 of the second)
+__device__ __forceinline__ double lane_xor16(double v, bool odd_row) {
+  const int lo = __double2loint(v), hi = __double2hiint(v);
+  const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+  const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+  return __hiloint2double(odd_row ? b[0] : b[1], odd_row ? a[0] : a[1]);
+}
+
+// value of the same register in the lane of the same row i in half H of the wave (lanes 32 H .. 32 H + 31), for every lane
+// (v_permlane32_swap: the upper half of the first operand trades places with the lower half of the second)
+template <int H>
+__device__ __forceinline__ double half_bcast(double v) {
+  const int lo = __double2loint(v), hi = __double2hiint(v);
+  const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+  const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+  return __hiloint2double(b[H], a[H]);
+}
+
+// One pivot pair E = [[a, b], [b, c]], all lanes with the same (wave-uniform) operands: Bunch-Kaufman's choice INSIDE the
+// pair, without permutation.
+//   * a diagonal entry carries the pair (max(|a|, |c|) >= alpha |b|, alpha = (1 + sqrt 17) / 8): two scalar pivots, the
+//     larger diagonal entry first -- mode 1: a then c, mode 2: c then a.  The multipliers of a row with entries (y0, y1) in
+//     the pair's columns are formed the way the two eliminations would form them (first = yf / pf, second =
+//     (ys - g yf) / d2, then the in-pair multiplier g = b / pf is folded back: first -= second g), so that L keeps its
+//     zero at (2q+1, 2q) and the rounding errors of the two columns stay correlated: a pair can be as ill conditioned as a
+//     single sliver element makes it (1e9, two nodes of the scalar pencil) and products of its multipliers with the raw
+//     1e9-sized columns still cancel to working accuracy, which multipliers from an explicit E^-1 do not;
+//   * neither does (both below alpha |b|): a genuine 2 x 2 pivot, mode 0, through the explicit inverse adj(E) / det with
+//     det = ac - b^2 by Kahan's difference of products; |det| >= (1 - alpha^2) b^2, so E is well conditioned.
+// e11, e12, e22: E^-1 explicitly, for the solve sweeps (D^-1 = blockdiag(E^-1) applied to a vector is benign either way).
+// Vanishing pivots -- below thr = 1e-13 of the largest entry the pair's two rows had in the pivot block when the step
+// began -- are perturbed statically and counted: the second scalar pivot becomes +-thr, a pair that vanishes altogether
+// thr I.
+struct PairPivot {
+  int mode;
+  double k0, k1, k2;          // mode 0: e11, e12, e22;  modes 1, 2: g, 1 / (first pivot), 1 / (second pivot)
+  double e11, e12, e22;
+};
+
+__device__ __forceinline__ void pair_pivot(double a, double b, double c, double thr, PairPivot& P, int& nper) {
+  constexpr double ALPHA = 0.6403882032022076;
+  const double s = fmax(fmax(fabs(a), fabs(c)), fabs(b));
+  if (!(s >= thr)) {                                        // (also NaN)
+    P.mode = 0;
+    P.e11 = P.e22 = P.k0 = P.k2 = fast_rcp(thr);
+    P.e12 = P.k1 = 0.0;
+    nper += 2;
+  } else if (fmax(fabs(a), fabs(c)) >= ALPHA * fabs(b)) {
+    const bool cf = fabs(c) > fabs(a);
+    const double pf = cf ? c : a, ps = cf ? a : c;
+    const double r1 = fast_rcp(pf);
+    const double g = b * r1;
+    double d2 = fma(-g, b, ps);
+    if (!(fabs(d2) >= thr)) {
+      d2 = (d2 < 0.0) ? -thr : thr;
+      nper += 1;
+    }
+    const double r2 = fast_rcp(d2);
+    const double eff = fma(g * g, r2, r1);
+    P.mode = cf ? 2 : 1;
+    P.k0 = g;
+    P.k1 = r1;
+    P.k2 = r2;
+    P.e11 = cf ? r2 : eff;
+    P.e22 = cf ? eff : r2;
+    P.e12 = -g * r2;
+  } else {
+    const double p = b * b;
+    const double rd = fast_rcp(fma(a, c, -p) - fma(b, b, -p));
+    P.mode = 0;
+    P.e11 = P.k0 = c * rd;
+    P.e12 = P.k1 = -b * rd;
+    P.e22 = P.k2 = a * rd;
+  }
+}
+
+// (w0, w1) = (y0, y1) E^-1 for one row, see pair_pivot
+__device__ __forceinline__ void pair_multipliers(int mode, double k0, double k1, double k2, double y0, double y1,
+                                                 double& w0, double& w1) {
+  if (mode == 0) {
+    w0 = fma(y0, k0, y1 * k1);
+    w1 = fma(y0, k1, y1 * k2);
+  } else {
+    const bool cf = mode == 2;
+    const double yf = cf ? y1 : y0, ys = cf ? y0 : y1;
+    const double ws = fma(-yf, k0, ys) * k2;
+    const double wf = fma(-ws, k0, yf * k1);
+    w0 = cf ? ws : wf;
+    w1 = cf ? wf : ws;
+  }
+}
+
+// The block LDL^T of the NB x NB pivot block by ONE wave (64 lanes), so the 16 dependent pair steps need no workgroup
+// barrier.  Lane (i, h) keeps columns 16h .. 16h+15 of row i in registers -- entry c is a[i][c] while c belongs to a
+// pair that is still to come and x[i][c] (X = L^-1, built by applying the row operations to the identity) afterwards.
+// A step broadcasts the pair's three entries with v_readlane, stages rows 2q, 2q+1 in LDS (double buffered: one
+// wave-level round trip per step), hands columns 2q, 2q+1 to the other half of the wave with v_permlane32_swap and
+// works out the pivot (pair_pivot) while the rows travel; row i > 2q+1 then loses
+// l1 row(2q) + l2 row(2q+1) with (l1, l2) = (a[i][2q], a[i][2q+1]) E_q^-1 (pair_multipliers) in all its columns.
+// Inputs come straight from F; results go to LDS: tile[i][c] = X[i][c] (zero above the diagonal), sDd[i] / sDo[i] =
+// diagonal / off-diagonal entry of D^-1 in row i (identity for the padding of a partial block).
+struct PivotLds {
+  double row[2][2][NB];
+  double coef[NB / 2][3];     // per pair: PairPivot k0, k1, k2 and mode, for the panel
+  int mode[NB / 2];
+};
+
 __device__ __forceinline__ void ldl_pivot_wave(const double* __restrict__ F, int m, int k0, int nbk, int lane,
-                                               double (*tile)[NB + 1], double* __restrict__ sD, double* __restrict__ srow,
-                                               int32_t* __restrict__ counters) {
+                                               double (*tile)[NB + 1], double* __restrict__ sDd, double* __restrict__ sDo,
+                                               PivotLds& S, int32_t* __restrict__ counters) {
   static_assert(NB == 32, "lane map of ldl_pivot_wave");
   const int i = lane & 31, h = lane >> 5;
   double v[16];
-  double amax = 0.0;
+  double rmax = 0.0;
 #pragma unroll
   for (int cc = 0; cc < 16; ++cc) {
     const int c = 16 * h + cc;
     v[cc] = (i < nbk && c < nbk) ? F[(int64_t)(k0 + c) * m + (k0 + i)] : (i == c ? 1.0 : 0.0);
-    amax = fmax(amax, fabs(v[cc]));
+    rmax = fmax(rmax, fabs(v[cc]));
   }
-  for (int off = 32; off >= 1; off >>= 1) amax = fmax(amax, __shfl_xor(amax, off));
-  const double thr = fmax(1e-13 * amax, 1e-300);
-  double dmine = 1.0;
-  int nperturbed = 0;                                          // (counted without a branch inside the 32 dependent steps)
+  // "vanishing" is judged against the pair's OWN two rows of the block as they arrive (not against the whole block: a
+  // sliver element's 1e9-sized entries in the same block would declare a healthy pivot of 1e-4 a zero)
+  rmax = fmax(rmax, __shfl_xor(rmax, 32));
+  rmax = fmax(rmax, __shfl_xor(rmax, 1));
+  double dd = 1.0, od = 0.0;
+  int nper = 0;
 #pragma unroll
-  for (int k = 0; k < NB; ++k) {
-    const int kh = k >> 4, kc = k & 15;
-    double dk = readlane_f64(v[kc], k + 32 * kh);              // a[k][k]
-    const bool vanishing = !(fabs(dk) >= thr);
-    dk = vanishing ? ((dk < 0.0) ? -thr : thr) : dk;
-    nperturbed += vanishing ? 1 : 0;
-    if (i == k) dmine = dk;
-    double colk = 0.0;
-    if (h == kh) {                                            // column k leaves a and becomes a column of x
-      colk = v[kc];
-      v[kc] = (i == k) ? 1.0 : 0.0;
-    }
-    // one LDS row: entries c <= k = row k of x (from lane row k), entries c > k = a[c][k], the RAW column below the
-    // pivot (from lane row c).  The LDS queue of a wave is in order, so the second write wins where both touch.
-    // Row i then loses l_i x (that row) with ONE multiplier l_i = a[i][k] / d_k for every column: behind the pivot it
-    // is a[i][c] -= l_i a[c][k], in front of it x[i][c] -= l_i x[k][c].  Storing the raw column keeps the reciprocal
-    // of the pivot (v_rcp_f64 + two Newton steps instead of the ~25-instruction IEEE division) out of the LDS round
-    // trip: it is computed while the row travels.
-    if (i == k) {
+  for (int q = 0; q < NB / 2; ++q) {
+    const int k = 2 * q, kh = k >> 4, kc = k & 15, buf = q & 1;
+    if (k >= nbk) break;                                       // (partial block: the rest is identity padding)
+    const double a = readlane_f64(v[kc], k + 32 * kh);         // a[k][k]
+    const double b = readlane_f64(v[kc], k + 1 + 32 * kh);     // a[k+1][k]
+    const double c = readlane_f64(v[kc + 1], k + 1 + 32 * kh); // a[k+1][k+1]
+    const double thr = fmax(1e-13 * readlane_f64(rmax, k), 1e-300);
+    // columns k, k+1 leave a and become columns of x; every lane of row i needs a[i][k], a[i][k+1] (held by half kh)
+    const double c0 = kh ? half_bcast<1>(v[kc]) : half_bcast<0>(v[kc]);
+    const double c1 = kh ? half_bcast<1>(v[kc + 1]) : half_bcast<0>(v[kc + 1]);
+    v[kc] = (h == kh) ? ((i == k) ? 1.0 : 0.0) : v[kc];
+    v[kc + 1] = (h == kh) ? ((i == k + 1) ? 1.0 : 0.0) : v[kc + 1];
+    if ((i | 1) == k + 1) {
 #pragma unroll
-      for (int cc = 0; cc < 16; ++cc) srow[16 * h + cc] = v[cc];
+      for (int cc = 0; cc < 16; ++cc) S.row[buf][i & 1][16 * h + cc] = v[cc];
     }
-    if (h == kh && i > k) srow[i] = colk;
-    const double rdk = fast_rcp(dk);
+    // Behind the pair the staged rows carry the RAW columns a[c][k], a[c][k+1] (from lane row c) instead of row k's own
+    // copy a[k][c] of them: the block is then eliminated from its lower triangle alone, like the panel below it (the
+    // two copies of a 1e9-sized sliver entry differ by their rounding, and a mix of them costs two digits of K^-1).
+    // The LDS queue of a wave is in order, so this second write wins where both touch.
+    if (h == kh && i > k + 1) {
+      S.row[buf][0][i] = c0;
+      S.row[buf][1][i] = c1;
+    }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const double li = (i > k) ? srow[i] * rdk : 0.0;
+    // all 16 row reads are issued before the (dependent) arithmetic of E^-1, which runs while they travel
+    double ra[16], rb[16];
 #pragma unroll
-    for (int cc = 0; cc < 16; ++cc) v[cc] -= li * srow[16 * h + cc];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (int cc = 0; cc < 16; ++cc) {
+      ra[cc] = S.row[buf][0][16 * h + cc];
+      rb[cc] = S.row[buf][1][16 * h + cc];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    PairPivot P;
+    pair_pivot(a, b, c, thr, P, nper);
+    if ((i | 1) == k + 1) {
+      dd = (i == k) ? P.e11 : P.e22;
+      od = P.e12;
+    }
+    if (lane == 0) {
+      S.coef[q][0] = P.k0;
+      S.coef[q][1] = P.k1;
+      S.coef[q][2] = P.k2;
+      S.mode[q] = P.mode;
+    }
+    double l1, l2;
+    pair_multipliers(P.mode, P.k0, P.k1, P.k2, c0, c1, l1, l2);
+    l1 = (i > k + 1) ? l1 : 0.0;
+    l2 = (i > k + 1) ? l2 : 0.0;
+#pragma unroll
+    for (int cc = 0; cc < 16; ++cc) v[cc] = fma(-l1, ra[cc], fma(-l2, rb[cc], v[cc]));
+  }
+  if (lane >= nbk / 2 && lane < NB / 2) {                      // identity padding of a partial block
+    S.coef[lane][0] = 1.0;
+    S.coef[lane][1] = 0.0;
+    S.coef[lane][2] = 1.0;
+    S.mode[lane] = 0;
   }
   // x[i][c] = v for c <= i, 0 above the diagonal
 #pragma unroll
@@ -223,16 +359,20 @@ __device__ __forceinline__ void ldl_pivot_wave(const double* __restrict__ F, int
     const int c = 16 * h + cc;
     tile[i][c] = (c <= i) ? v[cc] : 0.0;
   }
-  if (h == 0) sD[i] = dmine;
-  if (lane == 0 && nperturbed > 0 && counters) atomicAdd(&counters[0], nperturbed);
+  if (h == 0) {
+    sDd[i] = dd;
+    sDo[i] = od;
+  }
+  if (lane == 0 && nper > 0 && counters) atomicAdd(&counters[0], nper);
 }
 
 // Launch A of a block step: pivot block + panel.  Every panel workgroup (64 rows below the pivot block, 4 waves of 16
 // rows) factorises the pivot block ITSELF in its wave 0 -- the same arithmetic in every workgroup, so the same bits --
 // while its other waves' panel operands are in flight: no launch boundary between pivot and panel, and nobody writes
-// the pivot block in this launch (workgroup 0 of the front stores X and D in dinv / delta; the block is written back
-// into F by the next launch).  Panel: Y = R X^T (= R L^-T), W = Y D^-1 (= the L panel); W, Y are saved for the update
-// kernel and W replaces R in F (a workgroup reads and writes its own rows only).
+// the pivot block in this launch (workgroup 0 of the front stores X in dinv and D^-1 in delta; the block is written back
+// into F by the next launch).  Panel: Y = R X^T (= R L^-T), W = Y D^-1 (= the L panel; D^-1 couples the two columns of a
+// node pair: the partner column of an accumulator register sits in lane ^ 16); W, Y are saved for the update kernel and
+// W replaces R in F (a workgroup reads and writes its own rows only).
 // blockIdx.y < n_tb: these workgroups save the block row L[k, <k] of L11 for the triangular-inverse update (tbuf).
 __global__ __launch_bounds__(256) void k_ldl_pivot_panel(int n_tb, const int32_t* __restrict__ forder, int kb,
                                                          const int32_t* __restrict__ fs2, const int32_t* __restrict__ fm,
@@ -269,9 +409,9 @@ __global__ __launch_bounds__(256) void k_ldl_pivot_panel(int n_tb, const int32_t
   const int n_pan = gridDim.y - n_tb;
   const int t0 = k0 + nbk;
   if (bx > 0 && t0 + bx * 64 >= m) return;
-  __shared__ double srow[NB];
+  __shared__ __attribute__((aligned(16))) PivotLds piv;
   __shared__ double tile[NB][NB + 1];
-  __shared__ double sD[NB];
+  __shared__ double sDd[NB], sDo[NB];
   // this wave's 16 panel rows of the first chunk: B operand R^T (k = pivot column j, col = row i), requested before the
   // pivot work
   const int lr = lane & 15, lk = lane >> 4;
@@ -284,31 +424,25 @@ __global__ __launch_bounds__(256) void k_ldl_pivot_panel(int n_tb, const int32_t
       b[kk] = (ibase < m && jx < nbk) ? F[(int64_t)(k0 + jx) * m + ibase + lr] : 0.0;
     }
   }
-  if (wave == 0) ldl_pivot_wave(F, m, k0, nbk, lane, tile, sD, srow, bx == 0 ? counters : nullptr);
+  if (wave == 0) ldl_pivot_wave(F, m, k0, nbk, lane, tile, sDd, sDo, piv, bx == 0 ? counters : nullptr);
   __syncthreads();
   if (bx == 0) {
     double* D = dinv + (int64_t)f * NB * NB;              // D[r + c*NB] = X[r][c]
     for (int e = threadIdx.x; e < NB * NB; e += 256) D[e] = tile[e & (NB - 1)][e >> 5];
-    if (threadIdx.x < nbk) delta[2 * fnode_ptr[f] + k0 + threadIdx.x] = sD[threadIdx.x];
+    if (threadIdx.x < nbk)                                    // D^-1: (diagonal, off-diagonal) of every row
+      reinterpret_cast<double2*>(delta)[2 * fnode_ptr[f] + k0 + threadIdx.x] = make_double2(sDd[threadIdx.x], sDo[threadIdx.x]);
   }
   // Y^T[c][i] = sum_j X[c][j] R[i][j] on v_mfma_f64_16x16x4_f64: A <- X (row c, k = j), B <- R^T; the accumulator
   // register r of lane l is Y[i = ibase + (l & 15)][c = 16 tc + (l >> 4) + 4 r]: 128-B runs of W, Y and of the panel
   // columns of F.
   double* W = wbuf + 2 * fnode_ptr[f] * NB;
   double* Y = rbuf + 2 * fnode_ptr[f] * NB;
-  double xa0[NB / 4], xa1[NB / 4], rd[2][4];
+  double xa0[NB / 4], xa1[NB / 4];
 #pragma unroll
   for (int kk = 0; kk < NB / 4; ++kk) {
     xa0[kk] = tile[lr][4 * kk + lk];
     xa1[kk] = tile[16 + lr][4 * kk + lk];
   }
-#pragma unroll
-  for (int tc = 0; tc < 2; ++tc)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int c = 16 * tc + lk + 4 * r;
-      rd[tc][r] = (c < nbk) ? fast_rcp(sD[c]) : 0.0;
-    }
   for (int ch = bx; t0 + ch * 64 < m; ch += n_pan) {
     const int ibase = t0 + ch * 64 + 16 * wave;
     if (ibase >= m) break;                                 // m is a multiple of 16: the wave's 16 rows are all valid
@@ -332,7 +466,11 @@ __global__ __launch_bounds__(256) void k_ldl_pivot_panel(int n_tb, const int32_t
       for (int r = 0; r < 4; ++r) {
         const int c = 16 * tc + lk + 4 * r;
         const double y = tc == 0 ? y0[r] : y1[r];
-        const double w = y * rd[tc][r];
+        const double yp = lane_xor16(y, lk & 1);             // the pair's other column
+        const int q = c >> 1;
+        double wa, wb;
+        pair_multipliers(piv.mode[q], piv.coef[q][0], piv.coef[q][1], piv.coef[q][2], (c & 1) ? yp : y, (c & 1) ? y : yp, wa, wb);
+        const double w = (c & 1) ? wb : wa;
         W[(int64_t)c * m + i] = w;
         Y[(int64_t)c * m + i] = y;
         if (c < nbk) F[(int64_t)(k0 + c) * m + i] = w;

@@ -3,8 +3,11 @@
 // (P = 1: plfem_solve and the single-vector Lanczos; P = 4: block Lanczos -- every entry of the factors is read
 // once for P vectors).
 //
-//   forward : [ys; u] = [D^-1 L11^-1 r ;  w_b - Z r],     r = rhs_own + children's updates
-//   backward: x_own   = L11^-T ys - Z^T x_b
+//   forward : [t; u]  = [L11^-1 r ;  w_b - Z r],          r = rhs_own + children's updates
+//   backward: x_own   = L11^-T ys - Z^T x_b,              ys = D^-1 t
+// D is block diagonal with one 2 x 2 block per node pair (kernels_front.hip): ys_i = dd_i t_i + od_i t_(i^1).  The
+// backward sweep applies it while it stages ys (a thread reads t_i, its partner t_(i^1) and the row's two entries of
+// D^-1: one memory round trip, nothing crosses lanes), so the forward kernels store their sums as they are.
 //
 // One kernel per tree level and direction.  A workgroup of such a kernel is latency, not bandwidth (a few tens of
 // KB of factor entries each), so everything is laid out for ONE memory round trip before the arithmetic starts:
@@ -45,7 +48,8 @@ struct SweepArgs {
   const int32_t *fs2, *fm;
   const int64_t *foff, *fnode_ptr;
   const int32_t *cinv0, *cinv1, *prow;
-  const double *front, *delta;
+  const double* front;
+  const double2* dinv2;             // D^-1 of every front row: (diagonal, off-diagonal entry of the row's node pair)
   double *fr, *u0, *u1, *ys, *xl;
 };
 
@@ -120,21 +124,19 @@ __device__ __forceinline__ void stage_fwd(const SweepArgs& A, double* sv, int64_
   first.request(A, np, tid, tid < need);
 }
 
-// epilogue of one forward row r (already summed: acc = [L11^-1 ; Z] r): owned rows -> ys = acc / D, boundary rows ->
+// epilogue of one forward row r (already summed: acc = [L11^-1 ; Z] r): owned rows -> t = acc, boundary rows ->
 // u = w - acc pushed into the parent's slot.  The operands are requested by `request` before the sums.
 template <int P>
 struct FwdOut {
-  double dl, w0[P], w1[P];
+  double w0[P], w1[P];
   int c0, c1;
   int64_t dst;
   __device__ __forceinline__ void request(const SweepArgs& A, int f, int64_t np, int s2, int m, int r) {
-    dl = 1.0;
     c0 = c1 = -1;
     dst = -1;
 #pragma unroll
     for (int u = 0; u < P; ++u) { w0[u] = 0.0; w1[u] = 0.0; }
-    if (r >= m) return;
-    if (r < s2) { dl = A.delta[2 * np + r]; return; }
+    if (r >= m || r < s2) return;
     const int pr = A.prow[np + (r >> A.sh)];
     if (!A.leaf_level) {
       c0 = A.cinv0[np + (r >> A.sh)];
@@ -212,9 +214,8 @@ __device__ __forceinline__ void fwd_tile_body(const SweepArgs& A, int f, int rb,
       tot[u] = t;
     }
     if (r < s2) {
-      const double di = 1.0 / out.dl;
 #pragma unroll
-      for (int u = 0; u < P; ++u) A.ys[(2 * np + r) * P + u] = tot[u] * di;
+      for (int u = 0; u < P; ++u) A.ys[(2 * np + r) * P + u] = tot[u];
     } else if (out.dst >= 0) {
       double* d = ((f & 1) ? A.u0 : A.u1) + out.dst;
 #pragma unroll
@@ -300,7 +301,7 @@ __device__ __forceinline__ void fwd_rows_body(const SweepArgs& A, int f, int rb,
   if (lane < V && orow < m) {
     const int u = oidx % P;
     if (orow < s2) {
-      A.ys[(2 * np + orow) * P + u] = acc[0] / out.dl;
+      A.ys[(2 * np + orow) * P + u] = acc[0];
     } else if (out.dst >= 0) {
       double wu = out.w(0);
 #pragma unroll
@@ -325,9 +326,10 @@ struct BwdStage {
     own = i < s2;
     pr = -1;
     if (on && !own) pr = A.prow[np + (i >> A.sh)];
-    if (on && own) {
+    if (on && own) {                        // ys_i = dd_i t_i + od_i t_(i^1)  (s2 is even: the partner is an owned row too)
+      const double2 d = A.dinv2[2 * np + i];
 #pragma unroll
-      for (int u = 0; u < P; ++u) v[u] = A.ys[(2 * np + i) * P + u];
+      for (int u = 0; u < P; ++u) v[u] = fma(d.x, A.ys[(2 * np + i) * P + u], d.y * A.ys[(2 * np + (i ^ 1)) * P + u]);
     }
   }
   __device__ __forceinline__ void request_value(const SweepArgs& A, int64_t npp) {
@@ -581,7 +583,7 @@ void sweeps(plfem_ctx* c) {
   A.dbg = c->debug_sweep_filter;
   A.fs2 = c->d_fs2; A.fm = c->d_fm; A.foff = c->d_foff; A.fnode_ptr = c->d_fnode_ptr;
   A.cinv0 = c->d_cinv0; A.cinv1 = c->d_cinv1; A.prow = c->d_prow;
-  A.front = c->d_front; A.delta = c->d_delta;
+  A.front = c->d_front; A.dinv2 = reinterpret_cast<const double2*>(c->d_delta);
   A.fr = c->d_fvec; A.u0 = c->d_u0; A.u1 = c->d_u1; A.ys = c->d_fvec2; A.xl = c->d_xl;
   double sweep_total = 0.0;                     // algorithmic bytes of one whole sweep (either direction)
   for (const LevelInfo& li : c->levels) sweep_total += li.sweep_bytes + 8.0 * (P - 1) * li.sweep_vec_doubles;

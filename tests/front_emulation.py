@@ -82,16 +82,22 @@ def assemble_front(T: FrontTree, f, Ke, S):
 
 
 def ldl_partial(Fm, s2):
-    """Unpivoted partial LDL^T of the first s2 pivots.  Returns the storage the HIP path leaves in F:
-    lower(F11) = L11^-1, upper(F11) = L11^-T, F21 = Z = L21 L11^-1, F12 = Z^T, F22 = S; and D."""
+    """Partial block LDL^T of the first s2 pivots with 2 x 2 node-pair pivots in the static order (local DOFs 2q, 2q+1
+    together, no permutation; kernels_front.hip).  Returns the storage the HIP path leaves in F: lower(F11) = L11^-1,
+    upper(F11) = L11^-T, F21 = Z = L21 L11^-1, F12 = Z^T, F22 = S; and D^-1 as (diagonal, off-diagonal) per row."""
     F = Fm.copy()
-    m = F.shape[0]
-    d = np.zeros(s2)
-    for k in range(s2):
-        d[k] = F[k, k]
-        l = F[k + 1:, k] / d[k]
-        F[k + 1:, k + 1:] -= np.outer(l, F[k + 1:, k])
-        F[k + 1:, k] = l
+    Dinv = np.zeros((s2, 2))
+    for k in range(0, s2, 2):
+        a, b, c = F[k, k], F[k + 1, k], F[k + 1, k + 1]
+        det = a * c - b * b
+        e11, e12, e22 = c / det, -b / det, a / det
+        Dinv[k] = (e11, e12)
+        Dinv[k + 1] = (e22, e12)
+        C = F[k + 2:, k:k + 2].copy()
+        Lc = np.stack([C[:, 0] * e11 + C[:, 1] * e12, C[:, 0] * e12 + C[:, 1] * e22], 1)
+        F[k + 2:, k + 2:] -= Lc @ C.T
+        F[k + 2:, k:k + 2] = Lc
+        F[k + 1, k] = 0.0
     L11 = np.tril(F[:s2, :s2], -1) + np.eye(s2)
     X = sla.solve_triangular(L11, np.eye(s2), lower=True, unit_diagonal=True) if s2 else np.zeros((0, 0))
     out = F.copy()
@@ -99,7 +105,7 @@ def ldl_partial(Fm, s2):
     Z = F[s2:, :s2] @ np.tril(X)
     out[s2:, :s2] = Z
     out[:s2, s2:] = Z.T
-    return out, d
+    return out, Dinv
 
 
 def factor(T: FrontTree, Ke):
@@ -135,7 +141,8 @@ def solve(T: FrontTree, Fs, Ds, rhs):
                 w[ok] += W[ch][T.s2(ch) + 2 * inv[ok] + comp[ok]]
         F = Fs[f]
         r = w[:s2].copy()
-        ys = np.array([F[:i + 1, i] @ r[:i + 1] for i in range(s2)]) / Ds[f] if s2 else np.zeros(0)
+        t = np.array([F[:i + 1, i] @ r[:i + 1] for i in range(s2)]) if s2 else np.zeros(0)
+        ys = Ds[f][:, 0] * t + Ds[f][:, 1] * t.reshape(-1, 2)[:, ::-1].ravel()        # D^-1 t, partner of row i = i ^ 1
         w[s2:] -= F[s2:, :s2] @ r                                  # u = w_b - Z r
         W[f], Y[f] = w, ys
     x = np.zeros(2 * N)

@@ -135,7 +135,7 @@ def test_fronts_match_numpy_emulation(small):
             if a.size:
                 assert np.abs(a - b).max() <= 1e-8 * max(np.abs(b).max(), 1e-300), (f, name)
         if s2:
-            dg = P.ctx.debug_copy("delta", 2 * T.fptr[f], s2)
+            dg = P.ctx.debug_copy("delta", 2 * 2 * T.fptr[f], 2 * s2).reshape(s2, 2)     # D^-1: (diagonal, off-diagonal) per row
             assert np.abs(dg - Ds[f]).max() <= 1e-8 * np.abs(Ds[f]).max(), f
 
 
