@@ -159,12 +159,6 @@ __device__ __forceinline__ double fast_rcp(double d) {
   return fma(fma(-d, r, 1.0), r, r);
 }
 
-__device__ __forceinline__ double readlane_f64(double v, int src) {
-  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
-  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
-  return __hiloint2double(hi, lo);
-}
-
 // value of the same register in lane ^ 16 (v_permlane16_swap: rows 1 / 3 of the first operand trade places with rows
 // 0 / 2 of the second)
 __device__ __forceinline__ double lane_xor16(double v, bool odd_row) {
@@ -172,16 +166,6 @@ __device__ __forceinline__ double lane_xor16(double v, bool odd_row) {
   const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
   const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
   return __hiloint2double(odd_row ? b[0] : b[1], odd_row ? a[0] : a[1]);
-}
-
-// value of the same register in the lane of the same row i in half H of the wave (lanes 32 H .. 32 H + 31), for every lane
-// (v_permlane32_swap: the upper half of the first operand trades places with the lower half of the second)
-template <int H>
-__device__ __forceinline__ double half_bcast(double v) {
-  const int lo = __double2loint(v), hi = __double2hiint(v);
-  const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
-  const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
-  return __hiloint2double(b[H], a[H]);
 }
 
 // One pivot pair E = [[a, b], [b, c]], all lanes with the same (wave-uniform) operands: Bunch-Kaufman's choice INSIDE the
@@ -205,44 +189,7 @@ struct PairPivot {
   double e11, e12, e22;
 };
 
-__device__ __forceinline__ void pair_pivot(double a, double b, double c, double thr, PairPivot& P, int& nper) {
-  constexpr double ALPHA = 0.6403882032022076;
-  const double s = fmax(fmax(fabs(a), fabs(c)), fabs(b));
-  if (!(s >= thr)) {                                        // (also NaN)
-    P.mode = 0;
-    P.e11 = P.e22 = P.k0 = P.k2 = fast_rcp(thr);
-    P.e12 = P.k1 = 0.0;
-    nper += 2;
-  } else if (fmax(fabs(a), fabs(c)) >= ALPHA * fabs(b)) {
-    const bool cf = fabs(c) > fabs(a);
-    const double pf = cf ? c : a, ps = cf ? a : c;
-    const double r1 = fast_rcp(pf);
-    const double g = b * r1;
-    double d2 = fma(-g, b, ps);
-    if (!(fabs(d2) >= thr)) {
-      d2 = (d2 < 0.0) ? -thr : thr;
-      nper += 1;
-    }
-    const double r2 = fast_rcp(d2);
-    const double eff = fma(g * g, r2, r1);
-    P.mode = cf ? 2 : 1;
-    P.k0 = g;
-    P.k1 = r1;
-    P.k2 = r2;
-    P.e11 = cf ? r2 : eff;
-    P.e22 = cf ? eff : r2;
-    P.e12 = -g * r2;
-  } else {
-    const double p = b * b;
-    const double rd = fast_rcp(fma(a, c, -p) - fma(b, b, -p));
-    P.mode = 0;
-    P.e11 = P.k0 = c * rd;
-    P.e12 = P.k1 = -b * rd;
-    P.e22 = P.k2 = a * rd;
-  }
-}
-
-// (w0, w1) = (y0, y1) E^-1 for one row, see pair_pivot
+// (w0, w1) = (y0, y1) E^-1 for one row, see above
 __device__ __forceinline__ void pair_multipliers(int mode, double k0, double k1, double k2, double y0, double y1,
                                                  double& w0, double& w1) {
   if (mode == 0) {
@@ -258,117 +205,182 @@ __device__ __forceinline__ void pair_multipliers(int mode, double k0, double k1,
   }
 }
 
-// The block LDL^T of the NB x NB pivot block by ONE wave (64 lanes), so the 16 dependent pair steps need no workgroup
-// barrier.  Lane (i, h) keeps columns 16h .. 16h+15 of row i in registers -- entry c is a[i][c] while c belongs to a
-// pair that is still to come and x[i][c] (X = L^-1, built by applying the row operations to the identity) afterwards.
-// A step broadcasts the pair's three entries with v_readlane, stages rows 2q, 2q+1 in LDS (double buffered: one
-// wave-level round trip per step), hands columns 2q, 2q+1 to the other half of the wave with v_permlane32_swap and
-// works out the pivot (pair_pivot) while the rows travel; row i > 2q+1 then loses
-// l1 row(2q) + l2 row(2q+1) with (l1, l2) = (a[i][2q], a[i][2q+1]) E_q^-1 (pair_multipliers) in all its columns.
+// The pivot of one pair AND the multipliers (l1, l2) = (y0, y1) E^-1 of this thread's row.  What a step of the pivot
+// block costs is the number of instructions its waves issue (one wave per SIMD: ~5 clocks each, v_rcp_f64 16) and the
+// compare -> select pairs on its path (56 clocks against 7 for a dependent v_fma_f64, scripts/micro/f64_latency.hip), so
+// the three cases are wave-uniform BRANCHES, each with its roles fixed at compile time, not selects: measured per pair
+// step (scripts/micro/pivot_bench.hip), all three candidates carried to one final select 1216 clocks, selects on the
+// operands 1455.
+template <bool CF>   // scalar pivots, CF: c first
+__device__ __forceinline__ void pair_step_diag(double pf, double b, double ps, double thr, double yf, double ys,
+                                               PairPivot& P, double& lf, double& ls, int& nper) {
+  const double r1 = fast_rcp(pf);
+  const double g = b * r1;
+  double d2 = fma(-g, b, ps);
+  if (__builtin_expect(!(fabs(d2) >= thr), 0)) {             // the second scalar pivot vanishes: d2 := +-thr
+    d2 = (d2 < 0.0) ? -thr : thr;
+    nper += 1;
+  }
+  const double r2 = fast_rcp(d2);
+  ls = fma(-yf, g, ys) * r2;
+  lf = fma(-ls, g, yf * r1);
+  const double eff = fma(g * g, r2, r1);
+  P.mode = CF ? 2 : 1;
+  P.k0 = g;
+  P.k1 = r1;
+  P.k2 = r2;
+  P.e11 = CF ? r2 : eff;
+  P.e22 = CF ? eff : r2;
+  P.e12 = -g * r2;
+}
+
+__device__ __forceinline__ void pair_step(double a, double b, double c, double thr, double y0, double y1, PairPivot& P,
+                                          double& l1, double& l2, int& nper) {
+  constexpr double ALPHA = 0.6403882032022076;
+  const double fa = fabs(a), fb = fabs(b), fc = fabs(c);
+  const double pmax = fmax(fa, fc);
+  if (__builtin_expect(!(fmax(pmax, fb) >= thr), 0)) {       // the pair vanishes altogether (also NaN): E := thr I
+    const double it = 1.0 / thr;
+    P.mode = 0;
+    P.k0 = P.k2 = P.e11 = P.e22 = it;
+    P.k1 = P.e12 = 0.0;
+    l1 = y0 * it;
+    l2 = y1 * it;
+    nper += 2;
+  } else if (pmax >= ALPHA * fb) {
+    if (fc > fa) {
+      pair_step_diag<true>(c, b, a, thr, y1, y0, P, l2, l1, nper);
+      asm volatile("" ::: "memory");                         // (keeps the two arms apart: no if-conversion into selects)
+    } else {
+      pair_step_diag<false>(a, b, c, thr, y0, y1, P, l1, l2, nper);
+      asm volatile("" ::: "memory");
+    }
+  } else {
+    const double p = b * b;
+    const double rd = fast_rcp(fma(a, c, -p) - fma(b, b, -p));   // Kahan: ac - b^2 to two roundings
+    const double x11 = c * rd, x12 = -b * rd, x22 = a * rd;
+    l1 = fma(y0, x11, y1 * x12);
+    l2 = fma(y0, x12, y1 * x22);
+    P.mode = 0;
+    P.k0 = P.e11 = x11;
+    P.k1 = P.e12 = x12;
+    P.k2 = P.e22 = x22;
+    asm volatile("" ::: "memory");
+  }
+}
+
+// The block LDL^T of the NB x NB pivot block by the 4 waves of a workgroup.  Thread (i, cg) keeps columns 4 cg .. 4 cg + 3
+// of row i in registers -- entry c is a[i][c] while c belongs to a pair that is still to come and x[i][c] (X = L^-1, built
+// by applying the row operations to the identity) afterwards.  A pair step publishes through LDS (double buffered, ONE
+// workgroup barrier per step): rows 2q, 2q+1 (their x part, c <= 2q+1, is what gets read) and the RAW columns a[c][2q],
+// a[c][2q+1] from thread row c -- behind the pair a step reads those, not row 2q's own copy a[2q][c] of them: the block is
+// eliminated from its lower triangle alone, like the panel below it (the two copies of a 1e9-sized sliver entry differ by
+// their rounding, and a mix of them costs two digits of K^-1).  Every thread then works out the pivot (pair_step, the same
+// bits everywhere) and row i > 2q+1 loses l1 row(2q) + l2 row(2q+1) with (l1, l2) = (a[i][2q], a[i][2q+1]) E_q^-1.
+// Why four waves: what a step costs is its LDS instructions (a lone wave gets a fraction of the LDS rate; measured with
+// scripts/micro/pivot_bench.hip: one wave holding 16 columns per lane spends 470 of a step's 1370 clocks issuing its 16
+// ds_read_b128 and 460 on the then serial reciprocals); four waves read 4 columns each, in parallel.
 // Inputs come straight from F; results go to LDS: tile[i][c] = X[i][c] (zero above the diagonal), sDd[i] / sDo[i] =
-// diagonal / off-diagonal entry of D^-1 in row i (identity for the padding of a partial block).
+// diagonal / off-diagonal entry of D^-1 in row i (identity for the padding of a partial block), S.coef / S.mode.
 struct PivotLds {
-  double row[2][2][NB];
+  double row[2][2][NB];       // x part of rows 2q, 2q+1 of the pair in flight (entries c <= 2q+1 are read)
+  double col[2][2][NB];       // raw columns 2q, 2q+1: a[c][2q], a[c][2q+1] for every row c (entries c >= 2q are read)
+  double rmax[NB];            // largest entry of every row pair of the block on arrival
   double coef[NB / 2][3];     // per pair: PairPivot k0, k1, k2 and mode, for the panel
   int mode[NB / 2];
 };
 
-__device__ __forceinline__ void ldl_pivot_wave(const double* __restrict__ F, int m, int k0, int nbk, int lane,
-                                               double (*tile)[NB + 1], double* __restrict__ sDd, double* __restrict__ sDo,
-                                               PivotLds& S, int32_t* __restrict__ counters) {
-  static_assert(NB == 32, "lane map of ldl_pivot_wave");
-  const int i = lane & 31, h = lane >> 5;
-  double v[16];
+__device__ __forceinline__ void ldl_pivot_block(const double* __restrict__ F, int m, int k0, int nbk, int tid,
+                                                double (*tile)[NB + 1], double* __restrict__ sDd, double* __restrict__ sDo,
+                                                PivotLds& S, int32_t* __restrict__ counters) {
+  static_assert(NB == 32, "thread map of ldl_pivot_block");
+  const int i = tid & 31, cg = tid >> 5;
+  double v[4];
   double rmax = 0.0;
 #pragma unroll
-  for (int cc = 0; cc < 16; ++cc) {
-    const int c = 16 * h + cc;
+  for (int cc = 0; cc < 4; ++cc) {
+    const int c = 4 * cg + cc;
     v[cc] = (i < nbk && c < nbk) ? F[(int64_t)(k0 + c) * m + (k0 + i)] : (i == c ? 1.0 : 0.0);
     rmax = fmax(rmax, fabs(v[cc]));
   }
   // "vanishing" is judged against the pair's OWN two rows of the block as they arrive (not against the whole block: a
   // sliver element's 1e9-sized entries in the same block would declare a healthy pivot of 1e-4 a zero)
-  rmax = fmax(rmax, __shfl_xor(rmax, 32));
-  rmax = fmax(rmax, __shfl_xor(rmax, 1));
+  tile[cg][i] = rmax;
+  __syncthreads();
+  if (tid < NB) {
+    double r = 0.0;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) r = fmax(r, fmax(tile[g][tid], tile[g][tid ^ 1]));
+    S.rmax[tid] = r;
+  }
   double dd = 1.0, od = 0.0;
   int nper = 0;
 #pragma unroll
   for (int q = 0; q < NB / 2; ++q) {
-    const int k = 2 * q, kh = k >> 4, kc = k & 15, buf = q & 1;
+    const int k = 2 * q, cgk = k >> 2, pc = k & 3, buf = q & 1;
     if (k >= nbk) break;                                       // (partial block: the rest is identity padding)
-    const double a = readlane_f64(v[kc], k + 32 * kh);         // a[k][k]
-    const double b = readlane_f64(v[kc], k + 1 + 32 * kh);     // a[k+1][k]
-    const double c = readlane_f64(v[kc + 1], k + 1 + 32 * kh); // a[k+1][k+1]
-    const double thr = fmax(1e-13 * readlane_f64(rmax, k), 1e-300);
-    // columns k, k+1 leave a and become columns of x; every lane of row i needs a[i][k], a[i][k+1] (held by half kh)
-    const double c0 = kh ? half_bcast<1>(v[kc]) : half_bcast<0>(v[kc]);
-    const double c1 = kh ? half_bcast<1>(v[kc + 1]) : half_bcast<0>(v[kc + 1]);
-    v[kc] = (h == kh) ? ((i == k) ? 1.0 : 0.0) : v[kc];
-    v[kc + 1] = (h == kh) ? ((i == k + 1) ? 1.0 : 0.0) : v[kc + 1];
+    if (cg == cgk) {                                           // columns k, k+1 leave a and become columns of x
+      S.col[buf][0][i] = v[pc];
+      S.col[buf][1][i] = v[pc + 1];
+      v[pc] = (i == k) ? 1.0 : 0.0;
+      v[pc + 1] = (i == k + 1) ? 1.0 : 0.0;
+    }
     if ((i | 1) == k + 1) {
 #pragma unroll
-      for (int cc = 0; cc < 16; ++cc) S.row[buf][i & 1][16 * h + cc] = v[cc];
+      for (int cc = 0; cc < 4; ++cc) S.row[buf][i & 1][4 * cg + cc] = v[cc];
     }
-    // Behind the pair the staged rows carry the RAW columns a[c][k], a[c][k+1] (from lane row c) instead of row k's own
-    // copy a[k][c] of them: the block is then eliminated from its lower triangle alone, like the panel below it (the
-    // two copies of a 1e9-sized sliver entry differ by their rounding, and a mix of them costs two digits of K^-1).
-    // The LDS queue of a wave is in order, so this second write wins where both touch.
-    if (h == kh && i > k + 1) {
-      S.row[buf][0][i] = c0;
-      S.row[buf][1][i] = c1;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    // all 16 row reads are issued before the (dependent) arithmetic of E^-1, which runs while they travel
-    double ra[16], rb[16];
+    __syncthreads();
+    const double a = S.col[buf][0][k], b = S.col[buf][0][k + 1], c = S.col[buf][1][k + 1];
+    const double thr = fmax(1e-13 * S.rmax[k], 1e-300);
+    // this row's entries in the pair's columns (rows up to 2q+1 are done: no multipliers)
+    const double y0 = (i > k + 1) ? S.col[buf][0][i] : 0.0, y1 = (i > k + 1) ? S.col[buf][1][i] : 0.0;
+    double ra[4], rb[4];
 #pragma unroll
-    for (int cc = 0; cc < 16; ++cc) {
-      ra[cc] = S.row[buf][0][16 * h + cc];
-      rb[cc] = S.row[buf][1][16 * h + cc];
+    for (int cc = 0; cc < 4; ++cc) {
+      const int cidx = 4 * cg + cc;
+      const bool behind = cidx > k + 1;
+      ra[cc] = behind ? S.col[buf][0][cidx] : S.row[buf][0][cidx];
+      rb[cc] = behind ? S.col[buf][1][cidx] : S.row[buf][1][cidx];
     }
-    __builtin_amdgcn_sched_barrier(0);
     PairPivot P;
-    pair_pivot(a, b, c, thr, P, nper);
+    double l1, l2;
+    pair_step(a, b, c, thr, y0, y1, P, l1, l2, nper);
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc) v[cc] = fma(-l1, ra[cc], fma(-l2, rb[cc], v[cc]));
     if ((i | 1) == k + 1) {
       dd = (i == k) ? P.e11 : P.e22;
       od = P.e12;
     }
-    if (lane == 0) {
+    if (tid == 0) {
       S.coef[q][0] = P.k0;
       S.coef[q][1] = P.k1;
       S.coef[q][2] = P.k2;
       S.mode[q] = P.mode;
     }
-    double l1, l2;
-    pair_multipliers(P.mode, P.k0, P.k1, P.k2, c0, c1, l1, l2);
-    l1 = (i > k + 1) ? l1 : 0.0;
-    l2 = (i > k + 1) ? l2 : 0.0;
-#pragma unroll
-    for (int cc = 0; cc < 16; ++cc) v[cc] = fma(-l1, ra[cc], fma(-l2, rb[cc], v[cc]));
   }
-  if (lane >= nbk / 2 && lane < NB / 2) {                      // identity padding of a partial block
-    S.coef[lane][0] = 1.0;
-    S.coef[lane][1] = 0.0;
-    S.coef[lane][2] = 1.0;
-    S.mode[lane] = 0;
+  if (tid >= nbk / 2 && tid < NB / 2) {                        // identity padding of a partial block
+    S.coef[tid][0] = 1.0;
+    S.coef[tid][1] = 0.0;
+    S.coef[tid][2] = 1.0;
+    S.mode[tid] = 0;
   }
+  __syncthreads();                                             // (tile was the scratch of the row maxima)
   // x[i][c] = v for c <= i, 0 above the diagonal
 #pragma unroll
-  for (int cc = 0; cc < 16; ++cc) {
-    const int c = 16 * h + cc;
+  for (int cc = 0; cc < 4; ++cc) {
+    const int c = 4 * cg + cc;
     tile[i][c] = (c <= i) ? v[cc] : 0.0;
   }
-  if (h == 0) {
+  if (tid < NB) {
     sDd[i] = dd;
     sDo[i] = od;
   }
-  if (lane == 0 && nper > 0 && counters) atomicAdd(&counters[0], nper);
+  if (tid == 0 && nper > 0 && counters) atomicAdd(&counters[0], nper);
 }
 
 // Launch A of a block step: pivot block + panel.  Every panel workgroup (64 rows below the pivot block, 4 waves of 16
-// rows) factorises the pivot block ITSELF in its wave 0 -- the same arithmetic in every workgroup, so the same bits --
-// while its other waves' panel operands are in flight: no launch boundary between pivot and panel, and nobody writes
+// rows) factorises the pivot block ITSELF -- the same arithmetic in every workgroup, so the same bits -- while its panel
+// operands are in flight: no launch boundary between pivot and panel, and nobody writes
 // the pivot block in this launch (workgroup 0 of the front stores X in dinv and D^-1 in delta; the block is written back
 // into F by the next launch).  Panel: Y = R X^T (= R L^-T), W = Y D^-1 (= the L panel; D^-1 couples the two columns of a
 // node pair: the partner column of an accumulator register sits in lane ^ 16); W, Y are saved for the update kernel and
@@ -424,7 +436,7 @@ __global__ __launch_bounds__(256) void k_ldl_pivot_panel(int n_tb, const int32_t
       b[kk] = (ibase < m && jx < nbk) ? F[(int64_t)(k0 + jx) * m + ibase + lr] : 0.0;
     }
   }
-  if (wave == 0) ldl_pivot_wave(F, m, k0, nbk, lane, tile, sDd, sDo, piv, bx == 0 ? counters : nullptr);
+  ldl_pivot_block(F, m, k0, nbk, threadIdx.x, tile, sDd, sDo, piv, bx == 0 ? counters : nullptr);
   __syncthreads();
   if (bx == 0) {
     double* D = dinv + (int64_t)f * NB * NB;              // D[r + c*NB] = X[r][c]
