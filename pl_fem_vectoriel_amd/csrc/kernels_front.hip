@@ -142,15 +142,18 @@ __global__ __launch_bounds__(256) void k_front_gather(
 // ------------------------------------------------------------------------------------------------
 // block LDL^T, step kb of a level:  launch A (pivot block + panel) -> launch B (update + inverse row)
 // ------------------------------------------------------------------------------------------------
-// The pivots are 2 x 2 NODE blocks: local DOFs (2q, 2q+1) of a front are the two field components of one P2 node
-// (scalar pencil: two neighbouring nodes), and the LDL^T eliminates such a pair at a time,
-//     K = L D L^T,   D = blockdiag(E_q), E_q = [[a, b], [b, c]],   L unit lower triangular with L[2q+1, 2q] = 0.
-// This is Bunch-Kaufman's 2 x 2 pivot taken at every node and without any permutation: the pencil A - sigma B is
-// indefinite (mid-spectrum shift), so the Schur complement of a single DOF vanishes by chance now and then -- in every
-// case met so far its partner was the other component of the same node -- while E_q is singular
-// only if the whole node is.  L^-1 keeps its unit lower triangular form (what lower(F11) / upper(F11) store), D^-1 is
-// kept as its diagonal plus ONE off-diagonal entry per DOF (the partner of local DOF i is i ^ 1).  It also halves the
-// chain of dependent elimination steps of a 32 x 32 pivot block (16 pair steps).
+// The pivots are taken NODE PAIR by node pair: local DOFs (2q, 2q+1) of a front are the two field components of one P2
+// node (scalar pencil: two neighbouring nodes), and a step of the LDL^T eliminates such a pair -- Bunch-Kaufman's choice
+// between scalar and 2 x 2 pivots, restricted to the pair and without any permutation:
+//     K = L D L^T,   L unit lower triangular,   D = blockdiag(D_q),   E_q = [[a, b], [b, c]] the pair's Schur complement,
+//   * two scalar pivots in the static order (a, then c - b^2 / a): D_q diagonal, L[2q+1, 2q] = b / a;
+//   * one genuine 2 x 2 pivot: D_q = E_q, L[2q+1, 2q] = 0, applied through the explicit inverse adj(E_q) / det.
+// The pencil A - sigma B is indefinite (mid-spectrum shift), so a scalar Schur complement vanishes by chance now and then
+// while its pair does not; a pair, on the other hand, can be nearly singular with healthy diagonal entries (a local
+// resonance), and then only the scalar order keeps the error down.  Rule: whichever amplifies rounding errors less --
+// (b / a)^2 for the scalar order against the condition number max|E|^2 / |det| of the explicit inverse.  L^-1 keeps its unit
+// lower triangular form either way (what lower(F11) / upper(F11) store); D^-1 is kept as its diagonal plus ONE
+// off-diagonal entry per DOF (the partner of local DOF i is i ^ 1; zero for scalar pivots).
 // 1 / d by v_rcp_f64 + two Newton steps: full precision (~1 ulp, not correctly rounded), 5 instructions instead of
 // the ~25 of the IEEE division sequence; for finite, normal d
 __device__ __forceinline__ double fast_rcp(double d) {
@@ -168,103 +171,54 @@ __device__ __forceinline__ double lane_xor16(double v, bool odd_row) {
   return __hiloint2double(odd_row ? b[0] : b[1], odd_row ? a[0] : a[1]);
 }
 
-// One pivot pair E = [[a, b], [b, c]], all lanes with the same (wave-uniform) operands: Bunch-Kaufman's choice INSIDE the
-// pair, without permutation.
-//   * a diagonal entry carries the pair (max(|a|, |c|) >= alpha |b|, alpha = (1 + sqrt 17) / 8): two scalar pivots, the
-//     larger diagonal entry first -- mode 1: a then c, mode 2: c then a.  The multipliers of a row with entries (y0, y1) in
-//     the pair's columns are formed the way the two eliminations would form them (first = yf / pf, second =
-//     (ys - g yf) / d2, then the in-pair multiplier g = b / pf is folded back: first -= second g), so that L keeps its
-//     zero at (2q+1, 2q) and the rounding errors of the two columns stay correlated: a pair can be as ill conditioned as a
-//     single sliver element makes it (1e9, two nodes of the scalar pencil) and products of its multipliers with the raw
-//     1e9-sized columns still cancel to working accuracy, which multipliers from an explicit E^-1 do not;
-//   * neither does (both below alpha |b|): a genuine 2 x 2 pivot, mode 0, through the explicit inverse adj(E) / det with
-//     det = ac - b^2 by Kahan's difference of products; |det| >= (1 - alpha^2) b^2, so E is well conditioned.
-// e11, e12, e22: E^-1 explicitly, for the solve sweeps (D^-1 = blockdiag(E^-1) applied to a vector is benign either way).
-// Vanishing pivots -- below thr = 1e-13 of the largest entry the pair's two rows had in the pivot block when the step
-// began -- are perturbed statically and counted: the second scalar pivot becomes +-thr, a pair that vanishes altogether
-// thr I.
-struct PairPivot {
-  int mode;
-  double k0, k1, k2;          // mode 0: e11, e12, e22;  modes 1, 2: g, 1 / (first pivot), 1 / (second pivot)
-  double e11, e12, e22;
-};
-
-// (w0, w1) = (y0, y1) E^-1 for one row, see above
-__device__ __forceinline__ void pair_multipliers(int mode, double k0, double k1, double k2, double y0, double y1,
-                                                 double& w0, double& w1) {
-  if (mode == 0) {
-    w0 = fma(y0, k0, y1 * k1);
-    w1 = fma(y0, k1, y1 * k2);
-  } else {
-    const bool cf = mode == 2;
-    const double yf = cf ? y1 : y0, ys = cf ? y0 : y1;
-    const double ws = fma(-yf, k0, ys) * k2;
-    const double wf = fma(-ws, k0, yf * k1);
-    w0 = cf ? ws : wf;
-    w1 = cf ? wf : ws;
-  }
-}
-
-// The pivot of one pair AND the multipliers (l1, l2) = (y0, y1) E^-1 of this thread's row.  What a step of the pivot
-// block costs is the number of instructions its waves issue (one wave per SIMD: ~5 clocks each, v_rcp_f64 16) and the
-// compare -> select pairs on its path (56 clocks against 7 for a dependent v_fma_f64, scripts/micro/f64_latency.hip), so
-// the three cases are wave-uniform BRANCHES, each with its roles fixed at compile time, not selects: measured per pair
-// step (scripts/micro/pivot_bench.hip), all three candidates carried to one final select 1216 clocks, selects on the
-// operands 1455.
-template <bool CF>   // scalar pivots, CF: c first
-__device__ __forceinline__ void pair_step_diag(double pf, double b, double ps, double thr, double yf, double ys,
-                                               PairPivot& P, double& lf, double& ls, int& nper) {
-  const double r1 = fast_rcp(pf);
-  const double g = b * r1;
-  double d2 = fma(-g, b, ps);
-  if (__builtin_expect(!(fabs(d2) >= thr), 0)) {             // the second scalar pivot vanishes: d2 := +-thr
-    d2 = (d2 < 0.0) ? -thr : thr;
-    nper += 1;
-  }
-  const double r2 = fast_rcp(d2);
-  ls = fma(-yf, g, ys) * r2;
-  lf = fma(-ls, g, yf * r1);
-  const double eff = fma(g * g, r2, r1);
-  P.mode = CF ? 2 : 1;
-  P.k0 = g;
-  P.k1 = r1;
-  P.k2 = r2;
-  P.e11 = CF ? r2 : eff;
-  P.e22 = CF ? eff : r2;
-  P.e12 = -g * r2;
-}
-
-__device__ __forceinline__ void pair_step(double a, double b, double c, double thr, double y0, double y1, PairPivot& P,
-                                          double& l1, double& l2, int& nper) {
-  constexpr double ALPHA = 0.6403882032022076;
-  const double fa = fabs(a), fb = fabs(b), fc = fabs(c);
-  const double pmax = fmax(fa, fc);
-  if (__builtin_expect(!(fmax(pmax, fb) >= thr), 0)) {       // the pair vanishes altogether (also NaN): E := thr I
-    const double it = 1.0 / thr;
-    P.mode = 0;
-    P.k0 = P.k2 = P.e11 = P.e22 = it;
-    P.k1 = P.e12 = 0.0;
-    l1 = y0 * it;
-    l2 = y1 * it;
-    nper += 2;
-  } else if (pmax >= ALPHA * fb) {
-    if (fc > fa) {
-      pair_step_diag<true>(c, b, a, thr, y1, y0, P, l2, l1, nper);
-      asm volatile("" ::: "memory");                         // (keeps the two arms apart: no if-conversion into selects)
-    } else {
-      pair_step_diag<false>(a, b, c, thr, y0, y1, P, l1, l2, nper);
-      asm volatile("" ::: "memory");
+// One pivot pair E = [[a, b], [b, c]] (the same bits in every thread: all operands come from LDS broadcasts) and what
+// this thread's row i does with it.  On entry y0, y1 = a[i][2q], a[i][2q+1] (zero for rows that are done), ra / rb = this
+// thread's four entries of rows 2q / 2q+1 as staged.  The three cases are wave-uniform branches, not selects: a step of
+// the pivot block costs what its waves issue (one wave per SIMD: ~5 clocks per instruction, 16 for v_rcp_f64) and a
+// compare -> select pair on the path costs 56 clocks against 7 for a dependent v_fma_f64 (scripts/micro/f64_latency.hip).
+// Vanishing pivots -- below thr = 1e-13 of the largest entry the pair's two rows had in the pivot block when the block
+// step began -- are perturbed statically (+-thr) and counted.
+//   dd, od: this pair's D^-1 (diagonal entry of row 2q + `second`, off-diagonal entry), for the panel and the sweeps.
+__device__ __forceinline__ void pair_step(double a, double b, double c, double thr, bool past_first, bool past_second,
+                                          double y0, double y1, const double (&ra)[4], const double (&rb)[4],
+                                          double (&v)[4], double& d0, double& d1, double& od, int& nper) {
+  const double p = b * b;
+  const double det = fma(a, c, -p) - fma(b, b, -p);          // Kahan: ac - b^2 to two roundings
+  const double s = fmax(fmax(fabs(a), fabs(c)), fabs(b));
+  if (p * fabs(det) <= (a * a) * (s * s)) {
+    // scalar pivots a, then d2 = c - g b with g = b / a: two eliminations in the arithmetic of the sequential LDL^T
+    // (row 2q+1 itself takes part in the first one: its x part becomes row 2q+1 of L^-1, entry 2q = -g)
+    if (__builtin_expect(!(fabs(a) >= thr), 0)) {
+      a = (a < 0.0) ? -thr : thr;
+      nper += 1;
     }
+    const double r1 = fast_rcp(a);
+    const double g = b * r1;
+    double d2 = fma(-g, b, c);
+    if (__builtin_expect(!(fabs(d2) >= thr), 0)) {
+      d2 = (d2 < 0.0) ? -thr : thr;
+      nper += 1;
+    }
+    const double r2 = fast_rcp(d2);
+    const double l0 = past_first ? y0 * r1 : 0.0;
+    const double l1 = past_second ? fma(-l0, b, y1) * r2 : 0.0;
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc) v[cc] = fma(-l1, fma(-g, ra[cc], rb[cc]), fma(-l0, ra[cc], v[cc]));
+    d0 = r1;
+    d1 = r2;
+    od = 0.0;
+    asm volatile("" ::: "memory");                          // (keeps the arms apart: no if-conversion into selects)
   } else {
-    const double p = b * b;
-    const double rd = fast_rcp(fma(a, c, -p) - fma(b, b, -p));   // Kahan: ac - b^2 to two roundings
+    // 2 x 2 pivot: |det| is a sizeable part of max|E|^2 here, the explicit inverse is benign
+    const double rd = fast_rcp(det);
     const double x11 = c * rd, x12 = -b * rd, x22 = a * rd;
-    l1 = fma(y0, x11, y1 * x12);
-    l2 = fma(y0, x12, y1 * x22);
-    P.mode = 0;
-    P.k0 = P.e11 = x11;
-    P.k1 = P.e12 = x12;
-    P.k2 = P.e22 = x22;
+    const double l0 = past_second ? fma(y0, x11, y1 * x12) : 0.0;
+    const double l1 = past_second ? fma(y0, x12, y1 * x22) : 0.0;
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc) v[cc] = fma(-l1, rb[cc], fma(-l0, ra[cc], v[cc]));
+    d0 = x11;
+    d1 = x22;
+    od = x12;
     asm volatile("" ::: "memory");
   }
 }
@@ -275,19 +229,17 @@ __device__ __forceinline__ void pair_step(double a, double b, double c, double t
 // workgroup barrier per step): rows 2q, 2q+1 (their x part, c <= 2q+1, is what gets read) and the RAW columns a[c][2q],
 // a[c][2q+1] from thread row c -- behind the pair a step reads those, not row 2q's own copy a[2q][c] of them: the block is
 // eliminated from its lower triangle alone, like the panel below it (the two copies of a 1e9-sized sliver entry differ by
-// their rounding, and a mix of them costs two digits of K^-1).  Every thread then works out the pivot (pair_step, the same
-// bits everywhere) and row i > 2q+1 loses l1 row(2q) + l2 row(2q+1) with (l1, l2) = (a[i][2q], a[i][2q+1]) E_q^-1.
+// their rounding, and a mix of them costs two digits of K^-1).  Every thread then works out the pivot and the update of
+// its row (pair_step, the same bits everywhere).
 // Why four waves: what a step costs is its LDS instructions (a lone wave gets a fraction of the LDS rate; measured with
 // scripts/micro/pivot_bench.hip: one wave holding 16 columns per lane spends 470 of a step's 1370 clocks issuing its 16
 // ds_read_b128 and 460 on the then serial reciprocals); four waves read 4 columns each, in parallel.
 // Inputs come straight from F; results go to LDS: tile[i][c] = X[i][c] (zero above the diagonal), sDd[i] / sDo[i] =
-// diagonal / off-diagonal entry of D^-1 in row i (identity for the padding of a partial block), S.coef / S.mode.
+// diagonal / off-diagonal entry of D^-1 in row i (identity for the padding of a partial block).
 struct PivotLds {
   double row[2][2][NB];       // x part of rows 2q, 2q+1 of the pair in flight (entries c <= 2q+1 are read)
   double col[2][2][NB];       // raw columns 2q, 2q+1: a[c][2q], a[c][2q+1] for every row c (entries c >= 2q are read)
   double rmax[NB];            // largest entry of every row pair of the block on arrival
-  double coef[NB / 2][3];     // per pair: PairPivot k0, k1, k2 and mode, for the panel
-  int mode[NB / 2];
 };
 
 __device__ __forceinline__ void ldl_pivot_block(const double* __restrict__ F, int m, int k0, int nbk, int tid,
@@ -332,8 +284,8 @@ __device__ __forceinline__ void ldl_pivot_block(const double* __restrict__ F, in
     __syncthreads();
     const double a = S.col[buf][0][k], b = S.col[buf][0][k + 1], c = S.col[buf][1][k + 1];
     const double thr = fmax(1e-13 * S.rmax[k], 1e-300);
-    // this row's entries in the pair's columns (rows up to 2q+1 are done: no multipliers)
-    const double y0 = (i > k + 1) ? S.col[buf][0][i] : 0.0, y1 = (i > k + 1) ? S.col[buf][1][i] : 0.0;
+    // this row's entries in the pair's columns (rows up to 2q are done; row 2q+1 still takes part in a scalar step)
+    const double y0 = (i > k) ? S.col[buf][0][i] : 0.0, y1 = (i > k + 1) ? S.col[buf][1][i] : 0.0;
     double ra[4], rb[4];
 #pragma unroll
     for (int cc = 0; cc < 4; ++cc) {
@@ -342,27 +294,12 @@ __device__ __forceinline__ void ldl_pivot_block(const double* __restrict__ F, in
       ra[cc] = behind ? S.col[buf][0][cidx] : S.row[buf][0][cidx];
       rb[cc] = behind ? S.col[buf][1][cidx] : S.row[buf][1][cidx];
     }
-    PairPivot P;
-    double l1, l2;
-    pair_step(a, b, c, thr, y0, y1, P, l1, l2, nper);
-#pragma unroll
-    for (int cc = 0; cc < 4; ++cc) v[cc] = fma(-l1, ra[cc], fma(-l2, rb[cc], v[cc]));
+    double d0, d1, o01;
+    pair_step(a, b, c, thr, i > k, i > k + 1, y0, y1, ra, rb, v, d0, d1, o01, nper);
     if ((i | 1) == k + 1) {
-      dd = (i == k) ? P.e11 : P.e22;
-      od = P.e12;
+      dd = (i == k) ? d0 : d1;
+      od = o01;
     }
-    if (tid == 0) {
-      S.coef[q][0] = P.k0;
-      S.coef[q][1] = P.k1;
-      S.coef[q][2] = P.k2;
-      S.mode[q] = P.mode;
-    }
-  }
-  if (tid >= nbk / 2 && tid < NB / 2) {                        // identity padding of a partial block
-    S.coef[tid][0] = 1.0;
-    S.coef[tid][1] = 0.0;
-    S.coef[tid][2] = 1.0;
-    S.mode[tid] = 0;
   }
   __syncthreads();                                             // (tile was the scratch of the row maxima)
   // x[i][c] = v for c <= i, 0 above the diagonal
@@ -449,12 +386,20 @@ __global__ __launch_bounds__(256) void k_ldl_pivot_panel(int n_tb, const int32_t
   // columns of F.
   double* W = wbuf + 2 * fnode_ptr[f] * NB;
   double* Y = rbuf + 2 * fnode_ptr[f] * NB;
-  double xa0[NB / 4], xa1[NB / 4];
+  double xa0[NB / 4], xa1[NB / 4], rdd[2][4], rdo[2][4];
 #pragma unroll
   for (int kk = 0; kk < NB / 4; ++kk) {
     xa0[kk] = tile[lr][4 * kk + lk];
     xa1[kk] = tile[16 + lr][4 * kk + lk];
   }
+#pragma unroll
+  for (int tc = 0; tc < 2; ++tc)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int c = 16 * tc + lk + 4 * r;
+      rdd[tc][r] = (c < nbk) ? sDd[c] : 0.0;
+      rdo[tc][r] = (c < nbk) ? sDo[c] : 0.0;
+    }
   for (int ch = bx; t0 + ch * 64 < m; ch += n_pan) {
     const int ibase = t0 + ch * 64 + 16 * wave;
     if (ibase >= m) break;                                 // m is a multiple of 16: the wave's 16 rows are all valid
@@ -478,11 +423,7 @@ __global__ __launch_bounds__(256) void k_ldl_pivot_panel(int n_tb, const int32_t
       for (int r = 0; r < 4; ++r) {
         const int c = 16 * tc + lk + 4 * r;
         const double y = tc == 0 ? y0[r] : y1[r];
-        const double yp = lane_xor16(y, lk & 1);             // the pair's other column
-        const int q = c >> 1;
-        double wa, wb;
-        pair_multipliers(piv.mode[q], piv.coef[q][0], piv.coef[q][1], piv.coef[q][2], (c & 1) ? yp : y, (c & 1) ? y : yp, wa, wb);
-        const double w = (c & 1) ? wb : wa;
+        const double w = fma(y, rdd[tc][r], lane_xor16(y, lk & 1) * rdo[tc][r]);   // (the pair's other column: lane ^ 16)
         W[(int64_t)c * m + i] = w;
         Y[(int64_t)c * m + i] = y;
         if (c < nbk) F[(int64_t)(k0 + c) * m + i] = w;

@@ -45,47 +45,50 @@ def ldl_scalar(Fm, s2, stats):
 
 
 def ldl_pairs(Fm, s2, stats):
-    """2 x 2 pivots on (2q, 2q+1): L has zeros at (2q+1, 2q), Dinv holds the inverses of the 2 x 2 blocks."""
+    """Node-pair pivots as kernels_front.hip takes them: two scalar pivots in the static order or one 2 x 2 pivot through the
+    explicit inverse, whichever amplifies rounding errors less; vanishing = below 1e-13 of the pair's own rows."""
     F = Fm.copy()
     Dinv = np.zeros((s2, 2))       # [:, 0] diagonal of D^-1, [:, 1] the off-diagonal entry of the pair
-    thr = 0.0
     for k in range(0, s2, 2):
         if k % NB == 0:
             blk = F[k:min(k + NB, s2), k:min(k + NB, s2)]
-            thr = max(1e-13 * np.abs(blk).max(), 1e-300)
-        if k % NB == 0:
             rowmax = np.abs(blk).max(axis=1)
+            bmax = np.abs(blk).max()
         a, b, c = F[k, k], F[k + 1, k], F[k + 1, k + 1]
-        if ROW_THR:
-            thr = max(1e-13 * max(rowmax[k % NB], rowmax[k % NB + 1]), 1e-300)
+        thr = max(1e-13 * (max(rowmax[k % NB], rowmax[k % NB + 1]) if ROW_THR else bmax), 1e-300)
         det = a * c - b * b
         s = max(abs(a), abs(b), abs(c))
-        lam_min = abs(det) / max(s, 1e-300)
-        stats["rel"].append(lam_min / (thr * 1e13))
-        if s < thr or abs(det) < thr * s:
-            print(f"    pair {k} of s2 {s2} (m {F.shape[0]}): a b c = {a:.3e} {b:.3e} {c:.3e} det {det:.3e} thr {thr:.3e}; assembled diagonal "
-                  f"{Fm[k, k]:.3e} {Fm[k + 1, k + 1]:.3e}; largest entry of the two rows now {np.abs(F[k:k + 2, k:]).max():.3e}, "
-                  f"assembled {np.abs(Fm[k:k + 2, :]).max():.3e}", flush=True)
-        if s < thr:
-            e11, e12, e22 = 1.0 / thr, 0.0, 1.0 / thr
-            stats["perturbed"] += 2
-        elif abs(det) < thr * s:
-            tr = a + c
-            lamp = thr if det * tr >= 0 else -thr
-            e11 = a / tr ** 2 + c / (tr * lamp)
-            e12 = b / tr ** 2 - b / (tr * lamp)
-            e22 = c / tr ** 2 + a / (tr * lamp)
-            stats["perturbed"] += 1
+        if b * b * abs(det) <= a * a * s * s:
+            stats["modes"][1] += 1
+            for j in (k, k + 1):
+                d = F[j, j]
+                stats["rel"].append(abs(d) / (thr * 1e13))
+                if not abs(d) >= thr:
+                    d = -thr if d < 0 else thr
+                    stats["perturbed"] += 1
+                l = F[j + 1:, j] / d
+                gr = float(np.abs(l[(k + 1 - j):]).max()) if len(l) > k + 1 - j else 0.0      # (not the in-pair multiplier)
+                if gr > stats["growth"]:
+                    stats["growth"] = gr
+                    stats["where"] = (k, s2, F.shape[0], a, b, c)
+                F[j + 1:, j + 1:] -= np.outer(l, F[j + 1:, j])
+                F[j + 1:, j] = l
+                Dinv[j] = (1.0 / d, 0.0)
         else:
+            stats["modes"][0] += 1
+            stats["rel"].append(abs(det) / s / (thr * 1e13))
             e11, e12, e22 = c / det, -b / det, a / det
-        Dinv[k] = (e11, e12)
-        Dinv[k + 1] = (e22, e12)
-        C = F[k + 2:, k:k + 2].copy()
-        Lc = np.stack([C[:, 0] * e11 + C[:, 1] * e12, C[:, 0] * e12 + C[:, 1] * e22], 1)
-        stats["growth"] = max(stats["growth"], float(np.abs(Lc).max()) if len(Lc) else 0.0)
-        F[k + 2:, k + 2:] -= Lc @ C.T
-        F[k + 2:, k:k + 2] = Lc
-        F[k + 1, k] = 0.0
+            Dinv[k] = (e11, e12)
+            Dinv[k + 1] = (e22, e12)
+            C = F[k + 2:, k:k + 2].copy()
+            Lc = np.stack([C[:, 0] * e11 + C[:, 1] * e12, C[:, 0] * e12 + C[:, 1] * e22], 1)
+            gr = float(np.abs(Lc).max()) if len(Lc) else 0.0
+            if gr > stats["growth"]:
+                stats["growth"] = gr
+                stats["where"] = (k, s2, F.shape[0], a, b, c)
+            F[k + 2:, k + 2:] -= Lc @ C.T
+            F[k + 2:, k:k + 2] = Lc
+            F[k + 1, k] = 0.0
     return F, Dinv
 
 
@@ -177,14 +180,15 @@ def main():
     xs = spla.splu(K).solve(rhs[ii])
     print("splu residual", np.linalg.norm(K @ xs - rhs[ii]) / np.linalg.norm(rhs[ii]), flush=True)
     for mode in sys.argv[3:] or ("scalar", "pairs"):
-        stats = {"perturbed": 0, "rel": [], "growth": 0.0}
+        stats = {"perturbed": 0, "rel": [], "growth": 0.0, "modes": [0, 0, 0, 0], "where": None}
         t0 = time.time()
         Fs, Ds = factor(T, Ke, mode, stats)
         x = solve(T, Fs, Ds, rhs, mode)
         rel = np.sort(np.array(stats["rel"]))
         print(f"{mode:6s}: perturbed {stats['perturbed']}  smallest pivots / block max {rel[:4]}  largest multiplier "
               f"{stats['growth']:.3e}  vs splu {np.linalg.norm(x[ii] - xs) / np.linalg.norm(xs):.3e}  residual "
-              f"{np.linalg.norm(K @ x[ii] - rhs[ii]) / np.linalg.norm(rhs[ii]):.3e}  ({time.time() - t0:.0f} s)", flush=True)
+              f"{np.linalg.norm(K @ x[ii] - rhs[ii]) / np.linalg.norm(rhs[ii]):.3e}  ({time.time() - t0:.0f} s)  pairs by mode "
+              f"[2 x 2, scalar order, -, -] {stats['modes']}  largest multiplier at (pair, s2, m, a, b, c) {stats['where']}", flush=True)
 
 
 if __name__ == "__main__":

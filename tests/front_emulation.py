@@ -82,22 +82,32 @@ def assemble_front(T: FrontTree, f, Ke, S):
 
 
 def ldl_partial(Fm, s2):
-    """Partial block LDL^T of the first s2 pivots with 2 x 2 node-pair pivots in the static order (local DOFs 2q, 2q+1
-    together, no permutation; kernels_front.hip).  Returns the storage the HIP path leaves in F: lower(F11) = L11^-1,
+    """Partial block LDL^T of the first s2 pivots, node pair by node pair in the static order (local DOFs 2q, 2q+1, no
+    permutation; kernels_front.hip): two scalar pivots (a, then c - b^2 / a) or one 2 x 2 pivot, whichever amplifies rounding
+    errors less ((b / a)^2 against max|E|^2 / |det|).  Returns the storage the HIP path leaves in F: lower(F11) = L11^-1,
     upper(F11) = L11^-T, F21 = Z = L21 L11^-1, F12 = Z^T, F22 = S; and D^-1 as (diagonal, off-diagonal) per row."""
     F = Fm.copy()
     Dinv = np.zeros((s2, 2))
     for k in range(0, s2, 2):
         a, b, c = F[k, k], F[k + 1, k], F[k + 1, k + 1]
         det = a * c - b * b
-        e11, e12, e22 = c / det, -b / det, a / det
-        Dinv[k] = (e11, e12)
-        Dinv[k + 1] = (e22, e12)
-        C = F[k + 2:, k:k + 2].copy()
-        Lc = np.stack([C[:, 0] * e11 + C[:, 1] * e12, C[:, 0] * e12 + C[:, 1] * e22], 1)
-        F[k + 2:, k + 2:] -= Lc @ C.T
-        F[k + 2:, k:k + 2] = Lc
-        F[k + 1, k] = 0.0
+        s = max(abs(a), abs(b), abs(c))
+        if b * b * abs(det) <= a * a * s * s:
+            for j in (k, k + 1):                             # two steps of the scalar LDL^T
+                d = F[j, j]
+                l = F[j + 1:, j] / d
+                F[j + 1:, j + 1:] -= np.outer(l, F[j + 1:, j])
+                F[j + 1:, j] = l
+                Dinv[j] = (1.0 / d, 0.0)
+        else:
+            e11, e12, e22 = c / det, -b / det, a / det
+            Dinv[k] = (e11, e12)
+            Dinv[k + 1] = (e22, e12)
+            C = F[k + 2:, k:k + 2].copy()
+            Lc = np.stack([C[:, 0] * e11 + C[:, 1] * e12, C[:, 0] * e12 + C[:, 1] * e22], 1)
+            F[k + 2:, k + 2:] -= Lc @ C.T
+            F[k + 2:, k:k + 2] = Lc
+            F[k + 1, k] = 0.0
     L11 = np.tril(F[:s2, :s2], -1) + np.eye(s2)
     X = sla.solve_triangular(L11, np.eye(s2), lower=True, unit_diagonal=True) if s2 else np.zeros((0, 0))
     out = F.copy()

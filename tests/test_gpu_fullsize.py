@@ -94,14 +94,13 @@ def test_c4_full_multiband_sweep_on_one_gpu(gpu_device, built_library):
         solver.clear_cache()
 
 
-def test_guard_repairs_the_sweep_items_with_perturbed_pivots(gpu_device, built_library):
-    """Three cross-sections of the 64-item sweep meet a vanishing pivot pair in the static LDL^T order (DESIGN.md section
-    5: element growth ~1e9, first-pass eigen-residual 2e-7 .. 2e-6).  Whatever the tree does to them in the future:
-    the modes a caller gets must satisfy the a-posteriori bound, and when the first pass did not, the refined re-run
-    must have brought the residual down by orders of magnitude (not merely under the bar)."""
+def test_sweep_items_that_needed_the_guard_in_round_2_factor_cleanly(gpu_device, built_library):
+    """Three cross-sections of the 64-item sweep met a "vanishing" pivot pair in round 2 (perturbed pivots, first-pass
+    eigen-residual 2e-7 .. 2e-6, a second eigen-solve with refinement): a healthy pivot of 2e-4 that shared its 32 x 32
+    block with the 1e9-sized entries of a sliver element and was judged against the block's largest entry.  With the
+    node-pair pivots and the row-relative threshold they factor like every other item."""
     from pl_fem_vectoriel_amd.sweep import multiband_sweep_items
     items = multiband_sweep_items()
-    tripped = 0
     for idx in (13, 31, 41):
         it = items[idx]
         g = it.geometry()
@@ -110,11 +109,6 @@ def test_guard_repairs_the_sweep_items_with_perturbed_pivots(gpu_device, built_l
         modes = solver.solve_vectorial_modes(mesh, it.n_modes)
         st = solver.last_stats
         assert 0 < len(modes) <= 22
-        assert st["true_residual"] <= solver.RESIDUAL_TOL
-        if st["refined"]:
-            tripped += 1
-            assert st["true_residual"] < 1e-2 * st["true_residual_first"], (idx, st["true_residual_first"], st["true_residual"])
-        else:
-            assert st["pivot_perturbations"] == 0
+        assert st["pivot_perturbations"] == 0 and st["refined"] is False, (idx, st["pivot_perturbations"], st["true_residual_first"])
+        assert st["true_residual"] < 1e-8, (idx, st["true_residual"])
         solver.clear_cache()
-    print(f"guard tripped on {tripped} of 3 items")
