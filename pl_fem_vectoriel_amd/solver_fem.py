@@ -319,7 +319,9 @@ class TrueVectorialMaxwellSolver:
                 "P_x": P_x, "P_y": P_y, "PDL_dB": PDL, "polarization": _classify(P_x / P_y),
                 "confinement": conf_raw, "core_overlap": conf_raw, "div_ratio": div_ratio,
                 "is_vectorial": True, "method": "H-field_V18.10"}))
+        # beta_sq: the n_req eigenvalues as the eigen-solver returned them (ascending), before the reference's filters
         self.last_stats = dict(st, sigma=sigma, n_req=n_req, ncv=ncv, N=sym.N, N_solve=N_solve, n=2 * N_solve,
+                               beta_sq=np.array(evals, dtype=np.float64),
                                t_symbolic=ent.get("t_symbolic", 0.0), t_context=ent.get("t_context", 0.0),
                                t_workspace=ent.get("t_workspace", 0.0),
                                t_device=t1 - t0, t_copy_out=t2 - t1, frac_core=frac_core, **timings)

@@ -54,6 +54,37 @@ def _eigen_properties(g, mesh, n_modes, device, expect_N, max_front_bound, mem_b
     return evals, st, sym
 
 
+def test_c1_cold_solve_matches_the_oracle(c1_geometry, gpu_device, built_library):
+    """BASELINE configs[1] at full size against the oracle itself: one cold
+    ``solve_vectorial_modes`` on C1 (N = 90 639, n = 180 742, k = 22) vs ``oracle.hfield.solve_vectorial_modes`` on the
+    same (p, t) -- all 22 records, north_star's bars |dn_eff| < 5e-5 and field L2 < 1e-6 (sign-invariant; subspace
+    distance inside clusters), the per-mode scalars on modes whose n_eff is isolated."""
+    from oracle import hfield
+    from oracle.compare import mode_field_errors
+    from oracle.p2 import MeshTriLite
+    g = c1_geometry
+    mesh = generate_mesh(g, 1.0, 1)
+    solver = TrueVectorialMaxwellSolver(g, device=gpu_device, reuse_symbolic=False)
+    modes = solver.solve_vectorial_modes(mesh, n_modes_target=10)
+    st = solver.last_stats
+    assert st["N"] == 90639 and st["n"] == 180742 and st["n_req"] == 22 and st["nconv"] == 22
+    assert st["pivot_perturbations"] == 0 and st["refined"] is False and st["true_residual"] < 1e-8
+    ref = hfield.solve_vectorial_modes(g, MeshTriLite(mesh.p, mesh.t), n_modes_target=10, fused=True)
+    assert len(modes) == len(ref) == 22
+    ne = np.array([m["n_eff"] for m in ref])
+    assert max(abs(a["n_eff"] - b["n_eff"]) for a, b in zip(modes, ref)) < 5e-5
+    assert max(abs(a["n_eff"] - b["n_eff"]) for a, b in zip(modes, ref)) < 1e-10          # (what is actually reached)
+    assert mode_field_errors(modes, ref).max() < 1e-6
+    gap = np.minimum(np.abs(np.diff(ne, prepend=np.inf)), np.abs(np.diff(ne, append=-np.inf)))
+    isolated = gap > 1e-6 * ne
+    assert isolated.sum() >= 6
+    for a, b, iso in zip(modes, ref, isolated):
+        assert set(a) == set(b) and a["polarization"] == b["polarization"] or not iso
+        if iso:                                           # inside a cluster only the subspace is determined
+            for key in ("P_x", "P_y", "confinement", "core_overlap", "div_ratio", "PDL_dB"):
+                assert abs(a[key] - b[key]) <= 1e-5 * max(1.0, abs(b[key])), (key, a[key], b[key])
+
+
 def test_ladder_rung_l2_full_size(c1_geometry, gpu_device, built_library):
     """BASELINE configs[2], finest rung: 7-core, 2 uniform refinements, N = 362 285, n = 723 498."""
     mesh = generate_mesh(c1_geometry, 1.0, 2)

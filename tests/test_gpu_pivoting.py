@@ -1,0 +1,70 @@
+"""Pivoting of the block LDL^T: the reference factorises A - sigma B with SuperLU's partial pivoting
+(solver_fem.py:197 -> scipy arpack.py:915) and returns modes for every mesh; this path pivots node pair by node pair in
+a static order (scalar or 2 x 2 pivots, kernels_front.hip) and must do the same without its a-posteriori guard stepping
+in.  104 random coarse cross-sections -- every layout of geometry_unified.py:98-184, pitch 6-10 um, wavelength
+1.45-1.65 um, mesh recipe refinement 0.3-0.6 (the recipe's hull slivers included) -- each solved cold and compared with
+the oracle: no perturbed pivot, no refined re-run, first-pass eigen-residual below 1e-8, n_eff equal to the oracle's."""
+import numpy as np
+import pytest
+
+from oracle import hfield
+from oracle.p2 import MeshTriLite
+from pl_fem_vectoriel_amd import MCFGeometry
+from pl_fem_vectoriel_amd.geometry import ARRANGEMENTS
+from pl_fem_vectoriel_amd.mesh import generate_mesh
+from pl_fem_vectoriel_amd.solver_fem import TrueVectorialMaxwellSolver
+
+pytestmark = pytest.mark.gpu
+
+N_CASES = 104
+
+
+def random_cross_sections(n=N_CASES, seed=20261004):
+    rng = np.random.default_rng(seed)
+    names = sorted(a for a in ARRANGEMENTS if a != "single_1")
+    for t in range(n):
+        arr = names[int(rng.integers(len(names)))]
+        yield t, arr, float(rng.uniform(6.0, 10.0)), float(rng.uniform(1.45, 1.65)), float(rng.uniform(0.3, 0.6))
+
+
+@pytest.mark.parametrize("chunk", range(4))          # (26 cases each: a test that stays silent for minutes looks hung)
+def test_random_coarse_cross_sections_factor_cleanly_and_match_the_oracle(chunk, gpu_device, built_library):
+    from scipy.sparse.linalg import eigsh
+    worst_dn, worst_res = 0.0, 0.0
+    for t, arr, pitch, lam, refinement in list(random_cross_sections())[chunk::4]:
+        n, variant = ARRANGEMENTS[arr]
+        g = MCFGeometry(n, pitch, 1.5, 1.535, 1.0, wavelength_um=lam, variant=variant)
+        mesh = generate_mesh(g, refinement, 0)
+        solver = TrueVectorialMaxwellSolver(g, device=gpu_device)
+        modes = solver.solve_vectorial_modes(mesh, 6)
+        st = solver.last_stats
+        case = (t, arr, round(pitch, 3), round(lam, 4), round(refinement, 3))
+        assert st["pivot_perturbations"] == 0 and st["refined"] is False, (case, st["pivot_perturbations"], st["true_residual_first"])
+        assert st["true_residual"] < 1e-8, (case, st["true_residual"])
+        ref, raw = hfield.solve_vectorial_modes(g, MeshTriLite(mesh.p, mesh.t), n_modes_target=6, fused=True, return_raw=True)
+        # the n_req = 18 eigenvalues nearest sigma themselves (before the reference's filters: for an exactly degenerate
+        # pair the div_ratio of a member depends on the basis eigsh happens to return inside the pair, so a pair that
+        # straddles the filter's threshold is filtered differently by ANY two runs, the reference's own included)
+        got = np.sort(np.sqrt(st["beta_sq"])) / g.k0
+        want = np.sort(np.sqrt(raw["beta_sq"])) / g.k0
+        wide = raw["beta_sq"]
+        if np.abs(got - want).max() >= 1e-9:
+            # The comparison is with what eigsh's contract promises -- the 18 eigenvalues nearest sigma -- taken from a
+            # wider and tighter run (k = 26, tol 1e-10): with the reference's own arguments (k = 18, tol 1e-7) ARPACK's
+            # single-vector recurrence now and then returns only ONE copy of an exactly degenerate pair at the far edge of
+            # the wanted set and the next eigenvalue in its place (case 38 of this list: pair at sigma - 0.36247, eigsh
+            # returns one copy and sigma - 0.36298); the block recurrence of the HIP path finds both copies.
+            wide = eigsh(raw["A_int"], k=26, M=raw["B_int"], sigma=raw["sigma"], which="LM", tol=1e-10, maxiter=12000,
+                         return_eigenvectors=False)
+            wide = wide[np.argsort(np.abs(wide - raw["sigma"]))][:18]
+            want = np.sort(np.sqrt(wide)) / g.k0
+        assert len(got) == len(want) == 18
+        dn = float(np.abs(got - want).max())
+        assert dn < 1e-9, (case, dn)                      # (north_star's bar is 5e-5)
+        assert 0 < len(modes) <= 18 and abs(len(modes) - len(ref)) <= 2, (case, len(modes), len(ref))
+        same_set = np.abs(np.sort(raw["beta_sq"]) - np.sort(wide)).max() < 1e-9 * raw["sigma"]
+        if len(modes) == len(ref) == 18 and same_set:     # nothing filtered on either side: the records line up
+            assert max(abs(a["n_eff"] - b["n_eff"]) for a, b in zip(modes, ref)) < 1e-9, case
+        worst_dn, worst_res = max(worst_dn, dn), max(worst_res, st["true_residual"])
+        solver.clear_cache()
+    print(f"chunk {chunk}: max |dn_eff| {worst_dn:.2e}, max first-pass residual {worst_res:.2e}")
