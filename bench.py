@@ -34,6 +34,8 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# the library no longer re-tunes the host allocator on its own: this application opts in
+os.environ.setdefault("PLFEM_MALLOC_TUNE", "1")
 
 N_MODES = 10
 SWEEP_LANES = 4      # --sweep: solves in flight per GPU unless --lanes says otherwise (1-GPU sweep: 1.42 s with 1, 0.89 s with 4)
@@ -60,14 +62,29 @@ def parse_args(argv=None):
 # ----------------------------------------------------------------------------------------------------
 def launch_ranks(args, argv) -> int:
     """Start ``args.gpus`` ranks of this script as fresh child processes (the parent has not imported torch or
-    touched the GPU, and never re-executes itself), wait for them, relay rank 0's output.  Returns the exit code."""
+    touched the GPU, and never re-executes itself), wait for them, relay rank 0's output.  Returns the exit code.
+    A rendezvous port found free here can be taken by somebody else before rank 0 listens on it: when a rank dies
+    within the first seconds the launch is repeated once on a fresh port.  ``PLFEM_BENCH_TIMEOUT`` (seconds, default
+    3600) bounds the whole launch: ranks still running then are stopped and the exit code is non-zero."""
+    limit = float(os.environ.get("PLFEM_BENCH_TIMEOUT", "3600"))
+    for attempt in range(2):
+        rc, early = _launch_once(args, argv, limit)
+        if rc == 0 or not early or attempt == 1:
+            return rc
+        sys.stderr.write("bench.py: a rank failed during start-up, retrying once on a new rendezvous port\n")
+    return rc
+
+
+def _launch_once(args, argv, limit: float):
     import socket
+    import threading
 
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     procs = []
+    t_start = time.time()
     for r in range(args.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
                    MASTER_ADDR="127.0.0.1",
@@ -77,11 +94,24 @@ def launch_ranks(args, argv) -> int:
     # rank 0's stdout is small (a few JSON lines): read it to the end first, then reap; if any rank dies early the
     # others would wait in a collective forever, so poll and stop the exact children that were started here
     failed = None
+    timed_out = False
     pending = set(range(args.gpus))
-    import threading
     chunks = []
     reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
     reader.start()
+
+    def stop_pending():
+        for r in sorted(pending):
+            if procs[r].poll() is None:
+                procs[r].terminate()
+        for r in sorted(pending):
+            try:
+                procs[r].wait(timeout=30)
+            except subprocess.TimeoutExpired:
+                procs[r].kill()
+        pending.clear()
+
+    t_fail = None
     while pending:
         for r in sorted(pending):
             rc = procs[r].poll()
@@ -90,110 +120,151 @@ def launch_ranks(args, argv) -> int:
             pending.discard(r)
             if rc != 0 and failed is None:
                 failed = (r, rc)
+                t_fail = time.time() - t_start
         if failed is not None and pending:
             time.sleep(5.0)                                    # let the others fail on their own (collective error) first
-            for r in sorted(pending):
-                if procs[r].poll() is None:
-                    procs[r].terminate()
-            for r in sorted(pending):
-                try:
-                    procs[r].wait(timeout=30)
-                except subprocess.TimeoutExpired:
-                    procs[r].kill()
-            pending.clear()
+            stop_pending()
+        elif pending and time.time() - t_start > limit:
+            timed_out = True
+            stop_pending()
         time.sleep(0.05)
     reader.join(timeout=10)
     text = (chunks[0] if chunks else b"").decode()
-    sys.stdout.write(text)
-    sys.stdout.flush()
-    if failed is not None:
-        sys.stderr.write(f"bench.py: rank {failed[0]} exited with code {failed[1]}\n")
-        return 1
-    return 0
+    if failed is None and not timed_out:
+        sys.stdout.write(text)
+        sys.stdout.flush()
+        return 0, False
+    if timed_out:
+        sys.stderr.write(f"bench.py: ranks still running after PLFEM_BENCH_TIMEOUT = {limit:.0f} s were stopped\n")
+        return 1, False
+    sys.stderr.write(f"bench.py: rank {failed[0]} exited with code {failed[1]}\n")
+    return 1, (t_fail is not None and t_fail < 20.0 and not text.strip())
 
 
 # ----------------------------------------------------------------------------------------------------
 # CPU baseline (rank 0, N = 1 only)
 # ----------------------------------------------------------------------------------------------------
-def cpu_baseline(geom, mesh, gpu_modes):
-    """Oracle (CPU port of the reference algorithm in scikit-fem's loop shape + SciPy eigsh with the
-    reference's arguments) timed once on the same workload; also yields the parity numbers."""
-    import numpy as np
+def cpu_baseline(geom, mesh):
+    """Oracle (CPU port of the reference algorithm in scikit-fem's loop shape + SciPy eigsh with the reference's
+    arguments) timed on the same workload, BEFORE the GPU steps (the driver samples GPU activity every few seconds: with
+    the CPU leg last, every sample of a 12-s run fell into it).  Two samples: BLAS limited to 4 threads (the reference
+    sets OMP/MKL_NUM_THREADS=4, main.py:19-20) and all host cores (SURVEY.md section 8d asks for both; assembly and
+    SuperLU are single-threaded, so they differ little).  Returns (cpu_baseline object, reference modes)."""
     from oracle import hfield
     from oracle.p2 import MeshTriLite
-    from oracle.compare import mode_field_errors
 
-    threads = int(os.environ.get("PLFEM_CPU_THREADS", "4"))         # the reference sets OMP/MKL_NUM_THREADS=4 (main.py:19-20)
-    try:
-        from threadpoolctl import threadpool_limits
-        limiter = threadpool_limits(limits=threads)
-    except Exception:                                                 # pragma: no cover
+    def one(threads):
         limiter = None
-    tm = {}
-    t0 = time.perf_counter()
-    ref = hfield.solve_vectorial_modes(geom, MeshTriLite(mesh.p, mesh.t), N_MODES, fused=False, timings=tm)
-    dt = time.perf_counter() - t0
-    if limiter is not None:
-        limiter.restore_original_limits()
-    dn = max(abs(a["n_eff"] - b["n_eff"]) for a, b in zip(gpu_modes, ref)) if len(ref) == len(gpu_modes) else float("nan")
-    worst = float(np.max(mode_field_errors(gpu_modes, ref))) if len(ref) == len(gpu_modes) else float("nan")
+        if threads is not None:
+            try:
+                from threadpoolctl import threadpool_limits
+                limiter = threadpool_limits(limits=threads)
+            except Exception:                                         # pragma: no cover
+                limiter = None
+        tm = {}
+        t0 = time.perf_counter()
+        ref = hfield.solve_vectorial_modes(geom, MeshTriLite(mesh.p, mesh.t), N_MODES, fused=False, timings=tm)
+        dt = time.perf_counter() - t0
+        if limiter is not None:
+            limiter.restore_original_limits()
+        return ref, dt, tm
+
+    threads = int(os.environ.get("PLFEM_CPU_THREADS", "4"))
+    ref, dt, tm = one(threads)
+    _ref2, dt_all, tm_all = one(None)
     base = {"value": N_MODES / dt, "unit": "modes/s", "cores": threads, "kind": "port",
             "sample": f"1 full solve of the same workload ({dt:.1f} s: assembly {tm['assembly']:.1f} s, "
                       f"eigsh {tm['eigsh']:.1f} s; assembly and SuperLU are single-threaded, BLAS limited to {threads} threads; "
-                      f"host has {os.cpu_count()} logical CPUs)"}
-    parity = {"max_abs_dn_eff": dn, "max_field_l2": worst, "n_modes_compared": len(ref),
-              "tolerance": {"dn_eff": 5e-5, "field_l2": 1e-6}}
-    return base, parity
+                      f"host has {os.cpu_count()} logical CPUs)",
+            "all_cores": {"value": N_MODES / dt_all, "unit": "modes/s", "cores": os.cpu_count(),
+                          "sample": f"the same solve with BLAS unrestricted ({dt_all:.1f} s: assembly {tm_all['assembly']:.1f} s, "
+                                    f"eigsh {tm_all['eigsh']:.1f} s)"}}
+    return base, ref
+
+
+def parity_block(gpu_modes, ref):
+    import numpy as np
+    from oracle.compare import mode_field_errors
+    same = len(ref) == len(gpu_modes)
+    dn = max(abs(a["n_eff"] - b["n_eff"]) for a, b in zip(gpu_modes, ref)) if same else float("nan")
+    worst = float(np.max(mode_field_errors(gpu_modes, ref))) if same else float("nan")
+    return {"max_abs_dn_eff": dn, "max_field_l2": worst, "n_modes_compared": len(ref),
+            "tolerance": {"dn_eff": 5e-5, "field_l2": 1e-6}}
 
 
 # ----------------------------------------------------------------------------------------------------
 # rooflines
 # ----------------------------------------------------------------------------------------------------
+PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc_families.json")
+
+
 def roofline_objects(kprof, stats, info, nv, ne):
-    """``roofline`` (dominant kernel, k_fwd) and ``roofline.kernels`` (the other kernel families of the step).
-    achieved = ALGORITHMIC bytes (or flop) / measured time; formulas in DESIGN.md section 6.
-    kprof: HIP-event ranges accumulated over the profiled step (plfem_profile_*); stats: solver.last_stats of that
-    step (assemble_us / factor_us are HIP-event times of the whole phase); info: plfem_symbolic_info."""
-    def hbm(name, bytes_, us, n, formula):
+    """``roofline`` = the dominant kernel FAMILY of the step, the forward + backward solve sweeps (47 % of the GPU time
+    of a solve; one launch per tree level and direction), and ``roofline.kernels`` = its parts and the other families.
+    achieved = ALGORITHMIC bytes (or flop) / time measured live with HIP events on the launch stream during the first
+    timed step (plfem_profile_*); formulas in DESIGN.md section 6.  ``traffic`` = HBM bytes from separate rocprofv3 --pmc
+    passes of this round (profiles/r03_pmc_families.json, scripts/gpu_profile_round.sh; 2 x FETCH_SIZE + WRITE_SIZE as
+    MI355X_MICROARCH.md prescribes for gfx950) per the same unit, ``traffic_ratio`` = traffic / algorithmic bytes."""
+    pmc = {}
+    if os.path.exists(PMC_FILE):
+        pmc = json.load(open(PMC_FILE)).get("families", {})
+
+    def traffic(family):
+        return pmc.get(family, {}).get("hbm_bytes")
+
+    def hbm(name, bytes_, us, n, formula, family=None):
         a = bytes_ / (us * 1e-6) / 1e9
+        tr = traffic(family) if family else None
         return {"kernel": name, "bound": "hbm", "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": a / HBM_PEAK_GBS,
-                "ranges_timed": n, "avg_us": us / n, "algorithmic_bytes": bytes_ / n, "formula": formula}
+                "ranges_timed": n, "avg_us": us / n, "algorithmic_bytes": bytes_ / n, "formula": formula,
+                "traffic": tr, "traffic_ratio": (tr / (bytes_ / n)) if tr else None}
 
     sl = kprof["slots"]
     kernels = []
     sweep_formula = "8 B x sum over fronts (s2 m - s2^2/2 + P (m + s2)), P = 4"
-    for key, name in (("fwd_sweep", "forward sweep (all levels: k_fwd + k_fwd_rows)"),
-                      ("bwd_sweep", "backward sweep (all levels: k_bwd + k_bwd_rows)")):
+    for key, name, fam in (("fwd_sweep", "forward sweep (all levels: k_fwd + k_fwd_mix + k_fwd_rows)", "forward sweep (k_fwd, k_fwd_mix, k_fwd_rows)"),
+                           ("bwd_sweep", "backward sweep (all levels: k_bwd + k_bwd_rows)", "backward sweep (k_bwd, k_bwd_rows)")):
         if sl[key]["ranges"] > 0:
-            kernels.append(hbm(name, sl[key]["bytes"], sl[key]["total_us"], sl[key]["ranges"], sweep_formula))
+            kernels.append(hbm(name, sl[key]["bytes"], sl[key]["total_us"], sl[key]["ranges"], sweep_formula, fam))
+    if kprof["launches"] > 0:
+        kernels.append(hbm("k_fwd<4> / k_fwd_mix<4> (tile-form forward levels, per launch)", kprof["bytes"], kprof["total_us"],
+                           kprof["launches"], "the level's share of the sweep formula", "k_fwd / k_fwd_mix (tile-form forward levels)"))
     if sl["spmv_b"]["ranges"] > 0:
         kernels.append(hbm("k_spmv_b_block<4>", sl["spmv_b"]["bytes"], sl["spmv_b"]["total_us"], sl["spmv_b"]["ranges"],
-                           "12 B x nnz + 4 B x (N + 1) + 2 x 8 B x 4 x 2N"))
+                           "12 B x nnz + 4 B x (N + 1) + 2 x 8 B x 4 x 2N", "k_spmv_b_block"))
     nnz = info["nnz"]
     asm_bytes = 24.0 * ne + 16.0 * nv + 8.0 * 5 * nnz
     if stats.get("assemble_us", 0) > 0:
         kernels.append(hbm("assembly (k_element_matrices + k_csr_gather)", asm_bytes, stats["assemble_us"], 1,
-                           "24 B x ne (t, edge dofs) + 16 B x nv (coordinates) + 8 B x 5 x nnz (Axx Axy Ayx Ayy Minv values written once)"))
+                           "24 B x ne (t, edge dofs) + 16 B x nv (coordinates) + 8 B x 5 x nnz (Axx Axy Ayx Ayy Minv values written once)",
+                           "assembly (k_element_matrices + k_csr_gather)"))
     if stats.get("factor_us", 0) > 0:
         tf = info["factor_flops"] / (stats["factor_us"] * 1e-6) / 1e12
+        mf = {}
+        if os.path.exists(PMC_FILE):
+            mf = json.load(open(PMC_FILE)).get("mfma", {}).get("factorisation (all kernels)", {})
         kernels.append({"kernel": "factorisation (block LDL^T, all kernels)", "bound": "mfma", "achieved": tf, "peak": FP64_MFMA_PEAK_TF,
                         "unit": "TFLOP/s", "frac": tf / FP64_MFMA_PEAK_TF, "ranges_timed": 1, "avg_us": stats["factor_us"],
-                        "algorithmic_flop": info["factor_flops"], "formula": "sum over fronts s2 m^2 (LDL^T + Schur complement + L11^-1 + Z)"})
+                        "algorithmic_flop": info["factor_flops"], "formula": "sum over fronts s2 m^2 (LDL^T + Schur complement + L11^-1 + Z)",
+                        "mfma_flop_counted": mf.get("mfma_flop_per_unit"), "mfma_busy_over_sq_busy": mf.get("mfma_busy_over_sq_busy"),
+                        "traffic": traffic("factorisation (all kernels)")})
     roof = None
-    if kprof["launches"] > 0:
-        achieved = kprof["bytes"] / (kprof["total_us"] * 1e-6) / 1e9
-        traffic, traffic_src = None, None
-        for tag in ("r02", "r01"):          # PMC passes run separately (scripts/gpu_profile_round.sh); newest committed file
-            pmc = os.path.join(ROOT, "profiles", f"{tag}_pmc_k_fwd.json")
-            if os.path.exists(pmc):
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
-                traffic_src = f"profiles/{tag}_pmc_k_fwd.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of that round, not this run)"
-                break
+    nf, nb = sl["fwd_sweep"]["ranges"], sl["bwd_sweep"]["ranges"]
+    if nf > 0 and nb > 0:
+        pairs = min(nf, nb)
+        bytes_pair = sl["fwd_sweep"]["bytes"] / nf + sl["bwd_sweep"]["bytes"] / nb
+        us_pair = sl["fwd_sweep"]["total_us"] / nf + sl["bwd_sweep"]["total_us"] / nb
+        achieved = bytes_pair / (us_pair * 1e-6) / 1e9
+        tf_, tb_ = traffic("forward sweep (k_fwd, k_fwd_mix, k_fwd_rows)"), traffic("backward sweep (k_bwd, k_bwd_rows)")
+        tr = (tf_ + tb_) if (tf_ and tb_) else None
+        launches_pair = 2 * (int(info.get("levels", 0)) + 1)
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic, "traffic_source": traffic_src, "kernel": "k_fwd<4> / k_fwd_mix<4> (tile-form forward sweep levels)",
-                "launches": kprof["launches"],
-                "avg_launch_us": kprof["total_us"] / kprof["launches"],
-                "algorithmic_bytes_per_launch": kprof["bytes"] / kprof["launches"],
+                "traffic": tr, "traffic_ratio": (tr / bytes_pair) if tr else None,
+                "traffic_source": "profiles/r03_pmc_families.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this round, not this run)" if tr else None,
+                "kernel": "forward + backward solve sweep of the shift-invert operator, P = 4 right-hand sides (k_fwd, k_fwd_mix, "
+                          "k_fwd_rows, k_bwd, k_bwd_rows: one launch per tree level and direction)",
+                "unit_of_work": "one sweep pair = one application of K^-1 to 4 vectors", "pairs_timed": pairs,
+                "avg_pair_us": us_pair, "algorithmic_bytes_per_pair": bytes_pair, "launches_per_pair": launches_pair,
                 "kernels": kernels}
     return roof
 
@@ -279,6 +350,9 @@ def run_solve_config(args, D: Dist, levels: int, with_cpu_baseline: bool):
 
     geom = MCFGeometry(7, 8.0, 1.5, 1.535, 1.0, wavelength_um=1.55)
     mesh = generate_mesh(geom, 1.0, levels)
+    base = ref_modes = None
+    if world == 1 and with_cpu_baseline:
+        base, ref_modes = cpu_baseline(geom, mesh)
     kprof = {"launches": 0, "total_us": 0.0, "bytes": 0.0, "slots": None}
     prof_stats = {}
 
@@ -379,10 +453,12 @@ def run_solve_config(args, D: Dist, levels: int, with_cpu_baseline: bool):
         out["concurrent"] = {"in_flight": in_flight, "value": conc, "unit": "modes/s",
                              "note": "same cold solves, several in flight on the one GPU (host thread + stream each); "
                                      "not the headline: the reference runs one solve at a time"}
-    if world == 1 and with_cpu_baseline:
-        base, parity = cpu_baseline(geom, mesh, modes)
+    if base is not None:
         out["cpu_baseline"] = base
-        out["parity"] = parity
+        out["parity"] = parity_block(modes, ref_modes)
+        # (vs_baseline stays null: BASELINE.md holds no published number for this metric; this is the ratio to the CPU
+        # port timed on this host, a reported baseline, not a target)
+        out["vs_cpu_baseline"] = {"cores_4": out["value"] / base["value"], "all_cores": out["value"] / base["all_cores"]["value"]}
     return out
 
 
@@ -409,28 +485,48 @@ def run_sweep_config(args, D: Dist):
         device = D.local_rank
     table = None
     lanes = args.lanes if args.lanes > 0 else SWEEP_LANES
+    n_local = 0
     for _ in range(args.warmup):
-        table, _n = run_sweep(items, D.rank, world, solve=solve, device=device, lanes=lanes)
+        table, n_local = run_sweep(items, D.rank, world, solve=solve, device=device, lanes=lanes)
     D.sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        table, _n = run_sweep(items, D.rank, world, solve=solve, device=device, lanes=lanes)
+        table, n_local = run_sweep(items, D.rank, world, solve=solve, device=device, lanes=lanes)
     D.sync()
     elapsed = D.max_over_ranks(time.perf_counter() - t0)
+    # the same sweep with the mesh producer INSIDE the timed region (Delaunay + refinement per cross-section, overlapped
+    # with the solves by the sweep's preparer thread): reported beside the headline, which keeps its inputs resident
+    elapsed_mesh = None
+    if not D.fake:
+        solve_m = default_solve(D.local_rank, meshes=None)
+        D.sync()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            table_m, _n = run_sweep(items, D.rank, world, solve=solve_m, device=device, lanes=lanes)
+        D.sync()
+        elapsed_mesh = D.max_over_ranks(time.perf_counter() - t1)
+        if D.rank == 0:
+            assert all(np.array_equal(table_m[i], table[i]) for i in table)
     if D.rank != 0:
         return None
     assert sorted(table) == list(range(len(items)))
-    return {"metric": METRIC, "value": args.steps * len(items) * N_MODES / elapsed, "unit": "modes/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "fake (rehearsal)" if D.fake else "synthetic",
-            "config": {"workload": "C4: 64-solve multi-band sweep = 16 cross-sections (12 multi-core layouts at pitch 8 um + 7-core at "
-                                   "pitch 6/7/9/10 um) x lambda in {1490, 1550, 1600, 1650} nm, 10 modes each, meshes as C1",
-                       "step": "one whole sweep: per mesh symbolic + context once, per wavelength assembly + factor + Lanczos + "
-                               "check + post; one all-gather of 64 fixed-size records",
-                       "parallelism": f"{world} rank(s), {len(items) // world} solves per GPU, {lanes} in flight per GPU, "
-                                      f"backend {D.backend}"},
-            "sweep": {"solves": len(items), "solves_per_s": args.steps * len(items) / elapsed,
-                      "n_eff_checksum": float(sum(float(np.sum(table[i])) for i in sorted(table)))}}
+    out = {"metric": METRIC, "value": args.steps * len(items) * N_MODES / elapsed, "unit": "modes/s", "n_gpus": world,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+           "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "fake (rehearsal)" if D.fake else "synthetic",
+           "config": {"workload": "C4: 64-solve multi-band sweep = 16 cross-sections (12 multi-core layouts at pitch 8 um + 7-core at "
+                                  "pitch 6/7/9/10 um) x lambda in {1490, 1550, 1600, 1650} nm, 10 modes each, meshes as C1",
+                      "step": "one whole sweep: per mesh symbolic once (shared by the lanes), per lane and mesh a context, per "
+                              "wavelength assembly + factor + Lanczos + check + post; one all-gather of 64 fixed-size records",
+                      "parallelism": f"{world} rank(s), {len(items) // world} solves per GPU, {lanes} in flight per GPU, "
+                                     f"backend {D.backend}"},
+           "sweep": {"solves": len(items), "solves_per_s": args.steps * len(items) / elapsed, "solves_rank0": n_local,
+                     "n_eff_checksum": float(sum(float(np.sum(table[i])) for i in sorted(table)))}}
+    if elapsed_mesh is not None:
+        out["sweep"]["with_mesh_production"] = {"ms_per_step": elapsed_mesh / args.steps * 1e3,
+                                                "value": args.steps * len(items) * N_MODES / elapsed_mesh, "unit": "modes/s",
+                                                "note": "MeshGenerator recipe (Delaunay + 1 refinement) of the 16 cross-sections inside the "
+                                                        "timed region, prepared ahead of the lanes on a host thread"}
+    return out
 
 
 def main(argv=None):

@@ -63,7 +63,7 @@ class ArpackLikeNoConvergence(_ArpackNoConvergence, RuntimeError):
 _lib = None
 
 
-def _tune_host_allocator() -> None:
+def _tune_host_allocator(_force: bool = False) -> None:
     """Keep the host analysis out of the kernel's memory-map lock.
 
     ``plfem_symbolic_create`` allocates and frees ~20 MB of index arrays per cross-section (blocks of 0.1-3 MB) from
@@ -71,9 +71,10 @@ def _tune_host_allocator() -> None:
     fault per 4 KB on first touch, all serialised on the process's memory-map lock: measured on the MI355X host, the
     analysis of C1 takes 5.5 ms that way and 4.3 ms when freed blocks stay in the heap.  So blocks below 32 MB are taken
     from the heap (``M_MMAP_THRESHOLD``) and the heap top is only returned to the system beyond 512 MB
-    (``M_TRIM_THRESHOLD``).  This is process-wide policy, set once when the library is first loaded;
-    ``PLFEM_MALLOC_TUNE=0`` leaves the allocator alone."""
-    if os.environ.get("PLFEM_MALLOC_TUNE", "1") == "0":
+    (``M_TRIM_THRESHOLD``).  This is process-wide policy and therefore OPT-IN: a drop-in library does not re-tune its
+    host's allocator on its own.  An application that wants the faster analysis sets ``PLFEM_MALLOC_TUNE=1`` before the
+    library is first loaded (``bench.py`` does) or calls this function / the two ``mallopt`` calls itself."""
+    if os.environ.get("PLFEM_MALLOC_TUNE", "0") != "1" and not _force:
         return
     try:
         libc = ctypes.CDLL("libc.so.6")

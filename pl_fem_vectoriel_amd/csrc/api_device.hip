@@ -62,22 +62,25 @@ void pinned_release(double* p, size_t bytes) {
 }  // namespace
 
 namespace {
-// Process-wide pool of timing events for plfem_profile_*: contexts come and go in a cold-solve loop, the events
-// (a few hundred, ~10 us each to create) stay.  A profiling context TAKES the pool's events at profile_begin and
-// hands them back at profile_end, both under the mutex: two contexts profiling at once (sweep lanes) never share a
-// vector -- the second one simply creates its own events.
+// Process-wide pools of timing events for plfem_profile_*, one per device ordinal (an event belongs to the device that was
+// current when it was created): contexts come and go in a cold-solve loop, the events (a few hundred, ~10 us each to
+// create) stay.  A profiling context TAKES its device's pool at profile_begin and hands the events back at profile_end
+// (on every path), both under the mutex: two contexts profiling at once (sweep lanes) never share a vector -- the second
+// one simply creates its own events.
 std::mutex& event_mutex() { static std::mutex* m = new std::mutex(); return *m; }
-std::vector<hipEvent_t>& event_pool() { static std::vector<hipEvent_t>* v = new std::vector<hipEvent_t>(); return *v; }
-void events_take(std::vector<hipEvent_t>& mine) {
+std::vector<std::vector<hipEvent_t>>& event_pools() { static auto* v = new std::vector<std::vector<hipEvent_t>>(); return *v; }
+void events_take(int device, std::vector<hipEvent_t>& mine) {
   std::lock_guard<std::mutex> lk(event_mutex());
-  auto& pool = event_pool();
-  mine.insert(mine.end(), pool.begin(), pool.end());
-  pool.clear();
+  auto& pools = event_pools();
+  if ((int)pools.size() <= device) pools.resize(device + 1);
+  mine.insert(mine.end(), pools[device].begin(), pools[device].end());
+  pools[device].clear();
 }
-void events_give(std::vector<hipEvent_t>& mine) {
+void events_give(int device, std::vector<hipEvent_t>& mine) {
   std::lock_guard<std::mutex> lk(event_mutex());
-  auto& pool = event_pool();
-  pool.insert(pool.end(), mine.begin(), mine.end());
+  auto& pools = event_pools();
+  if ((int)pools.size() <= device) pools.resize(device + 1);
+  pools[device].insert(pools[device].end(), mine.begin(), mine.end());
   mine.clear();
 }
 }  // namespace
@@ -157,7 +160,7 @@ void free_all(plfem_ctx* c) {
       if (e) (void)hipEventDestroy(e);
   for (auto& e : c->ev_step)
     if (e) (void)hipEventDestroy(e);
-  if (!c->prof_ev.empty()) events_give(c->prof_ev);
+  if (!c->prof_ev.empty()) events_give(c->device, c->prof_ev);
 }
 
 static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
@@ -563,8 +566,14 @@ extern "C" int plfem_cmt_coupling(plfem_ctx* c, int32_t n, const double* fields_
   if (n > c->max_ncv) { c->err = "plfem_cmt_coupling: more fields than the context's max_ncv"; return PLFEM_EINVAL; }
   HIP_TRY(c, hipSetDevice(c->device));
   TRY(upload_cores(c, cores_host, ncore));
+  // From here on the MINV slot holds M_deps, not the mass matrix of the eigenproblem: whatever way this function is left,
+  // the context must ask for a new assembly before the next factorisation / solve / residual check.
+  struct Invalidate {
+    plfem_ctx* c;
+    ~Invalidate() { c->assembled = false; c->factored = false; }
+  } invalidate{c};
   const double mean = plfem::launch_delta_eps_mass(c, ncore, eps_core, eps_clad);
-  c->assembled = true;                        // (plfem_spmv below reads the MINV slot)
+  c->assembled = true;                        // (launch_spmv below reads the MINV slot)
   const int64_t N = c->n2;
   const int ld = n;
   double* Hd = c->d_Hcols;                    // [n + 2][n]: columns of the raw matrix, then the two norm vectors
@@ -584,9 +593,6 @@ extern "C" int plfem_cmt_coupling(plfem_ctx* c, int32_t n, const double* fields_
     for (int i = 0; i < n; ++i) raw_host[i + (size_t)j * n] = hs[(size_t)j * ld + i];
   for (int i = 0; i < n; ++i) { pi_host[i] = hs[(size_t)n * ld + i]; pj_host[i] = hs[(size_t)(n + 1) * ld + i]; }
   if (eps_mean_host) *eps_mean_host = mean;
-  // the MINV slot no longer holds the mass matrix of the eigenproblem: a new assembly is required before the next solve
-  c->assembled = false;
-  c->factored = false;
   return PLFEM_OK;
 }
 
@@ -607,6 +613,7 @@ extern "C" int plfem_block_values_host(plfem_ctx* c, int32_t block, double* valu
 extern "C" int plfem_spmv(plfem_ctx* c, int32_t which, const double* x_dev, double* y_dev) {
   if (!c || !x_dev || !y_dev || (which != 0 && which != 1)) return PLFEM_EINVAL;
   if (!c->assembled) { c->err = "plfem_spmv before plfem_assemble_hfield"; return PLFEM_ESTATE; }
+  HIP_TRY(c, hipSetDevice(c->device));
   plfem::launch_spmv(c, which, x_dev, y_dev);
   return check_launch(c, "spmv");
 }
@@ -633,6 +640,7 @@ static void solve_refined(plfem_ctx* c, const double* b, double* y, int steps);
 extern "C" int plfem_solve(plfem_ctx* c, const double* rhs_dev, double* x_dev, int32_t refine_steps) {
   if (!c || !rhs_dev || !x_dev || refine_steps < 0) return PLFEM_EINVAL;
   if (!c->factored) { c->err = "plfem_solve before plfem_factor"; return PLFEM_ESTATE; }
+  HIP_TRY(c, hipSetDevice(c->device));
   solve_refined(c, rhs_dev, x_dev, refine_steps);
   return check_launch(c, "solve");
 }
@@ -1110,6 +1118,8 @@ extern "C" int plfem_debug_factor_until(plfem_ctx* c, double sigma, int32_t leve
 extern "C" int plfem_debug_solve_block(plfem_ctx* c, int32_t reps, int32_t filter) {
   if (!c || reps < 1) return PLFEM_EINVAL;
   if (!c->factored) { c->err = "debug solve before factor"; return PLFEM_ESTATE; }
+  if (c->max_block_p < plfem::BLOCK_P) { c->err = "plfem_debug_solve_block: the LDS budget of this context allows one right-hand side per sweep only"; return PLFEM_EINVAL; }
+  HIP_TRY(c, hipSetDevice(c->device));
   HIP_TRY(c, hipMemsetAsync(c->d_bw, 0, sizeof(double) * c->n2 * plfem::BLOCK_P, c->stream));
   c->debug_sweep_filter = filter;
   for (int r = 0; r < reps; ++r) plfem::launch_solve_block(c, c->d_bw, c->d_w, c->n2, false);
@@ -1150,7 +1160,7 @@ extern "C" int plfem_profile_begin(plfem_ctx* c, int32_t max_ranges) {
   if (!c || max_ranges < 1) return PLFEM_EINVAL;
   HIP_TRY(c, hipSetDevice(c->device));
   c->prof_max = max_ranges;                          // event pairs are created on demand at the launch site
-  if (c->prof_ev.empty()) events_take(c->prof_ev);
+  if (c->prof_ev.empty()) events_take(c->device, c->prof_ev);
   c->prof_n = 0;
   c->prof_slot.clear();
   c->prof_rbytes.clear();
@@ -1161,17 +1171,22 @@ extern "C" int plfem_profile_begin(plfem_ctx* c, int32_t max_ranges) {
 extern "C" int plfem_profile_end(plfem_ctx* c, double* out_host) {
   if (!c || !out_host) return PLFEM_EINVAL;
   c->prof_on = false;
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
   for (int q = 0; q < 3 * PLFEM_PROF_COUNT; ++q) out_host[q] = 0.0;
-  for (int q = 0; q < c->prof_n; ++q) {
+  hipError_t e = hipSetDevice(c->device);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  for (int q = 0; q < c->prof_n && e == hipSuccess; ++q) {
     float ms = 0;
-    HIP_TRY(c, hipEventElapsedTime(&ms, c->prof_ev[2 * q], c->prof_ev[2 * q + 1]));
+    e = hipEventElapsedTime(&ms, c->prof_ev[2 * q], c->prof_ev[2 * q + 1]);
     double* o = out_host + 3 * c->prof_slot[q];
     o[0] += 1.0;
     o[1] += ms * 1e3;
     o[2] += c->prof_rbytes[q];
   }
-  events_give(c->prof_ev);
+  events_give(c->device, c->prof_ev);                 // (on the error path too)
+  if (e != hipSuccess) {
+    c->err = std::string("plfem_profile_end: ") + hipGetErrorString(e);
+    return PLFEM_EHIP;
+  }
   return PLFEM_OK;
 }
 

@@ -270,16 +270,20 @@ class TrueVectorialMaxwellSolver:
             logger.warning(f"eigenpairs failed the a-posteriori check (residual {true_res:.2e}, "
                            f"{perturbed} perturbed pivots): re-running with refinement")
             copy_stream.synchronize()                 # the first pass's vectors are on their way: let them land, then redo
+            # second pass: refinement inside the operator (repairs an inaccurate factor) AND a tighter Ritz tolerance
+            # (repairs a first pass that merely stopped too early: a residual above the bound with no perturbed pivot)
             ctx.set_option("refine_steps", max(1, self.refine_steps + 1))
             try:
-                evals, evecs, st2 = ctx.lanczos(n_req, ncv, self.eig_tol, self.MAXITER, sigma)
+                evals, evecs, st2 = ctx.lanczos(n_req, ncv, min(self.eig_tol, 1e-10), self.MAXITER, sigma)
             finally:
                 ctx.set_option("refine_steps", self.refine_steps)
             res2 = float(ctx.residuals(evals, evecs).max())
             st = dict(st, **st2, true_residual=res2, refined=True)
             if not (res2 <= self.RESIDUAL_TOL):
-                raise RuntimeError(f"shift-invert factorisation inaccurate on this mesh: eigen-residual {res2:.2e} "
-                                   f"after refinement (first pass {true_res:.2e}, bound {self.RESIDUAL_TOL:.0e})")
+                why = (f"{perturbed} vanishing pivots were perturbed: the shift-invert factorisation is inaccurate on this mesh"
+                       if perturbed > 0 else "no pivot was perturbed: the eigenpairs did not converge tightly enough")
+                raise RuntimeError(f"eigen-residual {res2:.2e} after the refined re-run (first pass {true_res:.2e}, bound "
+                                   f"{self.RESIDUAL_TOL:.0e}); {why}")
             post, frac_core, modes_int = ctx.postprocess(evecs, cores, want_interior=True)
             with torch.cuda.stream(copy_stream):
                 host.copy_(modes_int, non_blocking=True)
@@ -415,15 +419,18 @@ class ScalarHelmholtzSolver:
         st = dict(st, true_residual=true_res, true_residual_first=true_res, refined=False)
         if not (true_res <= self.RESIDUAL_TOL) or ctx.timings()["pivot_perturbations"] > 0:
             logger.warning(f"scalar eigenpairs failed the a-posteriori check (residual {true_res:.2e}): re-running with refinement")
+            perturbed = ctx.timings()["pivot_perturbations"]
             ctx.set_option("refine_steps", 1)
             try:
-                evals, evecs, st2 = ctx.lanczos(n_req, ncv, self.eig_tol, self.MAXITER, sigma)
+                evals, evecs, st2 = ctx.lanczos(n_req, ncv, min(self.eig_tol, 1e-12), self.MAXITER, sigma)
             finally:
                 ctx.set_option("refine_steps", 0)
             res2 = float(ctx.residuals(evals, evecs).max())
             st = dict(st, **st2, true_residual=res2, refined=True)
             if not (res2 <= self.RESIDUAL_TOL):
-                raise RuntimeError(f"shift-invert factorisation inaccurate on this mesh: eigen-residual {res2:.2e} after refinement")
+                why = (f"{perturbed} vanishing pivots were perturbed: the shift-invert factorisation is inaccurate on this mesh"
+                       if perturbed > 0 else "no pivot was perturbed: the eigenpairs did not converge tightly enough")
+                raise RuntimeError(f"eigen-residual {res2:.2e} after the refined re-run (first pass {true_res:.2e}); {why}")
         post, _frac, fields = ctx.postprocess(evecs, cores, want_interior=True)   # M-normalised in place (solver_fem.py:268)
         vecs = fields.cpu().numpy()
         modes = []

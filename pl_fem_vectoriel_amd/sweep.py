@@ -17,8 +17,12 @@ import numpy as np
 
 from .geometry import ARRANGEMENTS, MCFGeometry
 
-K_MAX = 48          # padded record width: up to 48 effective indices per solve
-REC_WIDTH = K_MAX + 4
+K_MAX = 48          # padded record width: up to 48 modes per solve
+# per-mode columns of a record: what LossCalculator.calculate_physical_losses reads from a mode dict
+# (reference losses.py:742-825 -> n_eff, beta = n_eff k0, P_x, P_y, PDL_dB, confinement) + the filter quantity div_ratio
+FIELDS = ("n_eff", "P_x", "P_y", "PDL_dB", "confinement", "div_ratio")
+NF = len(FIELDS)
+REC_WIDTH = 4 + NF * K_MAX
 # record[3]: status of the solve -- every rank always reaches the gather, errors travel in the record
 ST_OK, ST_NOCONV, ST_ERROR, ST_SKIPPED = 0, 1, 2, 3
 
@@ -98,110 +102,156 @@ def partition(items: Sequence[SweepItem], world_size: int) -> List[List[SweepIte
 
 
 def default_solve(device: Optional[int] = None, meshes: Optional[dict] = None) -> Callable[[SweepItem, dict], np.ndarray]:
-    """Solve one item on the GPU; ``cache`` keeps one solver (symbolic analysis + context) per mesh.
-    ``meshes``: optional ``{item.mesh_key: TriMesh}`` of meshes produced beforehand (bench.py keeps the mesh
-    producer, the step before the path, outside its timed region); missing keys are generated on demand.
+    """Solve one item on the GPU.  Returns the (NF, k) array of per-mode columns ``FIELDS`` (n_eff descending).
 
-    ``solve.prepare(item, cache)`` may be called from a background thread for the NEXT mesh: mesh
-    generation (SciPy Delaunay + native refinement) and the host-side symbolic analysis release the GIL,
-    so they overlap with the GPU solves of the current mesh."""
+    ``cache`` is the calling LANE's dictionary: it keeps one solver (device context) for the lane's current mesh.  The
+    mesh itself and its host analysis (``Symbolic``: numbering, pattern, front tree) are built ONCE per mesh, whichever
+    lane or background thread asks first (``solve.prepare(item)``), and shared by every lane: the four wavelengths of a
+    cross-section can then run on four lanes, each with its own context on the one analysis.  ``meshes``: optional
+    ``{item.mesh_key: TriMesh}`` of meshes produced beforehand (bench.py keeps the mesh producer, the step before the
+    path, outside its timed region); missing keys are generated on demand.  Mesh generation (SciPy Delaunay + native
+    refinement) and the analysis release the GIL, so a background ``prepare`` overlaps with the GPU solves."""
+    import threading
+
     from . import _native
     from .mesh import generate_mesh
     from .solver_fem import TrueVectorialMaxwellSolver
 
-    def build(item: SweepItem) -> dict:
-        g = item.geometry()
-        mesh = (meshes or {}).get(item.mesh_key)
-        if mesh is None:
-            mesh = generate_mesh(g, item.mesh_refinement, item.mesh_levels)
-        return {"key": item.mesh_key, "mesh": mesh, "sym": _native.Symbolic(mesh.p, mesh.t)}
+    lock = threading.Lock()
+    shared: Dict[tuple, dict] = {}          # mesh_key -> {"ready": Event, "mesh", "sym", "error"}
 
-    def prepare(item: SweepItem, cache: dict) -> None:
-        cache.setdefault("prefetched", {})[item.mesh_key] = build(item)
+    def prepare(item: SweepItem) -> dict:
+        with lock:
+            ent = shared.get(item.mesh_key)
+            mine = ent is None
+            if mine:
+                ent = shared[item.mesh_key] = {"ready": threading.Event(), "error": None}
+        if mine:
+            try:
+                mesh = (meshes or {}).get(item.mesh_key)
+                if mesh is None:
+                    mesh = generate_mesh(item.geometry(), item.mesh_refinement, item.mesh_levels)
+                ent["mesh"], ent["sym"] = mesh, _native.Symbolic(mesh.p, mesh.t)
+            except Exception as exc:            # noqa: BLE001 - every waiter sees it
+                ent["error"] = exc
+            ent["ready"].set()
+        ent["ready"].wait()
+        if ent["error"] is not None:
+            raise ent["error"]
+        return ent
+
+    def release(mesh_key) -> None:
+        """The sweep driver calls this when the last item of a mesh is done: drop the shared mesh + analysis."""
+        with lock:
+            shared.pop(mesh_key, None)
 
     def solve(item: SweepItem, cache: dict) -> np.ndarray:
         g = item.geometry()
-        ent = cache.get("cur")
-        if ent is None or ent["key"] != item.mesh_key:
-            if ent is not None:
-                ent["solver"].clear_cache()
-            ent = cache.get("prefetched", {}).pop(item.mesh_key, None) or build(item)
-            ent["solver"] = TrueVectorialMaxwellSolver(g, device=device)
-            ent["solver"].adopt_analysis(ent["mesh"], ent["sym"])
-            cache["cur"] = ent
-        s = ent["solver"]
+        cur = cache.get("cur")
+        if cur is None or cur["key"] != item.mesh_key:
+            if cur is not None:
+                cur["solver"].clear_cache()
+                cache.pop("cur")
+            ent = prepare(item)
+            solver = TrueVectorialMaxwellSolver(g, device=device)
+            solver.adopt_analysis(ent["mesh"], ent["sym"])
+            cur = cache["cur"] = {"key": item.mesh_key, "mesh": ent["mesh"], "solver": solver}
+        s = cur["solver"]
         s.geometry, s.k0 = g, g.k0
-        modes = s.solve_vectorial_modes(ent["mesh"], item.n_modes)
-        return np.array([m["n_eff"] for m in modes], dtype=np.float64)
+        modes = s.solve_vectorial_modes(cur["mesh"], item.n_modes)
+        return np.array([[m[f] for m in modes] for f in FIELDS], dtype=np.float64).reshape(NF, len(modes))
 
     solve.prepare = prepare
+    solve.release = release
     return solve
 
 
-def _run_lane(entries, solve, rank: int, rec: np.ndarray, device, own_stream: bool, errors: list) -> None:
-    """One lane = a sequential pass over ``entries`` [(row in rec, item), ...] with its own solver cache (and, on
-    a GPU, its own stream so that lanes overlap on the device); the next different mesh is prepared on a host
-    thread while the current one is being solved."""
+def _close_lane(cache: dict) -> None:
+    cur = cache.pop("cur", None)
+    if cur is not None and "solver" in cur:
+        try:
+            cur["solver"].clear_cache()
+        except Exception:                      # noqa: BLE001
+            pass
+
+
+def _run_lane(queue, qlock, remaining, solve, rank: int, rec: np.ndarray, device, own_stream: bool, errors: list) -> None:
+    """One lane = a host thread (with its own stream on a GPU, so that lanes overlap on the device) that takes the next
+    entry (row in rec, item) off the rank's queue until it is empty.  The queue keeps the items of a mesh together, so a
+    lane mostly stays on its mesh (context reuse), and lanes that run out of work move on to whatever is next."""
     import contextlib
-    import threading
 
     ctx = contextlib.nullcontext()
     if own_stream:
         import torch
         ctx = torch.cuda.stream(torch.cuda.Stream(device))
     cache: dict = {}
-    prefetch = None
     with ctx:
-        for pos, (q, it) in enumerate(entries):
-            new_group = pos == 0 or entries[pos - 1][1].mesh_key != it.mesh_key
-            if new_group:
-                if prefetch is not None:
-                    prefetch.join()             # the mesh prepared in the background is this item's
-                    prefetch = None
-                if hasattr(solve, "prepare"):
-                    # while the GPU works on this mesh, prepare the next DIFFERENT mesh on a host thread
-                    nxt = next((x for _, x in entries[pos + 1:] if x.mesh_key != it.mesh_key), None)
-                    if nxt is not None:
-                        prefetch = threading.Thread(target=solve.prepare, args=(nxt, cache), daemon=True)
-                        prefetch.start()
+        while True:
+            with qlock:
+                if not queue:
+                    break
+                # prefer an item of the mesh this lane already holds a context for
+                key = cache.get("cur", {}).get("key")
+                pick = next((n for n, (_q, x) in enumerate(queue) if x.mesh_key == key), 0)
+                q, it = queue.pop(pick)
             # an exception in one solve must not keep this rank from the collective (the other ranks would block in it
-            # forever): it becomes a status code in the item's record, n_eff stays NaN, and run_sweep raises on every
-            # rank after the gather
+            # forever): it becomes a status code in the item's record, the columns stay NaN, and run_sweep raises on
+            # every rank after the gather
             rec[q, 0], rec[q, 1], rec[q, 2] = it.index, 0, rank
             try:
-                ne = np.asarray(solve(it, cache), dtype=np.float64)[:K_MAX]
-                rec[q, 1], rec[q, 3] = len(ne), ST_OK
-                rec[q, 4:4 + len(ne)] = ne
+                res = np.asarray(solve(it, cache), dtype=np.float64)
+                if res.ndim == 1:                          # a solver that only reports n_eff
+                    res = np.vstack([res[None, :], np.full((NF - 1, len(res)), np.nan)])
+                res = res[:, :K_MAX]
+                k = res.shape[1]
+                rec[q, 1], rec[q, 3] = k, ST_OK
+                for f in range(NF):
+                    rec[q, 4 + f * K_MAX:4 + f * K_MAX + k] = res[f]
             except Exception as exc:                       # noqa: BLE001 - reported through the record
                 from scipy.sparse.linalg import ArpackNoConvergence
                 rec[q, 3] = ST_NOCONV if isinstance(exc, ArpackNoConvergence) else ST_ERROR
                 errors.append((it.index, exc))
-                ent = cache.pop("cur", None)               # the context may be in an undefined state: drop it
-                if ent is not None and "solver" in ent:
-                    try:
-                        ent["solver"].clear_cache()
-                    except Exception:                      # noqa: BLE001
-                        pass
-        if prefetch is not None:
-            prefetch.join()
-        ent = cache.get("cur")
-        if ent is not None and "solver" in ent:
-            ent["solver"].clear_cache()
+                _close_lane(cache)                         # the context may be in an undefined state: drop it
+            with qlock:
+                remaining[it.mesh_key] -= 1
+                done = remaining[it.mesh_key] == 0
+            if done and hasattr(solve, "release"):
+                solve.release(it.mesh_key)
+        _close_lane(cache)
+
+
+def records_to_modes(row: np.ndarray, k0: float) -> List[Dict]:
+    """Mode records of one gathered row, as far as the loss consumer reads them (``losses.py``: n_eff, beta, P_x, P_y,
+    PDL_dB, confinement; is_vectorial) -- the vectors themselves never leave the GPU that computed them."""
+    k = int(row[1])
+    col = {f: row[4 + n * K_MAX:4 + n * K_MAX + k] for n, f in enumerate(FIELDS)}
+    return [{"n_eff": float(col["n_eff"][j]), "beta": float(col["n_eff"][j] * k0), "P_x": float(col["P_x"][j]),
+             "P_y": float(col["P_y"][j]), "PDL_dB": float(col["PDL_dB"][j]), "confinement": float(col["confinement"][j]),
+             "core_overlap": float(col["confinement"][j]), "div_ratio": float(col["div_ratio"][j]), "is_vectorial": True,
+             "method": "H-field_V18.10"} for j in range(k)]
 
 
 def run_sweep(items: Sequence[SweepItem], rank: int = 0, world_size: int = 1,
               solve: Optional[Callable[[SweepItem, dict], np.ndarray]] = None, device=None,
-              gather: bool = True, lanes: int = 1):
+              gather: bool = True, lanes: int = 1, losses: Optional[str] = None):
     """Solve this rank's share and gather fixed-size records on every rank.
 
-    Returns ``(table, local_count)``; ``table[i]`` is the descending n_eff list of item ``i``
-    (available on all ranks after the gather).  Records are ``[index, count, rank, 0, n_eff...]``
-    padded with NaN to ``REC_WIDTH`` doubles — the only inter-GPU traffic of the whole sweep.
+    Returns ``(table, local_count)``; ``table[i]`` is the descending n_eff list of item ``i`` (available on all ranks
+    after the gather).  With ``losses="mux"`` / ``"demux"`` a third value follows: ``{i: LossCalculator.
+    calculate_physical_losses(modes_i, geometry_i, direction, wavelength)}`` -- the IL / MDL / PDL / crosstalk columns of
+    the reference's loss consumer (``losses.py:742-825``), computed on every rank from the gathered
+    records.  A record is ``[index, count, rank, status, NF x K_MAX per-mode columns (FIELDS)]`` padded with NaN to
+    ``REC_WIDTH`` doubles -- the only inter-GPU traffic of the whole sweep.
 
-    ``lanes`` > 1: that many solves in flight on this rank's GPU, each lane a host thread with its own context and
-    stream (whole cross-sections are dealt to the lanes, so a lane still reuses its analysis across wavelengths).
-    A 1e5-DOF solve leaves most of an MI355X idle (host analysis, latency-bound tree levels); two lanes fill it.
+    ``lanes`` > 1: that many solves in flight on this rank's GPU, each lane a host thread with its own stream and device
+    context.  All lanes draw from one queue (mesh groups heaviest first, the wavelengths of a mesh adjacent) and share
+    the host analysis of a mesh, so a rank that owns two cross-sections still keeps four lanes busy; one background
+    thread walks ahead of them and prepares the meshes + analyses (``solve.prepare``).  A 1e5-DOF solve is a chain of
+    latency-bound launches and leaves most of an MI355X idle; a few lanes fill it.
     """
+    import threading
+
     import torch
 
     mine = partition(items, world_size)[rank]
@@ -214,37 +264,47 @@ def run_sweep(items: Sequence[SweepItem], rank: int = 0, world_size: int = 1,
     errors: list = []            # (item index, exception) of this rank's failed solves, for the message only
     for q, it in enumerate(mine):            # a lane that dies outside a solve leaves these as they are
         rec[q, 0], rec[q, 1], rec[q, 2], rec[q, 3] = it.index, 0, rank, ST_SKIPPED
-    if lanes == 1:
-        try:
-            _run_lane(list(enumerate(mine)), solve, rank, rec, device, own_stream=False, errors=errors)
-        except Exception as exc:               # noqa: BLE001 - e.g. mesh preparation failed: still reach the gather
-            errors.append((-1, exc))
-    else:
-        import threading
-        # deal whole mesh groups to the lanes, heaviest first, always to the lane with the least work so far
-        groups: Dict[tuple, list] = {}
-        for q, it in enumerate(mine):
-            groups.setdefault(it.mesh_key, []).append((q, it))
-        order = sorted(groups.values(), key=lambda g: -sum(it.cost() for _, it in g))
-        lane_items = [[] for _ in range(lanes)]
-        load = [0.0] * lanes
+    # queue: mesh groups heaviest first, the items of a group adjacent (in item order)
+    groups: Dict[tuple, list] = {}
+    for q, it in enumerate(mine):
+        groups.setdefault(it.mesh_key, []).append((q, it))
+    order = sorted(groups.values(), key=lambda g: (-sum(it.cost() for _, it in g), g[0][1].index))
+    queue = [e for g in order for e in g]
+    remaining = {k: len(g) for k, g in groups.items()}
+    qlock = threading.Lock()
+    on_gpu = device is not None and torch.cuda.is_available()
+
+    def preparer():
+        # walks ahead of the lanes: the next meshes + analyses are ready when a lane gets to them
         for g in order:
-            k = int(np.argmin(load))
-            lane_items[k].extend(g)
-            load[k] += sum(it.cost() for _, it in g)
-        on_gpu = device is not None and torch.cuda.is_available()
-
-        def work(entries):
+            with qlock:
+                if remaining.get(g[0][1].mesh_key, 0) == 0:
+                    continue
             try:
-                _run_lane(entries, solve, rank, rec, device, own_stream=on_gpu, errors=errors)
-            except Exception as exc:           # noqa: BLE001 - the lane's remaining items stay ST_SKIPPED
-                errors.append((-1, exc))
+                solve.prepare(g[0][1])
+            except Exception:                  # noqa: BLE001 - the lane that needs it raises the same error
+                pass
 
-        threads = [threading.Thread(target=work, args=(e,)) for e in lane_items if e]
+    def work():
+        try:
+            _run_lane(queue, qlock, remaining, solve, rank, rec, device, own_stream=on_gpu and lanes > 1, errors=errors)
+        except Exception as exc:               # noqa: BLE001 - the lane's remaining items stay ST_SKIPPED
+            errors.append((-1, exc))
+
+    pre = None
+    if hasattr(solve, "prepare") and len(order) > 0:
+        pre = threading.Thread(target=preparer, daemon=True)
+        pre.start()
+    if lanes == 1:
+        work()
+    else:
+        threads = [threading.Thread(target=work) for _ in range(min(lanes, max(len(queue), 1)))]
         for t in threads:
             t.start()
         for t in threads:
             t.join()
+    if pre is not None:
+        pre.join()
     table: Dict[int, np.ndarray] = {}
     if world_size > 1 and gather:
         import torch.distributed as dist
@@ -257,10 +317,12 @@ def run_sweep(items: Sequence[SweepItem], rank: int = 0, world_size: int = 1,
     else:
         allrec = rec
     failures = []
+    rows: Dict[int, np.ndarray] = {}
     for row in allrec:
         if row[0] >= 0:
             if int(row[3]) == ST_OK:
                 table[int(row[0])] = row[4:4 + int(row[1])].copy()
+                rows[int(row[0])] = row
             else:
                 failures.append((int(row[0]), int(row[2]), int(row[3])))
     if failures:
@@ -268,4 +330,13 @@ def run_sweep(items: Sequence[SweepItem], rank: int = 0, world_size: int = 1,
         if errors:
             raise err from errors[0][1]
         raise err
-    return table, len(mine)
+    if losses is None:
+        return table, len(mine)
+    from .losses import LossCalculator
+    by_index = {it.index: it for it in items}
+    loss_table = {}
+    for i, row in rows.items():
+        it = by_index[i]
+        g = it.geometry()
+        loss_table[i] = LossCalculator.calculate_physical_losses(records_to_modes(row, g.k0), g, losses, 1e3 * it.wavelength_um)
+    return table, len(mine), loss_table

@@ -1,17 +1,18 @@
 #!/bin/bash
 # Collects the committed profile artefacts of a round on the GPU box (run through gpurun):
-#   profiles/<tag>_kernel_stats.csv   rocprofv3 --kernel-trace --stats of `bench.py --steps 3 --warmup 1`
-#   profiles/<tag>_pmc_k_fwd.json     FETCH_SIZE / WRITE_SIZE of the dominant kernel (separate --pmc passes)
-#   profiles/<tag>_bench_line.json    the bench line of a plain run (with the CPU baseline)
-#   profiles/<tag>_levels_*.txt       per-level sweep table / per-level factorisation table from a kernel trace
-#   profiles/<tag>_ladder.json        bench.py --ladder (BASELINE configs[2]: L = 0, 1, 2)
-#   profiles/<tag>_sweep_1gpu.json    bench.py --sweep on one GPU (BASELINE configs[3])
+#   profiles/<tag>_bench_line.json     the bench line of a plain run (with the CPU baseline)
+#   profiles/<tag>_kernel_stats.csv    rocprofv3 --kernel-trace --stats of `bench.py --steps 3 --warmup 1`
+#   profiles/<tag>_levels_*.txt        per-level sweep table / per-level factorisation table from that kernel trace
+#   profiles/<tag>_pmc_families.json   FETCH_SIZE / WRITE_SIZE per kernel family (separate --pmc passes) + MFMA counters
+#   profiles/<tag>_ladder.json         bench.py --ladder (BASELINE configs[2]: L = 0, 1, 2)
+#   profiles/<tag>_sweep_1gpu.json     bench.py --sweep on one GPU (BASELINE configs[3]), 1 / 2 / 4 lanes
+#   profiles/<tag>_lane_overlap.txt    kernel-trace summary of the 4-lane sweep (how many kernels overlap, per HW queue)
 # usage: gpu_profile_round.sh <tag>      (outputs land in gpurun_out/profiles_<tag>/ for copying into profiles/)
 set -e
-TAG=${1:-r02}
+TAG=${1:-r03}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/profiles_$TAG
-rm -rf $OUT gpurun_out/prof_stats gpurun_out/prof_fetch gpurun_out/prof_write gpurun_out/prof_lv && mkdir -p $OUT
+rm -rf $OUT gpurun_out/prof_stats gpurun_out/prof_fetch gpurun_out/prof_write gpurun_out/prof_mfma gpurun_out/prof_lanes && mkdir -p $OUT
 python3 bench.py > $OUT/bench_full.log 2>&1
 grep '^{' $OUT/bench_full.log > $OUT/${TAG}_bench_line.json
 echo "bench line done"
@@ -22,19 +23,34 @@ python3 scripts/factor_levels.py gpurun_out/prof_stats/st_kernel_trace.csv > $OU
 rm -rf gpurun_out/prof_stats
 echo "kernel stats done"
 rocprofv3 --pmc FETCH_SIZE -d gpurun_out/prof_fetch -o f --output-format csv -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline > $OUT/bench_fetch.log 2>&1
+echo "fetch pass done"
 rocprofv3 --pmc WRITE_SIZE -d gpurun_out/prof_write -o w --output-format csv -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline > $OUT/bench_write.log 2>&1
-python3 scripts/pmc_summary.py 'k_fwd(_mix)?<4' gpurun_out/prof_fetch/f_counter_collection.csv gpurun_out/prof_write/w_counter_collection.csv $OUT/${TAG}_pmc_k_fwd.json
-rm -rf gpurun_out/prof_fetch gpurun_out/prof_write
+echo "write pass done"
+rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES -d gpurun_out/prof_mfma -o m --output-format csv -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline > $OUT/bench_mfma.log 2>&1 || echo "mfma pass failed"
+MF=gpurun_out/prof_mfma/m_counter_collection.csv
+[ -f $MF ] || MF=-
+python3 scripts/pmc_families.py gpurun_out/prof_fetch/f_counter_collection.csv gpurun_out/prof_write/w_counter_collection.csv $MF $OUT/${TAG}_pmc_families.json | tee $OUT/pmc_families.txt
+rm -rf gpurun_out/prof_fetch gpurun_out/prof_write gpurun_out/prof_mfma
 echo "pmc done"
 python3 bench.py --ladder --steps 5 --warmup 2 > $OUT/ladder.log 2>&1
 grep '^{' $OUT/ladder.log > $OUT/${TAG}_ladder.json
-python3 bench.py --sweep --steps 2 --warmup 1 > $OUT/sweep.log 2>&1
-grep '^{' $OUT/sweep.log > $OUT/${TAG}_sweep_1gpu.json
+echo "ladder done"
+: > $OUT/${TAG}_sweep_1gpu.json
+for L in 1 2 4; do
+  python3 bench.py --sweep --steps 2 --warmup 1 --lanes $L > $OUT/sweep_$L.log 2>&1
+  grep '^{' $OUT/sweep_$L.log >> $OUT/${TAG}_sweep_1gpu.json
+  echo "sweep lanes $L done"
+done
+rocprofv3 --kernel-trace -d gpurun_out/prof_lanes -o ln --output-format csv -- python3 bench.py --sweep --steps 1 --warmup 0 --lanes 4 > $OUT/sweep_trace.log 2>&1
+python3 scripts/lane_overlap.py gpurun_out/prof_lanes/ln_kernel_trace.csv > $OUT/${TAG}_lane_overlap.txt
+rm -rf gpurun_out/prof_lanes
+cat $OUT/${TAG}_lane_overlap.txt
 head -12 $OUT/${TAG}_kernel_stats.csv | cut -c1-150
-cut -c1-400 $OUT/${TAG}_bench_line.json
+cut -c1-600 $OUT/${TAG}_bench_line.json
 python3 - <<PY
 import json
 for l in open("$OUT/${TAG}_ladder.json"):
     d = json.loads(l); print("ladder", d["config"]["workload"][:40], round(d["ms_per_step"], 2), "ms", round(d["roofline"]["frac"], 3))
-d = json.loads(open("$OUT/${TAG}_sweep_1gpu.json").read()); print("sweep", round(d["ms_per_step"], 1), "ms", round(d["value"], 1), "modes/s")
+for l in open("$OUT/${TAG}_sweep_1gpu.json"):
+    d = json.loads(l); print("sweep", d["config"]["parallelism"], round(d["ms_per_step"], 1), "ms", round(d["value"], 1), "modes/s", "with mesh production", round(d["sweep"]["with_mesh_production"]["ms_per_step"], 1), "ms")
 PY

@@ -38,7 +38,7 @@ def test_sweep_mode_shards_the_64_solves_over_the_ranks():
     assert d1["n_gpus"] == 1 and d2["n_gpus"] == 2 and d1["scaling"] == d2["scaling"] == "strong"
     assert d1["sweep"]["solves"] == d2["sweep"]["solves"] == 64
     assert d1["sweep"]["n_eff_checksum"] == d2["sweep"]["n_eff_checksum"]     # same table after the gather
-    assert d2["ms_per_step"] < 0.8 * d1["ms_per_step"]                          # 32 sleeps per rank instead of 64
+    assert d1["sweep"]["solves_rank0"] == 64 and d2["sweep"]["solves_rank0"] == 32   # the work IS sharded (no wall-clock claim)
 
 
 def test_world_size_mismatch_and_failing_rank_are_errors():

@@ -8,8 +8,8 @@ import torch.multiprocessing as mp
 
 import pytest
 
-from pl_fem_vectoriel_amd.sweep import (K_MAX, ST_ERROR, ST_NOCONV, SweepError, SweepItem, multiband_sweep_items, partition,
-                                        run_sweep)
+from pl_fem_vectoriel_amd.sweep import (FIELDS, K_MAX, NF, ST_ERROR, ST_NOCONV, SweepError, SweepItem, multiband_sweep_items,
+                                        partition, run_sweep)
 
 
 def fake_solve(item: SweepItem, cache: dict) -> np.ndarray:
@@ -109,3 +109,90 @@ def test_failed_solve_reaches_the_gather_and_raises_on_every_rank(tmp_path):
     with pytest.raises(SweepError) as ei:
         run_sweep(multiband_sweep_items()[:24], 0, 1, solve=failing_solve)
     assert [f[0] for f in ei.value.failures] == [5, 13] and ei.value.__cause__ is not None
+
+
+# ---- records that feed the loss consumer (SURVEY.md row f2; VERDICT r2 item 8) -----------------------------------------
+def fake_solve_full(item: SweepItem, cache: dict) -> np.ndarray:
+    """(NF, k) per-mode columns like default_solve returns them: n_eff descending, P_x + P_y = 1, ..."""
+    k = 6 + item.index % 7
+    rng = np.random.default_rng(1000 + item.index)
+    n_eff = np.sort(1.26 + 0.004 * rng.random(k))[::-1]
+    px = rng.uniform(0.3, 0.7, k)
+    pdl = np.clip(10 * np.log10(np.maximum(px, 1 - px) / np.minimum(px, 1 - px)), 0, 50)
+    return np.stack([n_eff, px, 1 - px, pdl, rng.uniform(0.4, 0.8, k), rng.uniform(0.02, 0.04, k)])
+
+
+def _direct_losses(item, direction):
+    from pl_fem_vectoriel_amd.losses import LossCalculator
+    g = item.geometry()
+    cols = fake_solve_full(item, {})
+    modes = [{"n_eff": float(cols[0, j]), "beta": float(cols[0, j] * g.k0), "P_x": float(cols[1, j]), "P_y": float(cols[2, j]),
+              "PDL_dB": float(cols[3, j]), "confinement": float(cols[4, j]), "core_overlap": float(cols[4, j]),
+              "div_ratio": float(cols[5, j]), "is_vectorial": True} for j in range(cols.shape[1])]
+    return LossCalculator.calculate_physical_losses(modes, g, direction, 1e3 * item.wavelength_um)
+
+
+def _worker_losses(rank, world_size, port, out_dir):
+    import json
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world_size))
+    dist.init_process_group("gloo", rank=rank, world_size=world_size)
+    items = multiband_sweep_items()[:24]
+    table, n_local, losses = run_sweep(items, rank, world_size, solve=fake_solve_full, lanes=2, losses="demux")
+    dist.barrier()
+    with open(os.path.join(out_dir, f"l{rank}.json"), "w") as fh:
+        json.dump({str(i): losses[i] for i in sorted(losses)}, fh)
+    dist.destroy_process_group()
+
+
+def test_gathered_records_yield_the_loss_columns_on_every_rank(tmp_path):
+    import json
+    assert NF == 6 and FIELDS[0] == "n_eff"
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_worker_losses, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    got = [json.load(open(tmp_path / f"l{r}.json")) for r in range(2)]
+    assert got[0] == got[1] and len(got[0]) == 24            # every rank holds every item's loss columns
+    items = multiband_sweep_items()[:24]
+    for it in items:
+        want = _direct_losses(it, "demux")
+        have = got[0][str(it.index)]
+        assert have["success"] and set(have) == set(want)
+        for key, v in want.items():
+            if isinstance(v, float):
+                assert abs(have[key] - v) <= 1e-12 * max(1.0, abs(v)), (it.index, key)
+            else:
+                assert have[key] == v, (it.index, key)
+    # single process, one lane, the other direction
+    table, n, losses = run_sweep(items, 0, 1, solve=fake_solve_full, losses="mux")
+    assert n == 24 and losses[7]["direction"] == "mux" and abs(losses[7]["IL_dB"] - _direct_losses(items[7], "mux")["IL_dB"]) < 1e-12
+
+
+def test_four_lanes_stay_busy_on_a_rank_with_two_meshes():
+    """World size 8: a rank owns two cross-sections x four wavelengths.  The lanes draw single items from one queue and
+    share a mesh's analysis, so all four work (VERDICT r2 weak #10: whole groups per lane left two of four idle)."""
+    import threading
+    import time
+    items = multiband_sweep_items()
+    for rank in range(8):
+        mine = partition(items, 8)[rank]
+        assert len(mine) == 8 and len({i.mesh_key for i in mine}) == 2
+    seen, prepared, lock = {}, [], threading.Lock()
+
+    def solve(item, cache):
+        time.sleep(0.03)
+        with lock:
+            seen.setdefault(threading.get_ident(), []).append(item.index)
+        return fake_solve(item, cache)
+
+    def prepare(item):
+        with lock:
+            prepared.append(item.mesh_key)
+    solve.prepare = prepare
+    table, n = run_sweep(items, 3, 8, solve=solve, gather=False, lanes=4)
+    assert n == 8 and len(table) == 8
+    assert len(seen) == 4 and sorted(len(v) for v in seen.values()) == [2, 2, 2, 2]     # four lanes, two solves each
+    assert len(set(prepared)) == 2                                                       # one preparation per mesh
+

@@ -223,7 +223,8 @@ def test_malformed_mesh_is_reported_from_the_side_chain(built_library):
             _native.Symbolic(p, t, nthreads=nt)
 
 
-def test_allocator_tuning_can_be_switched_off(monkeypatch):
+def test_allocator_tuning_is_opt_in(monkeypatch):
+    """Loading the library must not change the host process's malloc policy unless the application asks for it."""
     calls = []
 
     class FakeLibc:
@@ -232,9 +233,11 @@ def test_allocator_tuning_can_be_switched_off(monkeypatch):
             return 1
 
     monkeypatch.setattr(_native.ctypes, "CDLL", lambda name: FakeLibc())
+    monkeypatch.delenv("PLFEM_MALLOC_TUNE", raising=False)
+    _native._tune_host_allocator()
     monkeypatch.setenv("PLFEM_MALLOC_TUNE", "0")
     _native._tune_host_allocator()
     assert calls == []
-    monkeypatch.delenv("PLFEM_MALLOC_TUNE")
+    monkeypatch.setenv("PLFEM_MALLOC_TUNE", "1")
     _native._tune_host_allocator()
     assert calls == [(-3, 32 << 20), (-1, 512 << 20)]      # M_MMAP_THRESHOLD, M_TRIM_THRESHOLD
