@@ -379,7 +379,7 @@ int create_impl(plfem_ctx* c, const plfem_symbolic* sym, int device, void* strea
   c->fnodes_total = fnodes_total;
   TRY(dalloc(c, &c->d_wbuf, (size_t)4 * fnodes_total * plfem::NB));   // two halves: panels of even / odd block steps
   TRY(dalloc(c, &c->d_rbuf, (size_t)4 * fnodes_total * plfem::NB));
-  TRY(dalloc(c, &c->d_dinv, (size_t)S.nfronts * plfem::NB * plfem::NB));
+  TRY(dalloc(c, &c->d_dinv, (size_t)2 * S.nfronts * plfem::NB * plfem::NB));   // X of the pivot blocks, by block-step parity
   TRY(dalloc(c, &c->d_delta, (size_t)4 * fnodes_total));   // D^-1: (diagonal, off-diagonal) per front row
   TRY(dalloc(c, &c->d_tbuf, (size_t)2 * fnodes_total * plfem::NB));
   TRY(dalloc(c, &c->d_fvec2, (size_t)2 * fnodes_total * plfem::BLOCK_P));

@@ -88,7 +88,7 @@ struct plfem_ctx {
   int32_t* d_npos = nullptr;      // [N] node -> front-order offset of its component 0: 2 fnode_ptr[owner] + dpn * local index, -1 = Dirichlet
   int32_t* d_prow = nullptr;      // per local node of a front: local node index in the PARENT front, -1 = none / padding
   double *d_wbuf = nullptr, *d_rbuf = nullptr;   // per-front panels m x NB, offset 2*fnode_ptr[f]*NB
-  double* d_dinv = nullptr;       // per-front NB x NB (inverse of the current unit-lower pivot block)
+  double* d_dinv = nullptr;       // 2 x per-front NB x NB (inverse of the unit-lower pivot block of even / odd block steps)
   double* d_delta = nullptr;      // per-front D^-1 of the block LDL^T: (diagonal, off-diagonal of the node pair) per row, offset 2 * (2*fnode_ptr[f])
   double* d_tbuf = nullptr;       // per-front NB x s2 scratch (block row of L11), offset 2*fnode_ptr[f]*NB
   double* d_fvec2 = nullptr;      // forward-sweep results of the owned rows (t = L11^-1 r; the backward sweep applies D^-1), front order

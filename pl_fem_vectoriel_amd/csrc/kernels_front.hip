@@ -242,7 +242,8 @@ struct PivotLds {
   double rmax[NB];            // largest entry of every row pair of the block on arrival
 };
 
-__device__ __forceinline__ void ldl_pivot_block(const double* __restrict__ F, int m, int k0, int nbk, int tid,
+// src: the block itself, src[i + c * ld] = a[i][c] -- the front in global memory (ld = m) or an LDS tile (look-ahead).
+__device__ __forceinline__ void ldl_pivot_block(const double* src, int64_t ld, int nbk, int tid,
                                                 double (*tile)[NB + 1], double* __restrict__ sDd, double* __restrict__ sDo,
                                                 PivotLds& S, int32_t* __restrict__ counters) {
   static_assert(NB == 32, "thread map of ldl_pivot_block");
@@ -252,9 +253,10 @@ __device__ __forceinline__ void ldl_pivot_block(const double* __restrict__ F, in
 #pragma unroll
   for (int cc = 0; cc < 4; ++cc) {
     const int c = 4 * cg + cc;
-    v[cc] = (i < nbk && c < nbk) ? F[(int64_t)(k0 + c) * m + (k0 + i)] : (i == c ? 1.0 : 0.0);
+    v[cc] = (i < nbk && c < nbk) ? src[(int64_t)c * ld + i] : (i == c ? 1.0 : 0.0);
     rmax = fmax(rmax, fabs(v[cc]));
   }
+  __syncthreads();                                             // (src may be the LDS tile that `tile` aliases: all loads first)
   // "vanishing" is judged against the pair's OWN two rows of the block as they arrive (not against the whole block: a
   // sliver element's 1e9-sized entries in the same block would declare a healthy pivot of 1e-4 a zero)
   tile[cg][i] = rmax;
@@ -315,11 +317,24 @@ __device__ __forceinline__ void ldl_pivot_block(const double* __restrict__ F, in
   if (tid == 0 && nper > 0 && counters) atomicAdd(&counters[0], nper);
 }
 
-// Launch A of a block step: pivot block + panel.  Every panel workgroup (64 rows below the pivot block, 4 waves of 16
-// rows) factorises the pivot block ITSELF -- the same arithmetic in every workgroup, so the same bits -- while its panel
-// operands are in flight: no launch boundary between pivot and panel, and nobody writes
-// the pivot block in this launch (workgroup 0 of the front stores X in dinv and D^-1 in delta; the block is written back
-// into F by the next launch).  Panel: Y = R X^T (= R L^-T), W = Y D^-1 (= the L panel; D^-1 couples the two columns of a
+// X = L^-1 of the pivot block -> dinv (D[r + c*NB] = X[r][c]), its D^-1 -> delta ((diagonal, off-diagonal) of every row)
+__device__ __forceinline__ void store_pivot_results(int f, int k0, int nbk, const int64_t* __restrict__ fnode_ptr,
+                                                    double* __restrict__ dinv, double* __restrict__ delta,
+                                                    double (*tile)[NB + 1], const double* __restrict__ sDd,
+                                                    const double* __restrict__ sDo) {
+  double* D = dinv + (int64_t)f * NB * NB;
+  for (int e = threadIdx.x; e < NB * NB; e += 256) D[e] = tile[e & (NB - 1)][e >> 5];
+  if ((int)threadIdx.x < nbk)
+    reinterpret_cast<double2*>(delta)[2 * fnode_ptr[f] + k0 + threadIdx.x] = make_double2(sDd[threadIdx.x], sDo[threadIdx.x]);
+}
+
+// Launch A of a block step: pivot block + panel.  At the FIRST step of a level every panel workgroup (64 rows below the
+// pivot block, 4 waves of 16 rows) factorises the pivot block itself -- the same arithmetic in every workgroup, so the same
+// bits -- while its panel operands are in flight (workgroup 0 of the front stores X in dinv and D^-1 in delta).  At every
+// later step the pivot block was factorised one launch EARLIER, by a look-ahead workgroup of the previous update launch,
+// where its chain of 16 dependent pair steps (7 us) runs beside the trailing update instead of in front of the panel: the
+// panel workgroups only load X and D^-1.  Nobody writes the pivot block in this launch (it is written back into F by the
+// next launch).  Panel: Y = R X^T (= R L^-T), W = Y D^-1 (= the L panel; D^-1 couples the two columns of a
 // node pair: the partner column of an accumulator register sits in lane ^ 16); W, Y are saved for the update kernel and
 // W replaces R in F (a workgroup reads and writes its own rows only).
 // blockIdx.y < n_tb: these workgroups save the block row L[k, <k] of L11 for the triangular-inverse update (tbuf).
@@ -373,13 +388,20 @@ __global__ __launch_bounds__(256) void k_ldl_pivot_panel(int n_tb, const int32_t
       b[kk] = (ibase < m && jx < nbk) ? F[(int64_t)(k0 + jx) * m + ibase + lr] : 0.0;
     }
   }
-  ldl_pivot_block(F, m, k0, nbk, threadIdx.x, tile, sDd, sDo, piv, bx == 0 ? counters : nullptr);
-  __syncthreads();
-  if (bx == 0) {
-    double* D = dinv + (int64_t)f * NB * NB;              // D[r + c*NB] = X[r][c]
-    for (int e = threadIdx.x; e < NB * NB; e += 256) D[e] = tile[e & (NB - 1)][e >> 5];
-    if (threadIdx.x < nbk)                                    // D^-1: (diagonal, off-diagonal) of every row
-      reinterpret_cast<double2*>(delta)[2 * fnode_ptr[f] + k0 + threadIdx.x] = make_double2(sDd[threadIdx.x], sDo[threadIdx.x]);
+  if (kb == 0) {
+    ldl_pivot_block(F + (int64_t)k0 * m + k0, m, nbk, threadIdx.x, tile, sDd, sDo, piv, bx == 0 ? counters : nullptr);
+    __syncthreads();
+    if (bx == 0) store_pivot_results(f, k0, nbk, fnode_ptr, dinv, delta, tile, sDd, sDo);
+  } else {
+    // the pivot block of this step was factorised by the look-ahead workgroup of the previous update launch
+    const double* D = dinv + (int64_t)f * NB * NB;
+    for (int e = threadIdx.x; e < NB * NB; e += 256) tile[e & (NB - 1)][e >> 5] = D[e];
+    if (threadIdx.x < NB) {
+      const double2 d = threadIdx.x < nbk ? reinterpret_cast<const double2*>(delta)[2 * fnode_ptr[f] + k0 + threadIdx.x] : make_double2(1.0, 0.0);
+      sDd[threadIdx.x] = d.x;
+      sDo[threadIdx.x] = d.y;
+    }
+    __syncthreads();
   }
   // Y^T[c][i] = sum_j X[c][j] R[i][j] on v_mfma_f64_16x16x4_f64: A <- X (row c, k = j), B <- R^T; the accumulator
   // register r of lane l is Y[i = ibase + (l & 15)][c = 16 tc + (l >> 4) + 4 r]: 128-B runs of W, Y and of the panel
@@ -601,12 +623,16 @@ __device__ __forceinline__ void ldl_update_tile(const int2 job, int kb, const in
       acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[it], b1[it], acc[1][1], 0, 0, 0);
     }
   }
+  // the pivot block of the NEXT step (rows and columns [t0, t0 + nbn)) is updated, and factorised, by the look-ahead
+  // workgroup of this launch: nothing else reads it before the write-back of the next update launch replaces it
+  const int nbn = (i0 == t0 && j0 == t0 && t0 < s2) ? min(NB, s2 - t0) : 0;
 #pragma unroll
   for (int tj = 0; tj < 2; ++tj) {
     if (tj == 1 && !jv1) continue;
 #pragma unroll
     for (int ti = 0; ti < 2; ++ti) {
       if (ti == 1 && !iv1) continue;
+      if (16 * tj < nbn && 16 * ti < nbn) continue;
 #pragma unroll
       for (int r = 0; r < 4; ++r)
         F[(int64_t)(j0 + 16 * tj + lk + 4 * r) * m + (i0 + 16 * ti + lr)] = fv[tj][ti][r] - acc[tj][ti][r];
@@ -614,23 +640,86 @@ __device__ __forceinline__ void ldl_update_tile(const int2 job, int kb, const in
   }
 }
 
+// Look-ahead workgroup of launch B: the pivot block of the front's NEXT block step -- rows and columns [t0, t0 + nbn) of
+// the trailing matrix -- receives this step's update here (wave w = quadrant (w & 1, w >> 1); rank 32 after an even
+// step, rank 64 with the panels of both steps after an odd one, exactly as ldl_update_tile would have done it), goes to
+// LDS instead of back to F, and is factorised on the spot: X -> dinv of the next step's parity, D^-1 -> delta.
+template <int MODE>
+__device__ __forceinline__ void ldl_lookahead_block(int f, int kb, const int32_t* __restrict__ fs2, const int32_t* __restrict__ fm,
+                                                    const int64_t* __restrict__ foff, const int64_t* __restrict__ fnode_ptr,
+                                                    const double* __restrict__ front, double* __restrict__ dinv_next,
+                                                    double* __restrict__ delta, const double* __restrict__ wbuf,
+                                                    const double* __restrict__ rbuf, const double* __restrict__ wbuf_prev,
+                                                    const double* __restrict__ rbuf_prev, int32_t* __restrict__ counters) {
+  const int s2 = fs2[f];
+  const int k0 = kb * NB;
+  const int t0 = k0 + NB;                      // (a front with a next step has a full block now)
+  if (t0 >= s2) return;
+  const int nbn = min(NB, s2 - t0);
+  const int m = fm[f];
+  const double* F = front + foff[f];
+  __shared__ __attribute__((aligned(16))) PivotLds piv;
+  __shared__ double tile[NB][NB + 1];
+  __shared__ double sDd[NB], sDo[NB];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int lr = lane & 15, lk = lane >> 4;
+  const int ti = wave & 1, tj = wave >> 1;
+  if (16 * ti < nbn && 16 * tj < nbn) {
+    double fv[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) fv[r] = F[(int64_t)(t0 + 16 * tj + lk + 4 * r) * m + (t0 + 16 * ti + lr)];
+    v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int pass = 0; pass <= MODE; ++pass) {
+      const double* W = (pass == 0 ? wbuf : wbuf_prev) + 2 * fnode_ptr[f] * NB;
+      const double* Y = (pass == 0 ? rbuf : rbuf_prev) + 2 * fnode_ptr[f] * NB;
+      double a[NB / 4], b[NB / 4];
+#pragma unroll
+      for (int it = 0; it < NB / 4; ++it) {
+        const int64_t col = (int64_t)(4 * it + lk) * m;
+        a[it] = Y[col + t0 + 16 * tj + lr];
+        b[it] = W[col + t0 + 16 * ti + lr];
+      }
+#pragma unroll
+      for (int it = 0; it < NB / 4; ++it) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[it], b[it], acc, 0, 0, 0);
+    }
+    // tile[c][i] = a[i][c]: column-major with leading dimension NB + 1, what ldl_pivot_block reads as src[i + c ld]
+#pragma unroll
+    for (int r = 0; r < 4; ++r) tile[16 * tj + lk + 4 * r][16 * ti + lr] = fv[r] - acc[r];
+  }
+  __syncthreads();
+  ldl_pivot_block(&tile[0][0], NB + 1, nbn, threadIdx.x, tile, sDd, sDo, piv, counters);
+  __syncthreads();
+  store_pivot_results(f, t0, nbn, fnode_ptr, dinv_next, delta, tile, sDd, sDo);
+}
+
 // Launch B of a block step: the trailing update (workgroups [0, un): the step's tile list) and, for every active
 // front, the triangular-inverse update of the block row (n_inv workgroups) plus one workgroup that writes the pivot
 // block of this step (lower X, upper X^T, from dinv) back into F -- all independent of one another: the update touches
 // rows / columns behind the pivot block, the inverse update rows of the pivot block in earlier columns.
 template <int MODE>
-__global__ __launch_bounds__(256) void k_ldl_update(int un, int n_inv, const int2* __restrict__ tiles,
+__global__ __launch_bounds__(256) void k_ldl_update(int un, int n_inv, int n_look, const int2* __restrict__ tiles,
                                                     const int32_t* __restrict__ forder, int kb, const int32_t* __restrict__ fs2,
                                                     const int32_t* __restrict__ fm, const int64_t* __restrict__ foff,
                                                     const int64_t* __restrict__ fnode_ptr, double* __restrict__ front,
-                                                    const double* __restrict__ dinv, const double* __restrict__ tbuf,
+                                                    const double* __restrict__ dinv, double* __restrict__ dinv_next,
+                                                    double* __restrict__ delta, const double* __restrict__ tbuf,
                                                     const double* __restrict__ wbuf, const double* __restrict__ rbuf,
-                                                    const double* __restrict__ wbuf_prev, const double* __restrict__ rbuf_prev) {
-  if ((int)blockIdx.x < un) {
-    ldl_update_tile<MODE>(tiles[blockIdx.x], kb, fs2, fm, foff, fnode_ptr, front, wbuf, rbuf, wbuf_prev, rbuf_prev);
+                                                    const double* __restrict__ wbuf_prev, const double* __restrict__ rbuf_prev,
+                                                    int32_t* __restrict__ counters) {
+  // look-ahead workgroups first: theirs is the longest chain of the launch (the fronts with a next step are a prefix of
+  // the launch order)
+  if ((int)blockIdx.x < n_look) {
+    ldl_lookahead_block<MODE>(forder[blockIdx.x], kb, fs2, fm, foff, fnode_ptr, front, dinv_next, delta, wbuf, rbuf, wbuf_prev,
+                              rbuf_prev, counters);
     return;
   }
-  const int e = blockIdx.x - un;
+  const int bid = blockIdx.x - n_look;
+  if (bid < un) {
+    ldl_update_tile<MODE>(tiles[bid], kb, fs2, fm, foff, fnode_ptr, front, wbuf, rbuf, wbuf_prev, rbuf_prev);
+    return;
+  }
+  const int e = bid - un;
   const int f = forder[e / (n_inv + 1)];
   const int sub = e % (n_inv + 1);
   if (sub < n_inv) {
@@ -785,20 +874,32 @@ void launch_factor(plfem_ctx* c, double sigma, int stop_level, int stop_step, in
       // workgroup 0 always exists: it owns the pivot results
       int n_pan = std::max(1, max_trail > 0 ? (max_trail + 63) / 64 : 0);
       if (li.count > 64) n_pan = std::min(n_pan, 2);
+      // X of the pivot blocks: two buffers by the parity of the block step (the look-ahead of step kb writes the one
+      // step kb + 1 reads while step kb's inverse-row / write-back workgroups still read theirs)
+      double* dinv_cur = c->d_dinv + (size_t)(kb & 1) * c->nfronts * NB * NB;
+      double* dinv_nxt = c->d_dinv + (size_t)((kb + 1) & 1) * c->nfronts * NB * NB;
       hipLaunchKernelGGL(k_ldl_pivot_panel, dim3(nact, n_tb + n_pan), dim3(256), 0, st, n_tb, ford, kb, c->d_fs2, c->d_fm,
-                         c->d_foff, c->d_fnode_ptr, c->d_front, c->d_dinv, c->d_delta, c->d_tbuf, wb, rb, c->d_counters);
+                         c->d_foff, c->d_fnode_ptr, c->d_front, dinv_cur, c->d_delta, c->d_tbuf, wb, rb, c->d_counters);
       if (stop_here && stop_stage >= 1 && stop_stage <= 2) return;
       // launch B: trailing update + triangular-inverse update + write-back of the pivot block
       const int un = c->upd_n[li.step0 + kb];                  // 64 x 64 blocks of this step's trailing updates
       const int n_inv = kb > 0 ? (k0 + 15) / 16 : 0;        // one workgroup per 16 columns of the block row
       const int2* ut = c->d_tiles + c->upd_off[li.step0 + kb];
-      const unsigned gridB = (unsigned)(un + nact * (n_inv + 1));
+      int n_look = 0;                                          // fronts with a next block step: s2 > k0 + NB (a prefix)
+      {
+        int lo = 0, hi = nact;
+        while (lo < hi) { int mid = (lo + hi) / 2; if (hs2[mid] > k0 + NB) lo = mid + 1; else hi = mid; }
+        n_look = lo;
+      }
+      const unsigned gridB = (unsigned)(n_look + un + nact * (n_inv + 1));
       if ((kb & 1) == 0)
-        hipLaunchKernelGGL(k_ldl_update<0>, dim3(gridB), dim3(256), 0, st, un, n_inv, ut, ford, kb, c->d_fs2, c->d_fm, c->d_foff,
-                           c->d_fnode_ptr, c->d_front, c->d_dinv, c->d_tbuf, wb, rb, wb, rb);
+        hipLaunchKernelGGL(k_ldl_update<0>, dim3(gridB), dim3(256), 0, st, un, n_inv, n_look, ut, ford, kb, c->d_fs2, c->d_fm,
+                           c->d_foff, c->d_fnode_ptr, c->d_front, dinv_cur, dinv_nxt, c->d_delta, c->d_tbuf, wb, rb, wb, rb,
+                           c->d_counters);
       else
-        hipLaunchKernelGGL(k_ldl_update<1>, dim3(gridB), dim3(256), 0, st, un, n_inv, ut, ford, kb, c->d_fs2, c->d_fm, c->d_foff,
-                           c->d_fnode_ptr, c->d_front, c->d_dinv, c->d_tbuf, wb, rb, c->d_wbuf, c->d_rbuf);
+        hipLaunchKernelGGL(k_ldl_update<1>, dim3(gridB), dim3(256), 0, st, un, n_inv, n_look, ut, ford, kb, c->d_fs2, c->d_fm,
+                           c->d_foff, c->d_fnode_ptr, c->d_front, dinv_cur, dinv_nxt, c->d_delta, c->d_tbuf, wb, rb, c->d_wbuf,
+                           c->d_rbuf, c->d_counters);
       if (stop_here && (stop_stage == 3 || stop_stage == 4)) return;
     }
     if (li.formz_n > 0 && stop_level >= 0) {          // (debug run that stops after a level: its Z now)

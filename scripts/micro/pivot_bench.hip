@@ -16,7 +16,7 @@ __global__ __launch_bounds__(256) void k_bench(const double* F, int m, int reps,
   const long long w0 = wall_clock64();
   const long long c0 = clock64();
   for (int r = 0; r < reps; ++r) {
-    ldl_pivot_block(F, m, 0, NB, lane, tile, sDd, sDo, piv, nullptr);
+    ldl_pivot_block(F, m, NB, lane, tile, sDd, sDo, piv, nullptr);
     __syncthreads();
   }
   const long long c1 = clock64();
