@@ -175,10 +175,12 @@ def _close_lane(cache: dict) -> None:
             pass
 
 
-def _run_lane(queue, qlock, remaining, solve, rank: int, rec: np.ndarray, device, own_stream: bool, errors: list) -> None:
+def _run_lane(queue, qlock, remaining, holders, solve, rank: int, rec: np.ndarray, device, own_stream: bool, errors: list) -> None:
     """One lane = a host thread (with its own stream on a GPU, so that lanes overlap on the device) that takes the next
-    entry (row in rec, item) off the rank's queue until it is empty.  The queue keeps the items of a mesh together, so a
-    lane mostly stays on its mesh (context reuse), and lanes that run out of work move on to whatever is next."""
+    entry (row in rec, item) off the rank's queue until it is empty.  A lane stays on the mesh it holds a device context
+    for while that mesh has items left; then it takes the first mesh NO other lane is working on (a context per lane and
+    mesh costs a millisecond and gigabytes: 16 meshes on 4 lanes should make 16 contexts, not 64), and only when every
+    remaining mesh is taken does it join another lane's mesh (a rank with two meshes still keeps four lanes busy)."""
     import contextlib
 
     ctx = contextlib.nullcontext()
@@ -186,15 +188,29 @@ def _run_lane(queue, qlock, remaining, solve, rank: int, rec: np.ndarray, device
         import torch
         ctx = torch.cuda.stream(torch.cuda.Stream(device))
     cache: dict = {}
+    held = None
     with ctx:
         while True:
             with qlock:
                 if not queue:
+                    if held is not None:
+                        holders[held] -= 1
                     break
-                # prefer an item of the mesh this lane already holds a context for
-                key = cache.get("cur", {}).get("key")
-                pick = next((n for n, (_q, x) in enumerate(queue) if x.mesh_key == key), 0)
+                pick = next((n for n, (_q, x) in enumerate(queue) if x.mesh_key == held), None)
+                if pick is None:
+                    pick = next((n for n, (_q, x) in enumerate(queue) if holders.get(x.mesh_key, 0) == 0), None)
+                if pick is None:                           # every remaining mesh has a lane: join the one with most items left
+                    left: Dict[tuple, int] = {}
+                    for _q, x in queue:
+                        left[x.mesh_key] = left.get(x.mesh_key, 0) + 1
+                    best = max(left, key=lambda k: (left[k] / (1 + holders.get(k, 0)), -min(n for n, (_q, x) in enumerate(queue) if x.mesh_key == k)))
+                    pick = next(n for n, (_q, x) in enumerate(queue) if x.mesh_key == best)
                 q, it = queue.pop(pick)
+                if it.mesh_key != held:
+                    if held is not None:
+                        holders[held] -= 1
+                    held = it.mesh_key
+                    holders[held] = holders.get(held, 0) + 1
             # an exception in one solve must not keep this rank from the collective (the other ranks would block in it
             # forever): it becomes a status code in the item's record, the columns stay NaN, and run_sweep raises on
             # every rank after the gather
@@ -274,27 +290,36 @@ def run_sweep(items: Sequence[SweepItem], rank: int = 0, world_size: int = 1,
     qlock = threading.Lock()
     on_gpu = device is not None and torch.cuda.is_available()
 
+    holders: Dict[tuple, int] = {}
+    todo = [g[0][1] for g in order]              # one item per mesh, in queue order
+
     def preparer():
-        # walks ahead of the lanes: the next meshes + analyses are ready when a lane gets to them
-        for g in order:
+        # walk ahead of the lanes: the next meshes + analyses are ready when a lane gets to them (Delaunay, the native
+        # refinement and the analysis release the GIL; a mesh takes 50-120 ms of host time, four solves on it 60-150 ms
+        # of GPU time, so one preparer cannot keep four lanes fed)
+        while True:
             with qlock:
-                if remaining.get(g[0][1].mesh_key, 0) == 0:
+                if not todo:
+                    return
+                it0 = todo.pop(0)
+                if remaining.get(it0.mesh_key, 0) == 0:
                     continue
             try:
-                solve.prepare(g[0][1])
+                solve.prepare(it0)
             except Exception:                  # noqa: BLE001 - the lane that needs it raises the same error
                 pass
 
     def work():
         try:
-            _run_lane(queue, qlock, remaining, solve, rank, rec, device, own_stream=on_gpu and lanes > 1, errors=errors)
+            _run_lane(queue, qlock, remaining, holders, solve, rank, rec, device, own_stream=on_gpu and lanes > 1, errors=errors)
         except Exception as exc:               # noqa: BLE001 - the lane's remaining items stay ST_SKIPPED
             errors.append((-1, exc))
 
-    pre = None
+    pres = []
     if hasattr(solve, "prepare") and len(order) > 0:
-        pre = threading.Thread(target=preparer, daemon=True)
-        pre.start()
+        pres = [threading.Thread(target=preparer, daemon=True) for _ in range(min(lanes, len(order), 4))]
+        for t in pres:
+            t.start()
     if lanes == 1:
         work()
     else:
@@ -303,8 +328,8 @@ def run_sweep(items: Sequence[SweepItem], rank: int = 0, world_size: int = 1,
             t.start()
         for t in threads:
             t.join()
-    if pre is not None:
-        pre.join()
+    for t in pres:
+        t.join()
     table: Dict[int, np.ndarray] = {}
     if world_size > 1 and gather:
         import torch.distributed as dist

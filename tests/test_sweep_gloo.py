@@ -196,3 +196,23 @@ def test_four_lanes_stay_busy_on_a_rank_with_two_meshes():
     assert len(seen) == 4 and sorted(len(v) for v in seen.values()) == [2, 2, 2, 2]     # four lanes, two solves each
     assert len(set(prepared)) == 2                                                       # one preparation per mesh
 
+
+
+def test_lanes_keep_one_context_per_mesh_while_meshes_outnumber_them():
+    """One rank, 16 meshes, 4 lanes: a lane takes a mesh nobody else is on while there is one, so the 64 solves need
+    about 16 (lane, mesh) contexts -- not the 64 that four lanes sharing every mesh would create."""
+    import threading
+    import time
+    items = multiband_sweep_items()
+    pairs, lock = set(), threading.Lock()
+
+    def solve(item, cache):
+        time.sleep(0.002)
+        with lock:
+            pairs.add((threading.get_ident(), item.mesh_key))
+        return fake_solve(item, cache)
+
+    table, n = run_sweep(items, 0, 1, solve=solve, lanes=4)
+    assert n == 64 and len(table) == 64
+    assert len({k for _t, k in pairs}) == 16 and len({t for t, _k in pairs}) == 4
+    assert len(pairs) <= 16 + 3                      # (only the tail, when fewer meshes than lanes remain, is shared)
