@@ -69,7 +69,7 @@ enum {
   PLFEM_INFO_NNZ, PLFEM_INFO_LEVELS, PLFEM_INFO_NFRONTS, PLFEM_INFO_FRONT_DOUBLES,
   PLFEM_INFO_MAX_FRONT, PLFEM_INFO_SOLVE_ENTRIES, PLFEM_INFO_FACTOR_FLOPS,
   PLFEM_INFO_T_NUMBERING_US, PLFEM_INFO_T_PATTERN_US, PLFEM_INFO_T_TREE_US, PLFEM_INFO_T_FRONTS_US,
-  PLFEM_INFO_DOFS_PER_NODE, PLFEM_INFO_COUNT
+  PLFEM_INFO_DOFS_PER_NODE, PLFEM_INFO_ARENA_DOUBLES, PLFEM_INFO_COUNT
 };
 int plfem_symbolic_info(const plfem_symbolic* sym, int64_t* info /* [PLFEM_INFO_COUNT] */);
 
@@ -77,7 +77,8 @@ int plfem_symbolic_info(const plfem_symbolic* sym, int64_t* info /* [PLFEM_INFO_
  * names: "edof"[6][ne] i32, "doflocs"[2][N] f64, "bmask"[N] u8, "interior"[nsolve] i32,
  * "rowptr"[N+1] i32, "colind"[nnz] i32, "slot_row"[nnz] i32, "nptr"[N+1] / "nadj"[6 ne] i32 / "nloc"[6 ne] u8
  * (node -> adjacent elements), "edges"[2][nedges] i32,
- * "leaf_of_elem"[ne] i32, "owner"[N] i32, "fs","fb"[nfronts] i32, "fnode_ptr","foff"[nfronts+1] i64,
+ * "leaf_of_elem"[ne] i32, "owner"[N] i32, "fs","fb"[nfronts] i32, "fnode_ptr","foff"[nfronts+1] i64, "soff"[nfronts] i64
+ * (foff: kept part of a front = [F11; F21] m x s2 then Z^T s2 x b2; soff: its Schur complement inside the level's arena),
  * "fnodes","cinv0","cinv1"[fnode_ptr[nfronts]] i32, "epos"[6][ne] i32.
  * plfem_symbolic_array_bytes returns the size in bytes or a negative error. */
 int64_t plfem_symbolic_array_bytes(const plfem_symbolic* sym, const char* name);

@@ -21,7 +21,8 @@ PLFEM_OK = 0
 PLFEM_EINVAL, PLFEM_EMESH, PLFEM_EHIP, PLFEM_ENOCONV, PLFEM_ESTATE, PLFEM_ESINGULAR = -1, -2, -3, -4, -5, -6
 BLOCKS = ("Axx", "Axy", "Ayx", "Ayy", "Minv", "Dxx", "Dxy", "Dyy")
 INFO_NAMES = ("nv", "ne", "nedges", "N", "nsolve", "nnz", "levels", "nfronts", "front_doubles", "max_front",
-              "solve_entries", "factor_flops", "t_numbering_us", "t_pattern_us", "t_tree_us", "t_fronts_us", "dofs_per_node")
+              "solve_entries", "factor_flops", "t_numbering_us", "t_pattern_us", "t_tree_us", "t_fronts_us", "dofs_per_node",
+              "arena_doubles")
 POST_NAMES = ("norm", "div_energy", "core_x", "core_y", "all_x", "all_y")
 
 # every symbol include/plfem.h declares (tests check the library exports all of them)
@@ -43,7 +44,7 @@ _ARRAY_DTYPES = {
     "interior": np.int32, "int_index": np.int32, "rowptr": np.int32, "colind": np.int32, "slot_row": np.int32,
     "nptr": np.int32, "nadj": np.int32, "nloc": np.uint8, "leaf_of_elem": np.int32, "leaf_elem_ptr": np.int32, "leaf_elems": np.int32, "epos": np.int32,
     "owner": np.int32, "fs": np.int32, "fb": np.int32, "fs_true": np.int32, "fb_true": np.int32,
-    "fnode_ptr": np.int64, "fnodes": np.int32, "cinv0": np.int32, "cinv1": np.int32, "foff": np.int64, "prow": np.int32, "npos": np.int32,
+    "fnode_ptr": np.int64, "fnodes": np.int32, "cinv0": np.int32, "cinv1": np.int32, "foff": np.int64, "soff": np.int64, "prow": np.int32, "npos": np.int32,
 }
 
 

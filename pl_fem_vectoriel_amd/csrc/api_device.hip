@@ -359,6 +359,7 @@ int create_impl(plfem_ctx* c, const plfem_symbolic* sym, int device, void* strea
   TRY(upload(c, items, &c->d_fm, fm));
   TRY(upload(c, items, &c->d_fnode_ptr, S.fnode_ptr));
   TRY(upload(c, items, &c->d_foff, S.foff));
+  TRY(upload(c, items, &c->d_soff, S.soff));
   TRY(upload(c, items, &c->d_fnodes, S.fnodes));
   TRY(upload(c, items, &c->d_cinv0, S.cinv0));
   TRY(upload(c, items, &c->d_cinv1, S.cinv1));
@@ -375,6 +376,8 @@ int create_impl(plfem_ctx* c, const plfem_symbolic* sym, int device, void* strea
   for (auto& p : c->d_vals) TRY(dalloc(c, &p, (size_t)c->nnz));
   const int64_t fnodes_total = S.fnode_ptr[S.nfronts];
   TRY(dalloc(c, &c->d_front, (size_t)S.foff[S.nfronts]));
+  c->arena_doubles = (S.arena_doubles + 31) & ~(int64_t)31;
+  TRY(dalloc(c, &c->d_schur, (size_t)2 * c->arena_doubles));
   TRY(dalloc(c, &c->d_fvec, (size_t)2 * fnodes_total * plfem::BLOCK_P));
   c->fnodes_total = fnodes_total;
   TRY(dalloc(c, &c->d_wbuf, (size_t)4 * fnodes_total * plfem::NB));   // two halves: panels of even / odd block steps
@@ -1133,6 +1136,7 @@ extern "C" int plfem_debug_copy(plfem_ctx* c, const char* name, int64_t offset, 
   std::string n(name);
   const double* src = nullptr;
   if (n == "front") src = c->d_front;
+  else if (n == "schur") src = c->d_schur;            // (arena of level l starts at (l & 1) * arena_doubles)
   else if (n == "fvec") src = c->d_fvec;
   else if (n == "wbuf") src = c->d_wbuf;
   else if (n == "rbuf") src = c->d_rbuf;

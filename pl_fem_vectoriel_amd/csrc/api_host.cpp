@@ -78,6 +78,7 @@ extern "C" int plfem_symbolic_info(const plfem_symbolic* sym, int64_t* info) {
   info[PLFEM_INFO_T_PATTERN_US] = (int64_t)(S.t_pattern * 1e6);
   info[PLFEM_INFO_T_TREE_US] = (int64_t)(S.t_tree * 1e6);
   info[PLFEM_INFO_T_FRONTS_US] = (int64_t)(S.t_fronts * 1e6);
+  info[PLFEM_INFO_ARENA_DOUBLES] = S.arena_doubles;
   info[PLFEM_INFO_DOFS_PER_NODE] = S.dpn;
   return PLFEM_OK;
 }
@@ -117,6 +118,7 @@ bool lookup(const Symbolic& S, const char* name, ArrayRef& r) {
   else if (n == "cinv0") r = aref(S.cinv0);
   else if (n == "cinv1") r = aref(S.cinv1);
   else if (n == "foff") r = aref(S.foff);
+  else if (n == "soff") r = aref(S.soff);
   else if (n == "prow") r = aref(S.prow);
   else if (n == "npos") r = aref(S.npos);
   else return false;

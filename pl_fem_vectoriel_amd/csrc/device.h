@@ -81,7 +81,10 @@ struct plfem_ctx {
   double* d_cores = nullptr;      // [64][3]
   double* d_elem = nullptr;       // [ne][8][36]
   double* d_vals[PLFEM_BLK_COUNT] = {nullptr};
-  double* d_front = nullptr;      // dense fronts
+  double* d_front = nullptr;      // what a front keeps: [F11; F21] (m x s2) and Z^T (s2 x b2), see symbolic.h
+  double* d_schur = nullptr;      // two arenas (even / odd tree levels) of arena_doubles for the Schur complements in flight
+  int64_t arena_doubles = 0;
+  int64_t* d_soff = nullptr;      // per front: offset of its Schur complement inside its level's arena
   double* d_fvec = nullptr;       // per-front solve vectors in front order, offset 2*fnode_ptr[f]: right-hand side (owned rows)
   double *d_u0 = nullptr, *d_u1 = nullptr;   // updates pushed into a front's rows by its left / right child (forward sweep)
   double* d_xl = nullptr;         // complete local solution of every front (backward sweep)

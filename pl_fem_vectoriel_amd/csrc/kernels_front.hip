@@ -3,8 +3,11 @@
 // Replaces splu((A - sigma B).tocsc()) and lu.solve() that the reference reaches through
 // eigsh(..., sigma=...) (reference solver_fem.py:197 -> scipy arpack.py:915, 920-928).
 //
-// Every front F (order m, column major, symmetric) holds [F11 F12; F21 F22] with the first s2 DOFs
-// fully summed.  The factorisation is a right-looking block LDL^T of those s2 pivots, NB at a time:
+// Every front F (order m, symmetric) is [F11 F12; F21 F22] with the first s2 DOFs fully summed.  Storage (symbolic.h):
+// the columns of [F11; F21] (m x s2, leading dimension m) are kept, F22 -- the Schur complement, needed only until the
+// parent has gathered it -- lives in one of two level arenas (b2 x b2, leading dimension b2), F12 is never formed
+// (the trailing matrix is maintained in its lower triangle) and its place is taken, after the factorisation, by Z^T
+// (s2 x b2, leading dimension s2, right behind [F11; F21]).  The factorisation is a right-looking block LDL^T of those s2 pivots, NB at a time:
 //     F11 = L11 D L11^T,   L21 = F21 L11^-T D^-1,   S = F22 - L21 D L21^T   (S: gathered by the parent)
 // and, interleaved with it, the explicit inverse of the unit lower triangular L11 (a triangular
 // inverse is benign numerically, unlike F11^-1: the stiffness scale of near-degenerate elements
@@ -24,6 +27,12 @@ namespace {
 
 typedef double v4d __attribute__((ext_vector_type(4)));
 
+// the Schur complement block of front f: arena of its tree level (fronts are numbered in heap order)
+__device__ __forceinline__ double* schur_of(int f, const int64_t* __restrict__ soff, double* __restrict__ schur, int64_t arena) {
+  const int level = 31 - __clz(f + 1);
+  return schur + (level & 1) * arena + soff[f];
+}
+
 // ------------------------------------------------------------------------------------------------
 // front assembly
 // ------------------------------------------------------------------------------------------------
@@ -31,21 +40,31 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 // order, one block per front, 144 lanes per element) -- element-based multifrontal assembly.
 template <int sh>
 __global__ __launch_bounds__(256) void k_leaf_assemble(
-    int first_front, int ne, double sigma, const int32_t* __restrict__ fm, const int64_t* __restrict__ foff,
+    int first_front, int ne, double sigma, const int32_t* __restrict__ fs2, const int32_t* __restrict__ fm,
+    const int64_t* __restrict__ foff, const int64_t* __restrict__ soff,
     const int64_t* __restrict__ fnode_ptr, const int32_t* __restrict__ fnodes,
     const int32_t* __restrict__ leaf_elem_ptr, const int32_t* __restrict__ leaf_elems,
-    const int32_t* __restrict__ epos, const double* __restrict__ elem, double* __restrict__ front) {
+    const int32_t* __restrict__ epos, const double* __restrict__ elem, double* __restrict__ front,
+    double* __restrict__ schur, int64_t arena) {
   const int lf = blockIdx.x;
   const int f = first_front + lf;
-  const int m = fm[f];
+  const int m = fm[f], s2 = fs2[f], b2 = m - s2;
   constexpr int dpn = sh + 1;                // unknowns per node: local DOF i of a front = (node i >> sh, component i & sh)
-  double* F = front + foff[f];
+  double* F = front + foff[f];               // columns < s2
+  double* S = schur_of(f, soff, schur, arena);   // columns >= s2, rows >= s2
+  // entry (row i, column j) of the front; (i < s2 <= j is F12: not stored, the lower triangle is what everything reads)
+  auto at = [&](int i, int j) -> int64_t { return j < s2 ? (int64_t)j * m + i : (i >= s2 ? -2 - ((int64_t)(j - s2) * b2 + (i - s2)) : -1); };
   const int tid = threadIdx.x;
-  // (the leaf fronts are contiguous in memory and were zeroed by one memset before this launch)
+  // (the leaf fronts are contiguous in memory, and so are their Schur complements in the arena: zeroed by two memsets
+  // before this launch)
   const int32_t* fn = fnodes + fnode_ptr[f];
   for (int q = tid; q < (m >> sh); q += 256)
     if (fn[q] < 0) {   // padding node: unit pivot, no coupling
-      for (int cc = 0; cc < dpn; ++cc) F[(int64_t)(dpn * q + cc) * m + dpn * q + cc] = 1.0;
+      for (int cc = 0; cc < dpn; ++cc) {
+        const int d = dpn * q + cc;
+        if (d < s2) F[(int64_t)d * m + d] = 1.0;
+        else S[(int64_t)(d - s2) * b2 + (d - s2)] = 1.0;
+      }
     }
   __syncthreads();
   constexpr int nd = 6 * dpn;                // DOFs of one element: 12 (Hx, Hy) or 6 (scalar)
@@ -72,13 +91,14 @@ __global__ __launch_bounds__(256) void k_leaf_assemble(
         const double* em = elem + (size_t)e * ELEM_STRIDE + a * 6 + b;
         double v = em[blk_a * 36];
         if (diag_blk) v -= sigma * em[PLFEM_BLK_MINV * 36];
-        if (pa >= 0 && pb >= 0) { dst[t] = (int64_t)(dpn * pb + cb) * m + (dpn * pa + ca); val[t] = v; }
+        if (pa >= 0 && pb >= 0) { dst[t] = at(dpn * pa + ca, dpn * pb + cb); val[t] = v; }
       }
     }
 #pragma unroll
     for (int t = 0; t < EB; ++t) {
       if (t < nb) {
         if (dst[t] >= 0) F[dst[t]] += val[t];
+        else if (dst[t] <= -2) S[-2 - dst[t]] += val[t];
         __syncthreads();
       }
     }
@@ -90,24 +110,27 @@ __global__ __launch_bounds__(256) void k_leaf_assemble(
 template <int sh>
 __global__ __launch_bounds__(256) void k_front_gather(
     const int2* __restrict__ tiles, const int32_t* __restrict__ fs2, const int32_t* __restrict__ fm,
-    const int64_t* __restrict__ foff, const int64_t* __restrict__ fnode_ptr, const int32_t* __restrict__ fnodes,
-    const int32_t* __restrict__ cinv0, const int32_t* __restrict__ cinv1, double* __restrict__ front) {
+    const int64_t* __restrict__ foff, const int64_t* __restrict__ soff, const int64_t* __restrict__ fnode_ptr,
+    const int32_t* __restrict__ fnodes, const int32_t* __restrict__ cinv0, const int32_t* __restrict__ cinv1,
+    double* __restrict__ front, double* __restrict__ schur, int64_t arena) {
   const int2 job = tiles[blockIdx.x];                    // (front, tx | ty << 16): 64 x 64 entries
   const int f = job.x;
-  const int m = fm[f];
+  const int m = fm[f], s2 = fs2[f], b2 = m - s2;
   constexpr int dpn = sh + 1;
   const int i = (job.y & 0xffff) * 64 + (threadIdx.x & 63);
   const int j0 = ((job.y >> 16) * 4 + (threadIdx.x >> 6)) * 16;
   if (i >= m || j0 >= m) return;
+  if (j0 >= s2 && i < s2) return;                        // F12 is not stored (s2 and j0 are multiples of 16)
   const int64_t np = fnode_ptr[f];
   const int qi = i >> sh, ci = i & sh;
   const int c0i = cinv0[np + qi], c1i = cinv1[np + qi];
   const bool dummy_i = fnodes[np + qi] < 0;
   const int ch0 = 2 * f + 1, ch1 = 2 * f + 2;
-  const int m0 = fm[ch0], s0 = fs2[ch0], m1 = fm[ch1], s1 = fs2[ch1];
-  const double* F0 = front + foff[ch0];
-  const double* F1 = front + foff[ch1];
+  const int b0 = fm[ch0] - fs2[ch0], b1 = fm[ch1] - fs2[ch1];
+  const double* S0 = schur_of(ch0, soff, schur, arena);   // the children's Schur complements (the other arena)
+  const double* S1 = schur_of(ch1, soff, schur, arena);
   double* F = front + foff[f];
+  double* S = schur_of(f, soff, schur, arena);
   // the column-node index pairs first (8 nodes at two DOFs per node, 16 at one), then all 32 child entries: two
   // memory round trips for 16 columns
   int c0j[16 >> sh], c1j[16 >> sh];
@@ -123,19 +146,21 @@ __global__ __launch_bounds__(256) void k_front_gather(
     double a = 0.0, b = 0.0;
     // (row, column) = (larger, smaller) local index: only the lower triangle of a Schur complement is maintained
     if (c0i >= 0 && c0j[q] >= 0) {
-      const int bi = s0 + dpn * c0i + ci, bj = s0 + dpn * c0j[q] + cj;
-      a = F0[(int64_t)min(bi, bj) * m0 + max(bi, bj)];
+      const int bi = dpn * c0i + ci, bj = dpn * c0j[q] + cj;
+      a = S0[(int64_t)min(bi, bj) * b0 + max(bi, bj)];
     }
     if (c1i >= 0 && c1j[q] >= 0) {
-      const int bi = s1 + dpn * c1i + ci, bj = s1 + dpn * c1j[q] + cj;
-      b = F1[(int64_t)min(bi, bj) * m1 + max(bi, bj)];
+      const int bi = dpn * c1i + ci, bj = dpn * c1j[q] + cj;
+      b = S1[(int64_t)min(bi, bj) * b1 + max(bi, bj)];
     }
     v[jj] = a + b;
   }
 #pragma unroll
   for (int jj = 0; jj < 16; ++jj) {
     const int j = j0 + jj;
-    F[(int64_t)j * m + i] = (dummy_i && i == j) ? 1.0 : v[jj];
+    const double val = (dummy_i && i == j) ? 1.0 : v[jj];
+    if (j0 < s2) F[(int64_t)j * m + i] = val;
+    else S[(int64_t)(j - s2) * b2 + (i - s2)] = val;
   }
 }
 
@@ -561,7 +586,8 @@ __device__ __forceinline__ void ldl_invrow_block(int f, int bx, int kb, const in
 template <int MODE>
 __device__ __forceinline__ void ldl_update_tile(const int2 job, int kb, const int32_t* __restrict__ fs2,
                                                 const int32_t* __restrict__ fm, const int64_t* __restrict__ foff,
-                                                const int64_t* __restrict__ fnode_ptr, double* __restrict__ front,
+                                                const int64_t* __restrict__ soff, const int64_t* __restrict__ fnode_ptr,
+                                                double* __restrict__ front, double* __restrict__ schur, int64_t arena,
                                                 const double* __restrict__ wbuf, const double* __restrict__ rbuf,
                                                 const double* __restrict__ wbuf_prev, const double* __restrict__ rbuf_prev) {
   // job = (front, tx | ty << 16): a 64 x 64 block of the trailing matrix
@@ -584,19 +610,25 @@ __device__ __forceinline__ void ldl_update_tile(const int2 job, int kb, const in
   // last, partial block) -- everything to their right is updated once, by the rank-64 pass after that step
   const bool next_only = MODE == 0 && t0 < s2;
   if (next_only && j0 != t0) return;
-  double* F = front + foff[f];
+  double* F = front + foff[f];                          // columns < s2 (all rows)
+  double* S = schur_of(f, soff, schur, arena);          // columns >= s2, rows >= s2
+  const int b2 = m - s2;
   const int lr = lane & 15, lk = lane >> 4;
   const bool iv1 = i0 + 16 < m, jv1 = j0 + 16 < m && !(next_only && s2 - t0 <= 16);
+  // a 16 x 16 quadrant lies on one side of s2 in either direction (s2, i0, j0 are multiples of 16); rows < s2 <= columns
+  // is F12, which is not stored (it can only come up in the quadrant above the diagonal of a diagonal tile)
+  auto quad_ok = [&](int tj, int ti) { return (tj == 0 || jv1) && (ti == 0 || iv1) && !(j0 + 16 * tj >= s2 && i0 + 16 * ti < s2); };
+  auto addr = [&](int tj, int ti, int r) -> double* {
+    const int j = j0 + 16 * tj + lk + 4 * r, i = i0 + 16 * ti + lr;
+    return j0 + 16 * tj < s2 ? F + (int64_t)j * m + i : S + (int64_t)(j - s2) * b2 + (i - s2);
+  };
   double fv[2][2][4];
 #pragma unroll
   for (int tj = 0; tj < 2; ++tj)
 #pragma unroll
     for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const bool ok = (tj == 0 || jv1) && (ti == 0 || iv1);
-        fv[tj][ti][r] = ok ? F[(int64_t)(j0 + 16 * tj + lk + 4 * r) * m + (i0 + 16 * ti + lr)] : 0.0;
-      }
+      for (int r = 0; r < 4; ++r) fv[tj][ti][r] = quad_ok(tj, ti) ? *addr(tj, ti, r) : 0.0;
   v4d acc[2][2];
 #pragma unroll
   for (int tj = 0; tj < 2; ++tj)
@@ -628,14 +660,12 @@ __device__ __forceinline__ void ldl_update_tile(const int2 job, int kb, const in
   const int nbn = (i0 == t0 && j0 == t0 && t0 < s2) ? min(NB, s2 - t0) : 0;
 #pragma unroll
   for (int tj = 0; tj < 2; ++tj) {
-    if (tj == 1 && !jv1) continue;
 #pragma unroll
     for (int ti = 0; ti < 2; ++ti) {
-      if (ti == 1 && !iv1) continue;
+      if (!quad_ok(tj, ti)) continue;
       if (16 * tj < nbn && 16 * ti < nbn) continue;
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-        F[(int64_t)(j0 + 16 * tj + lk + 4 * r) * m + (i0 + 16 * ti + lr)] = fv[tj][ti][r] - acc[tj][ti][r];
+      for (int r = 0; r < 4; ++r) *addr(tj, ti, r) = fv[tj][ti][r] - acc[tj][ti][r];
     }
   }
 }
@@ -701,7 +731,8 @@ template <int MODE>
 __global__ __launch_bounds__(256) void k_ldl_update(int un, int n_inv, int n_look, const int2* __restrict__ tiles,
                                                     const int32_t* __restrict__ forder, int kb, const int32_t* __restrict__ fs2,
                                                     const int32_t* __restrict__ fm, const int64_t* __restrict__ foff,
-                                                    const int64_t* __restrict__ fnode_ptr, double* __restrict__ front,
+                                                    const int64_t* __restrict__ soff, const int64_t* __restrict__ fnode_ptr,
+                                                    double* __restrict__ front, double* __restrict__ schur, int64_t arena,
                                                     const double* __restrict__ dinv, double* __restrict__ dinv_next,
                                                     double* __restrict__ delta, const double* __restrict__ tbuf,
                                                     const double* __restrict__ wbuf, const double* __restrict__ rbuf,
@@ -716,7 +747,7 @@ __global__ __launch_bounds__(256) void k_ldl_update(int un, int n_inv, int n_loo
   }
   const int bid = blockIdx.x - n_look;
   if (bid < un) {
-    ldl_update_tile<MODE>(tiles[bid], kb, fs2, fm, foff, fnode_ptr, front, wbuf, rbuf, wbuf_prev, rbuf_prev);
+    ldl_update_tile<MODE>(tiles[bid], kb, fs2, fm, foff, soff, fnode_ptr, front, schur, arena, wbuf, rbuf, wbuf_prev, rbuf_prev);
     return;
   }
   const int e = bid - un;
@@ -742,8 +773,8 @@ __global__ __launch_bounds__(256) void k_ldl_update(int un, int n_inv, int n_loo
 
 // ---- Z = L21 L11^-1 (formed once per front after its LDL^T): with Z in place of L21 the forward
 // sweep of a front is ONE product [L11^-1; Z] r and the backward sweep ONE product [L11^-1; -Z]^T [D^-1 y; x_b].
-// Z^T (s2 x b2) is written into the F12 mirror region (F21 = L21 and the upper mirror of L11^-1 are
-// only read), 32x32 tile per wave on v_mfma_f64_16x16x4_f64; k_mirror_z then copies it back into F21.
+// Z^T (s2 x b2) is written behind [F11; F21] (F21 = L21 and the upper mirror of L11^-1 are only read), 32x32 tile per
+// wave on v_mfma_f64_16x16x4_f64; k_mirror_z then copies it back into F21.
 __global__ __launch_bounds__(256) void k_form_z(const int2* __restrict__ tiles, const int32_t* __restrict__ fs2,
                                                 const int32_t* __restrict__ fm, const int64_t* __restrict__ foff,
                                                 double* __restrict__ front) {
@@ -782,19 +813,20 @@ __global__ __launch_bounds__(256) void k_form_z(const int2* __restrict__ tiles, 
       acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[t], x1[t], acc[1][1], 0, 0, 0);
     }
   }
-  // D[row = b (lk + 4r)][col = c (lr)] -> Z^T[c, b] at F[c + (s2 + b) m]: lanes lr contiguous
+  // D[row = b (lk + 4r)][col = c (lr)] -> Z^T[c, b] at FZ[c + b s2] (FZ: s2 x b2 behind [F11; F21]): lanes lr contiguous
+  double* FZ = F + (int64_t)m * s2;
   for (int tb = 0; tb < 2; ++tb) {
     if (tb == 1 && !bv1) continue;
     for (int tc = 0; tc < 2; ++tc) {
       if (tc == 1 && !cv1) continue;
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        F[(int64_t)(s2 + b0 + 16 * tb + lk + 4 * r) * m + (c0 + 16 * tc + lr)] = acc[tb][tc][r];
+        FZ[(int64_t)(b0 + 16 * tb + lk + 4 * r) * s2 + (c0 + 16 * tc + lr)] = acc[tb][tc][r];
     }
   }
 }
 
-// F21[b, c] = F12[c, b] through a 32x32 LDS tile
+// F21[b, c] = Z^T[c, b] through a 32x32 LDS tile
 __global__ __launch_bounds__(256) void k_mirror_z(const int2* __restrict__ tiles, const int32_t* __restrict__ fs2,
                                                   const int32_t* __restrict__ fm, const int64_t* __restrict__ foff,
                                                   double* __restrict__ front) {
@@ -810,7 +842,7 @@ __global__ __launch_bounds__(256) void k_mirror_z(const int2* __restrict__ tiles
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
   for (int yy = ty; yy < 32; yy += 8) {
     int c = c0 + tx, b = b0 + yy;
-    tile[yy][tx] = (c < s2 && b < b2) ? F[(int64_t)(s2 + b) * m + c] : 0.0;       // Z^T[c, b]
+    tile[yy][tx] = (c < s2 && b < b2) ? F[(int64_t)m * s2 + (int64_t)b * s2 + c] : 0.0;       // Z^T[c, b]
   }
   __syncthreads();
   for (int yy = ty; yy < 32; yy += 8) {
@@ -831,19 +863,29 @@ void launch_factor(plfem_ctx* c, double sigma, int stop_level, int stop_step, in
     if (lev == c->L) {
       const int64_t lo = c->S->foff[li.first], hi = c->S->foff[li.first + li.count];
       (void)hipMemsetAsync(c->d_front + lo, 0, sizeof(double) * (size_t)(hi - lo), st);
+      int64_t sch = 0;                                          // the leaf level's Schur complements in its arena
+      for (int f = li.first; f < li.first + li.count; ++f) {
+        const int64_t b2 = (int64_t)c->dpn * c->S->fb[f];
+        sch = std::max(sch, c->S->soff[f] + b2 * b2);
+      }
+      (void)hipMemsetAsync(c->d_schur + (size_t)(lev & 1) * c->arena_doubles, 0, sizeof(double) * (size_t)sch, st);
       if (c->sh)
-        hipLaunchKernelGGL(k_leaf_assemble<1>, dim3(li.count), dim3(256), 0, st, li.first, c->ne, sigma, c->d_fm, c->d_foff,
-                           c->d_fnode_ptr, c->d_fnodes, c->d_leaf_elem_ptr, c->d_leaf_elems, c->d_epos, c->d_elem, c->d_front);
+        hipLaunchKernelGGL(k_leaf_assemble<1>, dim3(li.count), dim3(256), 0, st, li.first, c->ne, sigma, c->d_fs2, c->d_fm, c->d_foff,
+                           c->d_soff, c->d_fnode_ptr, c->d_fnodes, c->d_leaf_elem_ptr, c->d_leaf_elems, c->d_epos, c->d_elem,
+                           c->d_front, c->d_schur, c->arena_doubles);
       else
-        hipLaunchKernelGGL(k_leaf_assemble<0>, dim3(li.count), dim3(256), 0, st, li.first, c->ne, sigma, c->d_fm, c->d_foff,
-                           c->d_fnode_ptr, c->d_fnodes, c->d_leaf_elem_ptr, c->d_leaf_elems, c->d_epos, c->d_elem, c->d_front);
+        hipLaunchKernelGGL(k_leaf_assemble<0>, dim3(li.count), dim3(256), 0, st, li.first, c->ne, sigma, c->d_fs2, c->d_fm, c->d_foff,
+                           c->d_soff, c->d_fnode_ptr, c->d_fnodes, c->d_leaf_elem_ptr, c->d_leaf_elems, c->d_epos, c->d_elem,
+                           c->d_front, c->d_schur, c->arena_doubles);
     } else if (li.gather_n > 0) {
       if (c->sh)
         hipLaunchKernelGGL(k_front_gather<1>, dim3(li.gather_n), dim3(256), 0, st, c->d_tiles + li.gather_off, c->d_fs2, c->d_fm,
-                           c->d_foff, c->d_fnode_ptr, c->d_fnodes, c->d_cinv0, c->d_cinv1, c->d_front);
+                           c->d_foff, c->d_soff, c->d_fnode_ptr, c->d_fnodes, c->d_cinv0, c->d_cinv1, c->d_front, c->d_schur,
+                           c->arena_doubles);
       else
         hipLaunchKernelGGL(k_front_gather<0>, dim3(li.gather_n), dim3(256), 0, st, c->d_tiles + li.gather_off, c->d_fs2, c->d_fm,
-                           c->d_foff, c->d_fnode_ptr, c->d_fnodes, c->d_cinv0, c->d_cinv1, c->d_front);
+                           c->d_foff, c->d_soff, c->d_fnode_ptr, c->d_fnodes, c->d_cinv0, c->d_cinv1, c->d_front, c->d_schur,
+                           c->arena_doubles);
     }
     if (lev == stop_level && stop_stage == 0) return;
     // Fronts of the level in order of decreasing s2 (c->forder): the fronts still active at block step kb are a
@@ -894,12 +936,12 @@ void launch_factor(plfem_ctx* c, double sigma, int stop_level, int stop_step, in
       const unsigned gridB = (unsigned)(n_look + un + nact * (n_inv + 1));
       if ((kb & 1) == 0)
         hipLaunchKernelGGL(k_ldl_update<0>, dim3(gridB), dim3(256), 0, st, un, n_inv, n_look, ut, ford, kb, c->d_fs2, c->d_fm,
-                           c->d_foff, c->d_fnode_ptr, c->d_front, dinv_cur, dinv_nxt, c->d_delta, c->d_tbuf, wb, rb, wb, rb,
-                           c->d_counters);
+                           c->d_foff, c->d_soff, c->d_fnode_ptr, c->d_front, c->d_schur, c->arena_doubles, dinv_cur, dinv_nxt,
+                           c->d_delta, c->d_tbuf, wb, rb, wb, rb, c->d_counters);
       else
         hipLaunchKernelGGL(k_ldl_update<1>, dim3(gridB), dim3(256), 0, st, un, n_inv, n_look, ut, ford, kb, c->d_fs2, c->d_fm,
-                           c->d_foff, c->d_fnode_ptr, c->d_front, dinv_cur, dinv_nxt, c->d_delta, c->d_tbuf, wb, rb, c->d_wbuf,
-                           c->d_rbuf, c->d_counters);
+                           c->d_foff, c->d_soff, c->d_fnode_ptr, c->d_front, c->d_schur, c->arena_doubles, dinv_cur, dinv_nxt,
+                           c->d_delta, c->d_tbuf, wb, rb, c->d_wbuf, c->d_rbuf, c->d_counters);
       if (stop_here && (stop_stage == 3 || stop_stage == 4)) return;
     }
     if (li.formz_n > 0 && stop_level >= 0) {          // (debug run that stops after a level: its Z now)

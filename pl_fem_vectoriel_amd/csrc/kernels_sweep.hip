@@ -235,12 +235,16 @@ __device__ __forceinline__ void fwd_rows_body(const SweepArgs& A, int f, int rb,
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int need = min(s2, j0 + RB);                      // rows < s2 only read r[0 .. row]
   const double* F = A.front + A.foff[f];
+  // row r of [L11^-1; Z] as a contiguous run: r < s2 -> column r of [F11; F21] (the upper mirror of L11^-1), r >= s2 ->
+  // column r - s2 of Z^T (s2 x b2, stored behind [F11; F21])
   int ce[R], cmax = 0;
+  const double* rowp[R];
 #pragma unroll
   for (int q = 0; q < R; ++q) {
     const int r = j0 + wave + NW * q;
     ce[q] = r < m ? ((r < s2) ? r + 1 : s2) : 0;
     cmax = max(cmax, ce[q]);
+    rowp[q] = r < s2 ? F + (int64_t)r * m : F + (int64_t)m * s2 + (int64_t)(r - s2) * s2;
   }
   // the lane that will hold output (q, u) after the reduction requests that row's epilogue operands now
   const int oidx = multi_reduce_index<V>(lane & (V - 1));
@@ -254,7 +258,7 @@ __device__ __forceinline__ void fwd_rows_body(const SweepArgs& A, int f, int rb,
   for (int t = 0; t < UNR; ++t) {
     const int i = 64 * t + lane;
 #pragma unroll
-    for (int q = 0; q < R; ++q) a0[t][q] = (i < ce[q]) ? F[(int64_t)(j0 + wave + NW * q) * m + i] : 0.0;
+    for (int q = 0; q < R; ++q) a0[t][q] = (i < ce[q]) ? rowp[q][i] : 0.0;
   }
   if (tid < need) {
 #pragma unroll
@@ -282,7 +286,7 @@ __device__ __forceinline__ void fwd_rows_body(const SweepArgs& A, int f, int rb,
     for (int t = 0; t < UNR; ++t) {
       const int i = c + 64 * t + lane;
 #pragma unroll
-      for (int q = 0; q < R; ++q) a[t][q] = (i < ce[q]) ? F[(int64_t)(j0 + wave + NW * q) * m + i] : 0.0;
+      for (int q = 0; q < R; ++q) a[t][q] = (i < ce[q]) ? rowp[q][i] : 0.0;
     }
 #pragma unroll
     for (int t = 0; t < UNR; ++t) {
@@ -374,13 +378,16 @@ __device__ __forceinline__ void bwd_tile_body(const SweepArgs& A, int f, int rb,
   st.request_index(A, np, s2, r0 + tid, r0 + tid < m);
   const int r = r0 + lane;
   const bool valid = r < s2;
-  // element (j = r, i) of [L11^-T | Z^T] at F[r + i m], i in [r, m)
+  // element (j = r, i) of [L11^-T | Z^T]: column i of [F11; F21] at row r for i < s2 (upper mirror), of Z^T (leading
+  // dimension s2, behind [F11; F21]) for i >= s2
   const double* p = A.front + A.foff[f] + r;
+  const double* pz = A.front + A.foff[f] + (int64_t)m * s2 + r - (int64_t)s2 * s2;     // pz[i s2] for i >= s2
+  auto entry = [&](int i) { return i < s2 ? p[(int64_t)i * m] : pz[(int64_t)i * s2]; };
   const int cb = valid ? r : m, ce = m;
   const int cstart = cb + ((wave - cb) & (NW - 1));
   double a0[TB];
 #pragma unroll
-  for (int t = 0; t < TB; ++t) a0[t] = (cstart + NW * t < ce) ? p[(int64_t)(cstart + NW * t) * m] : 0.0;
+  for (int t = 0; t < TB; ++t) a0[t] = (cstart + NW * t < ce) ? entry(cstart + NW * t) : 0.0;
   st.request_value(A, npp);
   stage_bwd_rest<P, false>(A, sv, r0, m, s2, np, npp, NW * 64, tid, publish);
   st.template finish<false>(A, sv, np, publish);
@@ -399,7 +406,7 @@ __device__ __forceinline__ void bwd_tile_body(const SweepArgs& A, int f, int rb,
   for (int c = cstart + NW * TB; c < ce; c += TB * NW) {
     double a[TB];
 #pragma unroll
-    for (int t = 0; t < TB; ++t) a[t] = (c + NW * t < ce) ? p[(int64_t)(c + NW * t) * m] : 0.0;
+    for (int t = 0; t < TB; ++t) a[t] = (c + NW * t < ce) ? entry(c + NW * t) : 0.0;
 #pragma unroll
     for (int t = 0; t < TB; ++t) {
       if (c + NW * t < ce) {

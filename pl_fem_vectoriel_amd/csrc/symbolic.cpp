@@ -810,10 +810,21 @@ std::string build_fronts(Symbolic& S, int nthreads) {
     int64_t mn = S.fs[f] + S.fb[f];
     S.fnode_ptr[f + 1] = S.fnode_ptr[f] + mn;
     int64_t m = S.dpn * mn, s2 = S.dpn * (int64_t)S.fs[f];
-    S.foff[f + 1] = S.foff[f] + m * m;
+    S.foff[f + 1] = S.foff[f] + s2 * (m + (m - s2));     // [F11; F21] and Z^T; the Schur complement lives in a level arena
     S.factor_flops += (double)s2 * (double)m * (double)m;     // ~ block LDL^T + triangular inverse
     S.solve_entries += s2 * (m + (m - s2));
     S.max_m = std::max<int>(S.max_m, (int)m);
+  }
+  S.soff.assign((size_t)nf, 0);
+  S.arena_doubles = 0;
+  for (int lev = 0; (1 << lev) - 1 < nf; ++lev) {
+    int64_t off = 0;
+    for (int f = (1 << lev) - 1; f < std::min(nf, (1 << (lev + 1)) - 1); ++f) {
+      const int64_t b2 = S.dpn * (int64_t)S.fb[f];
+      S.soff[f] = off;
+      off += b2 * b2;
+    }
+    S.arena_doubles = std::max(S.arena_doubles, off);
   }
   const int64_t tot = S.fnode_ptr[nf];
   S.fnodes.resize(tot);                  // uninitialised: every entry (padding included) is written below

@@ -66,7 +66,16 @@ struct Symbolic {
   rawvec_i32 cinv0, cinv1;             // per local node of an internal front: index in child's boundary list or -1
   rawvec_i32 prow;                     // per local node: local node index in the PARENT front (boundary nodes), -1 = none
   std::vector<int32_t> npos;           // [N] node -> front-order offset of its component 0: 2 fnode_ptr[owner] + dpn q, -1 = Dirichlet
-  std::vector<int64_t> foff;           // [nfronts+1] offsets (in doubles) of the dense front matrices, m = dpn (fs+fb)
+  // Storage of a front (m = dpn (fs + fb) DOFs, s2 = dpn fs owned, b2 = m - s2 boundary), what the factorisation KEEPS:
+  //   foff[f]           : [F11; F21], m x s2 column major (leading dimension m); after the factorisation lower(F11) = L11^-1,
+  //                       upper(F11) = L11^-T, F21 = Z
+  //   foff[f] + m s2    : Z^T, s2 x b2 column major (leading dimension s2)
+  // and what it only needs until the parent has gathered it, the Schur complement F22 (b2 x b2, leading dimension b2):
+  //   soff[f]           : offset inside the arena of the front's tree level; two arenas (even / odd levels) of
+  //                       arena_doubles each are alive at a time
+  std::vector<int64_t> foff;           // [nfronts+1]
+  std::vector<int64_t> soff;           // [nfronts]
+  int64_t arena_doubles = 0;           // max over the levels of sum b2^2
   std::vector<int32_t> owner;          // [N] front that eliminates the node, -1 for Dirichlet nodes
   // statistics
   double factor_flops = 0.0;           // sum over fronts of 2 * s2 * m^2  (block Gauss-Jordan sweep)

@@ -30,7 +30,7 @@ print("elem Axx max rel diff", np.abs(eb[:, 0] - Axx).max() / np.abs(Axx).max(),
 
 def gpu_front(f):
     m = T.m(f)
-    return ctx.debug_copy("front", T.foff[f], m * m).reshape(m, m).T   # column major -> [row, col]
+    return T.device_front(ctx, f, with_schur=True)   # [row, col]; the Schur complement while its level arena is alive
 
 def cmp(name, a, b, tol=1e-9):
     sc = max(np.abs(b).max(), 1e-300)

@@ -35,6 +35,26 @@ class FrontTree:
     def nodes(self, f):
         return self.fnodes[self.fptr[f]:self.fptr[f] + self.fs[f] + self.fb[f]]
 
+    def device_front(self, ctx, f, with_schur=False):
+        """Front f as the device context stores it, rebuilt as one m x m array [row, col] (symbolic.h): [F11; F21] (m x s2,
+        leading dimension m) and Z^T (s2 x b2, leading dimension s2) from the permanent storage; the Schur complement F22
+        (b2 x b2) from the arena of the front's tree level -- only meaningful while that arena has not been reused (after a
+        complete factorisation: levels 0 and 1), NaN otherwise."""
+        m, s2 = self.m(f), self.s2(f)
+        b2 = m - s2
+        off = int(self.foff[f])
+        F = np.full((m, m), np.nan)
+        if s2:
+            F[:, :s2] = ctx.debug_copy("front", off, m * s2).reshape(s2, m).T
+            if b2:
+                F[:s2, s2:] = ctx.debug_copy("front", off + m * s2, s2 * b2).reshape(b2, s2).T
+        if with_schur and b2:
+            level = int(np.floor(np.log2(f + 1)))
+            arena = (int(self.sym.info["arena_doubles"]) + 31) & ~31
+            soff = int(self.sym.array("soff")[f])
+            F[s2:, s2:] = ctx.debug_copy("schur", (level & 1) * arena + soff, b2 * b2).reshape(b2, b2).T
+        return F
+
 
 def element_K(em, k0sq, sigma):
     """12x12 element matrices of K = A - sigma B in the interleaved (node, component) DOF order."""

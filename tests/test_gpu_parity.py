@@ -127,11 +127,14 @@ def test_fronts_match_numpy_emulation(small):
     assert P.ctx.timings()["pivot_perturbations"] == 0
     for f in [0, 1, 2, 5, 11, T.leaf0 - 1, T.leaf0, T.leaf0 + 7, T.nf - 1] + list(range(17, T.nf, 97)):
         m, s2 = T.m(f), T.s2(f)
-        Fg = P.ctx.debug_copy("front", T.foff[f], m * m).reshape(m, m).T
-        for name, a, b in (("F11", Fg[:s2, :s2], Fs[f][:s2, :s2]), ("Z", Fg[s2:, :s2], Fs[f][s2:, :s2]),
-                           ("ZT", Fg[:s2, s2:], Fs[f][:s2, s2:]),
-                           # the Schur complement is maintained in its lower triangle only (symmetric)
-                           ("S", np.tril(Fg[s2:, s2:]), np.tril(Fs[f][s2:, s2:]))):
+        # the Schur complement of a front lives in the arena of its tree level until the level two above it reuses the
+        # arena: after a complete factorisation only the two fronts of level 1 still have theirs
+        keep_s = f in (1, 2)
+        Fg = T.device_front(P.ctx, f, with_schur=keep_s)
+        blocks = [("F11", Fg[:s2, :s2], Fs[f][:s2, :s2]), ("Z", Fg[s2:, :s2], Fs[f][s2:, :s2]), ("ZT", Fg[:s2, s2:], Fs[f][:s2, s2:])]
+        if keep_s:       # maintained in its lower triangle only (symmetric)
+            blocks.append(("S", np.tril(Fg[s2:, s2:]), np.tril(Fs[f][s2:, s2:])))
+        for name, a, b in blocks:
             if a.size:
                 assert np.abs(a - b).max() <= 1e-8 * max(np.abs(b).max(), 1e-300), (f, name)
         if s2:

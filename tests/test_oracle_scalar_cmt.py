@@ -86,7 +86,8 @@ def test_host_analysis_with_one_unknown_per_node():
         assert (fs % q == 0).all() and (fb % q == 0).all()
         foff = S.array("foff")
         m = S.dofs_per_node * (fs + fb)
-        assert np.array_equal(np.diff(foff), m.astype(np.int64) ** 2)
+        s2 = (S.dofs_per_node * fs).astype(np.int64)
+        assert np.array_equal(np.diff(foff), s2 * (2 * m.astype(np.int64) - s2))     # [F11; F21] m x s2 + Z^T s2 x b2
         # front-order maps: every kept node has exactly one owned slot; prow inverts the child maps
         fp, fn, fst = S.array("fnode_ptr"), S.array("fnodes"), S.array("fs_true")
         npos, prow, c0, c1 = S.array("npos"), S.array("prow"), S.array("cinv0"), S.array("cinv1")
