@@ -380,11 +380,19 @@ int create_impl(plfem_ctx* c, const plfem_symbolic* sym, int device, void* strea
   TRY(dalloc(c, &c->d_schur, (size_t)2 * c->arena_doubles));
   TRY(dalloc(c, &c->d_fvec, (size_t)2 * fnodes_total * plfem::BLOCK_P));
   c->fnodes_total = fnodes_total;
-  TRY(dalloc(c, &c->d_wbuf, (size_t)4 * fnodes_total * plfem::NB));   // two halves: panels of even / odd block steps
-  TRY(dalloc(c, &c->d_rbuf, (size_t)4 * fnodes_total * plfem::NB));
+  // panel / block-row scratch of the factorisation: one tree level is in flight at a time, so these are sized by the
+  // level with the most (padded) nodes and addressed relative to the level's first front (launch_factor)
+  int64_t level_nodes = 0;
+  for (int lev = 0; lev <= S.L; ++lev) {
+    const int first = (1 << lev) - 1, last = std::min(S.nfronts, (1 << (lev + 1)) - 1);
+    level_nodes = std::max(level_nodes, S.fnode_ptr[last] - S.fnode_ptr[first]);
+  }
+  c->level_nodes_max = level_nodes;
+  TRY(dalloc(c, &c->d_wbuf, (size_t)4 * level_nodes * plfem::NB));   // two halves: panels of even / odd block steps
+  TRY(dalloc(c, &c->d_rbuf, (size_t)4 * level_nodes * plfem::NB));
   TRY(dalloc(c, &c->d_dinv, (size_t)2 * S.nfronts * plfem::NB * plfem::NB));   // X of the pivot blocks, by block-step parity
   TRY(dalloc(c, &c->d_delta, (size_t)4 * fnodes_total));   // D^-1: (diagonal, off-diagonal) per front row
-  TRY(dalloc(c, &c->d_tbuf, (size_t)2 * fnodes_total * plfem::NB));
+  TRY(dalloc(c, &c->d_tbuf, (size_t)2 * level_nodes * plfem::NB));
   TRY(dalloc(c, &c->d_fvec2, (size_t)2 * fnodes_total * plfem::BLOCK_P));
   TRY(dalloc(c, &c->d_u0, (size_t)2 * fnodes_total * plfem::BLOCK_P));
   TRY(dalloc(c, &c->d_u1, (size_t)2 * fnodes_total * plfem::BLOCK_P));

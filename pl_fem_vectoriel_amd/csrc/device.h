@@ -57,6 +57,7 @@ struct plfem_ctx {
   int nv = 0, ne = 0, N = 0, nnz = 0, nsolve = 0, L = 0, nfronts = 0, max_ncv = 0;
   int dpn = 2, sh = 1;            // unknowns per node (2: Hx, Hy; 1: scalar Helmholtz) and sh = dpn - 1: node = dof >> sh, component = dof & sh
   int64_t fnodes_total = 0;       // sum over fronts of (padded) nodes = fnode_ptr[nfronts]
+  int64_t level_nodes_max = 0;    // the same sum over the fronts of one tree level, largest level
   int64_t n2 = 0;   // dpn N: length of every global vector (component-major blocks of N)
   std::vector<plfem::LevelInfo> levels;
   // ---- index structures on the device
@@ -90,10 +91,10 @@ struct plfem_ctx {
   double* d_xl = nullptr;         // complete local solution of every front (backward sweep)
   int32_t* d_npos = nullptr;      // [N] node -> front-order offset of its component 0: 2 fnode_ptr[owner] + dpn * local index, -1 = Dirichlet
   int32_t* d_prow = nullptr;      // per local node of a front: local node index in the PARENT front, -1 = none / padding
-  double *d_wbuf = nullptr, *d_rbuf = nullptr;   // per-front panels m x NB, offset 2*fnode_ptr[f]*NB
+  double *d_wbuf = nullptr, *d_rbuf = nullptr;   // per-front panels m x NB of the level in flight, offset 2*(fnode_ptr[f] - fnode_ptr[level first])*NB
   double* d_dinv = nullptr;       // 2 x per-front NB x NB (inverse of the unit-lower pivot block of even / odd block steps)
   double* d_delta = nullptr;      // per-front D^-1 of the block LDL^T: (diagonal, off-diagonal of the node pair) per row, offset 2 * (2*fnode_ptr[f])
-  double* d_tbuf = nullptr;       // per-front NB x s2 scratch (block row of L11), offset 2*fnode_ptr[f]*NB
+  double* d_tbuf = nullptr;       // per-front NB x s2 scratch (block row of L11) of the level in flight, same offsets
   double* d_fvec2 = nullptr;      // forward-sweep results of the owned rows (t = L11^-1 r; the backward sweep applies D^-1), front order
   int32_t* d_counters = nullptr;  // [0] pivot perturbations
   // ---- Lanczos workspace

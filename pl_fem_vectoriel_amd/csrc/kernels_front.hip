@@ -906,9 +906,15 @@ void launch_factor(plfem_ctx* c, double sigma, int stop_level, int stop_step, in
       if (nact == 0) break;
       const int max_trail = hpm[nact - 1] - k0 - 16;   // upper bound of the trailing order after this step
       // W / Y of even and odd steps live in separate halves of wbuf / rbuf (see ldl_update_tile)
-      const size_t half = (size_t)2 * c->fnodes_total * NB;
-      double* wb = c->d_wbuf + (kb & 1) * half;
-      double* rb = c->d_rbuf + (kb & 1) * half;
+      // (the kernels address these buffers by 2 fnode_ptr[f] NB: the pointers handed to them are shifted back by the
+      // offset of the level's first front, so that the level in flight starts at the beginning of the buffer)
+      const size_t half = (size_t)2 * c->level_nodes_max * NB;
+      const int64_t base = 2 * c->S->fnode_ptr[li.first] * NB;
+      double* wb0 = c->d_wbuf - base;
+      double* rb0 = c->d_rbuf - base;
+      double* tb0 = c->d_tbuf - base;
+      double* wb = wb0 + (kb & 1) * half;
+      double* rb = rb0 + (kb & 1) * half;
       // launch A: pivot block + panel (+ the copy of the block row of L11 for the triangular-inverse update)
       const int n_tb = (k0 + 63) / 64;
       // panel workgroups per front: all 64-row chunks in parallel where the level is a latency chain (few fronts), at
@@ -921,7 +927,7 @@ void launch_factor(plfem_ctx* c, double sigma, int stop_level, int stop_step, in
       double* dinv_cur = c->d_dinv + (size_t)(kb & 1) * c->nfronts * NB * NB;
       double* dinv_nxt = c->d_dinv + (size_t)((kb + 1) & 1) * c->nfronts * NB * NB;
       hipLaunchKernelGGL(k_ldl_pivot_panel, dim3(nact, n_tb + n_pan), dim3(256), 0, st, n_tb, ford, kb, c->d_fs2, c->d_fm,
-                         c->d_foff, c->d_fnode_ptr, c->d_front, dinv_cur, c->d_delta, c->d_tbuf, wb, rb, c->d_counters);
+                         c->d_foff, c->d_fnode_ptr, c->d_front, dinv_cur, c->d_delta, tb0, wb, rb, c->d_counters);
       if (stop_here && stop_stage >= 1 && stop_stage <= 2) return;
       // launch B: trailing update + triangular-inverse update + write-back of the pivot block
       const int un = c->upd_n[li.step0 + kb];                  // 64 x 64 blocks of this step's trailing updates
@@ -937,11 +943,11 @@ void launch_factor(plfem_ctx* c, double sigma, int stop_level, int stop_step, in
       if ((kb & 1) == 0)
         hipLaunchKernelGGL(k_ldl_update<0>, dim3(gridB), dim3(256), 0, st, un, n_inv, n_look, ut, ford, kb, c->d_fs2, c->d_fm,
                            c->d_foff, c->d_soff, c->d_fnode_ptr, c->d_front, c->d_schur, c->arena_doubles, dinv_cur, dinv_nxt,
-                           c->d_delta, c->d_tbuf, wb, rb, wb, rb, c->d_counters);
+                           c->d_delta, tb0, wb, rb, wb, rb, c->d_counters);
       else
         hipLaunchKernelGGL(k_ldl_update<1>, dim3(gridB), dim3(256), 0, st, un, n_inv, n_look, ut, ford, kb, c->d_fs2, c->d_fm,
                            c->d_foff, c->d_soff, c->d_fnode_ptr, c->d_front, c->d_schur, c->arena_doubles, dinv_cur, dinv_nxt,
-                           c->d_delta, c->d_tbuf, wb, rb, c->d_wbuf, c->d_rbuf, c->d_counters);
+                           c->d_delta, tb0, wb, rb, wb0, rb0, c->d_counters);
       if (stop_here && (stop_stage == 3 || stop_stage == 4)) return;
     }
     if (li.formz_n > 0 && stop_level >= 0) {          // (debug run that stops after a level: its Z now)
