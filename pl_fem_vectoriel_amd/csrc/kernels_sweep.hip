@@ -32,6 +32,9 @@
 #ifndef PLFEM_SWEEP_TB
 #define PLFEM_SWEEP_TB 8
 #endif
+#ifndef PLFEM_SWEEP_TB_BWD
+#define PLFEM_SWEEP_TB_BWD 8
+#endif
 #ifndef PLFEM_SWEEP_ROWLOADS
 #define PLFEM_SWEEP_ROWLOADS 8
 #endif
@@ -372,6 +375,7 @@ __device__ __forceinline__ void bwd_tile_body(const SweepArgs& A, int f, int rb,
   const int r0 = rb * 64;
   const int64_t np = A.fnode_ptr[f];
   const int64_t npp = f > 0 ? A.fnode_ptr[(f - 1) >> 1] : 0;
+  constexpr int TBB = PLFEM_SWEEP_TB_BWD;   // matrix loads in flight per lane and trip (leaf fronts: ~20 columns per wave)
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const bool publish = rb == 0 && !A.leaf_level;
   BwdStage<P> st;
@@ -385,9 +389,9 @@ __device__ __forceinline__ void bwd_tile_body(const SweepArgs& A, int f, int rb,
   auto entry = [&](int i) { return i < s2 ? p[(int64_t)i * m] : pz[(int64_t)i * s2]; };
   const int cb = valid ? r : m, ce = m;
   const int cstart = cb + ((wave - cb) & (NW - 1));
-  double a0[TB];
+  double a0[TBB];
 #pragma unroll
-  for (int t = 0; t < TB; ++t) a0[t] = (cstart + NW * t < ce) ? entry(cstart + NW * t) : 0.0;
+  for (int t = 0; t < TBB; ++t) a0[t] = (cstart + NW * t < ce) ? entry(cstart + NW * t) : 0.0;
   st.request_value(A, npp);
   stage_bwd_rest<P, false>(A, sv, r0, m, s2, np, npp, NW * 64, tid, publish);
   st.template finish<false>(A, sv, np, publish);
@@ -396,19 +400,19 @@ __device__ __forceinline__ void bwd_tile_body(const SweepArgs& A, int f, int rb,
 #pragma unroll
   for (int u = 0; u < P; ++u) acc[u] = 0.0;
 #pragma unroll
-  for (int t = 0; t < TB; ++t) {
+  for (int t = 0; t < TBB; ++t) {
     const int c = cstart + NW * t;
     if (c < ce) {
 #pragma unroll
       for (int u = 0; u < P; ++u) acc[u] += a0[t] * sv[c * P + u];
     }
   }
-  for (int c = cstart + NW * TB; c < ce; c += TB * NW) {
-    double a[TB];
+  for (int c = cstart + NW * TBB; c < ce; c += TBB * NW) {
+    double a[TBB];
 #pragma unroll
-    for (int t = 0; t < TB; ++t) a[t] = (c + NW * t < ce) ? entry(c + NW * t) : 0.0;
+    for (int t = 0; t < TBB; ++t) a[t] = (c + NW * t < ce) ? entry(c + NW * t) : 0.0;
 #pragma unroll
-    for (int t = 0; t < TB; ++t) {
+    for (int t = 0; t < TBB; ++t) {
       if (c + NW * t < ce) {
 #pragma unroll
         for (int u = 0; u < P; ++u) acc[u] += a[t] * sv[(c + NW * t) * P + u];
