@@ -1,7 +1,9 @@
 """Consumer of the eigenmode path: the reference's vectorial loss models, fed with the mode
 records ``TrueVectorialMaxwellSolver.solve_vectorial_modes`` returns.
 
-Reference: ``losses.py`` — ``LossCalculator.calculate_physical_losses`` (vectorial route, ``:742-825``),
+Reference: ``losses.py`` — ``LossCalculator.calculate_physical_losses`` (vectorial route ``:742-825``; scalar route
+``:828-865`` -> ``EnhancedLossCalculator.calculate_sectional_losses`` ``:74-440`` with ``_calculate_pdl_realistic``
+``:470-541``, the consumer of ``ScalarHelmholtzSolver``'s records, added in round 3),
 ``VectorialLossCalculator`` (``:996-1221``) and the helpers it reaches in ``EnhancedLossCalculator``
 (``_calculate_pdl_vectorial :445-467``, ``_calculate_crosstalk_vectorial :546-619``, ``_calculate_crosstalk_scalar
 :622-663``, ``_calculate_crosstalk :666-690``, ``_calculate_radiation_loss :693-720``).  These are O(#modes) closed-form
@@ -158,6 +160,139 @@ class EnhancedLossCalculator:
         return float(np.mean(per_mode)) if per_mode else 0.0
 
 
+    # ---- sectional model (polymer -> taper -> MMF), reference losses.py:74-440 ------------------------------------------
+    @staticmethod
+    def _calculate_pdl_realistic(modes: List[Dict], geometry, wavelength_nm: float) -> float:
+        """PDL estimate for scalar modes (no P_x / P_y): modal birefringence of near-degenerate n_eff, second-moment
+        asymmetry of the core positions, a coupling term, the confinement spread, a wavelength factor (``:470-541``)."""
+        if len(modes) < 2:
+            return 0.3
+        n_effs = np.array([float(m["n_eff"]) for m in modes])
+        desc = np.sort(n_effs)[::-1]
+        gaps = np.abs(desc[:-1] - desc[1:])
+        gaps = gaps[gaps < 5e-4]
+        if gaps.size:
+            k0 = 2.0 * np.pi / (wavelength_nm * 1e-9)
+            pdl_biref = 4.343 * k0 * np.mean(gaps) * 375e-6
+        else:
+            pdl_biref = np.ptp(n_effs) * 800.0
+        pdl_geom = 0.0
+        positions = getattr(geometry, "positions", None)
+        if positions is not None and len(positions) >= 3:
+            c = np.array(positions)
+            c = c - np.mean(c, axis=0)
+            ixx, iyy, ixy = np.sum(c[:, 0] ** 2), np.sum(c[:, 1] ** 2), np.sum(c[:, 0] * c[:, 1])
+            disc = np.sqrt(((ixx - iyy) / 2.0) ** 2 + ixy ** 2)
+            i_max, i_min = (ixx + iyy) / 2.0 + disc, (ixx + iyy) / 2.0 - disc
+            pdl_geom = abs(i_max - i_min) / (i_max + i_min + 1e-12) * 4.0
+        pdl_coupling = 0.15 * np.log10(len(modes) + 1)
+        if wavelength_nm < 1530:
+            wl = 1.0 + (1530.0 - wavelength_nm) / 1000.0
+        elif wavelength_nm > 1565:
+            wl = 1.0 + (wavelength_nm - 1565.0) / 1000.0
+        else:
+            wl = 1.0
+        pdl_conf = np.std(np.array([m["confinement"] for m in modes])) * 2.0
+        return float(np.clip((pdl_biref + pdl_geom + pdl_coupling + pdl_conf) * wl, 0.05, 6.0))
+
+    @staticmethod
+    def _calculate_polymer_section(modes: List[Dict], geometry, design_params, wavelength_nm: float) -> Dict:
+        """``:190-246``: coupling mismatch + confinement + 0.5 dB/m over L_mux; MDL from the confinement spread."""
+        confs = np.array([m["confinement"] for m in modes])
+        avg = float(np.mean(confs[confs > 0.01])) if np.any(confs > 0.01) else 0.5
+        il = 0.5 * (1.0 - design_params.coupling_uniformity) - 10.0 * np.log10(max(avg, 1e-6)) + 0.5 * (design_params.L_mux * 1e-6)
+        mdl = (-10.0 * np.log10(max(np.min(confs), 1e-9) / (np.max(confs) + 1e-12)) + 3.0 * np.std(confs)) if len(confs) >= 2 else 0.0
+        if modes[0].get("is_vectorial", False):
+            pdl = EnhancedLossCalculator._calculate_pdl_vectorial(modes)
+        else:
+            pdl = EnhancedLossCalculator._calculate_pdl_realistic(modes, geometry, wavelength_nm)
+        return {"IL": float(np.clip(il, 0.0, 10.0)), "MDL": float(np.clip(mdl, 0.0, 5.0)), "PDL": float(np.clip(pdl, 0.05, 3.0))}
+
+    @staticmethod
+    def _calculate_taper_section(modes: List[Dict], geometry, design_params, wavelength_nm: float) -> Dict:
+        """``:252-321``: adiabaticity (L_beat = 150 um), 0.5 dB/m, residual radiation; MDL from the three best / worst
+        confined modes; PDL from a 1e-5 birefringence over the taper."""
+        L, n_taper = design_params.L_taper, design_params.n_taper
+        eta = 1.0 - np.exp(-L / (150.0 * max(n_taper, 0.5)))
+        confs = np.array([m["confinement"] for m in modes])
+        conf_mean = float(np.mean(confs)) if len(confs) else 0.9
+        il = -10.0 * np.log10(max(eta, 1e-6)) + 0.5 * (L * 1e-6) + (max(0.0, 1.0 - conf_mean) * 0.5 + 0.05 * np.log10(len(modes) + 1))
+        if len(confs) >= 2:
+            asc = np.sort(confs)
+            mdl = float(np.clip(-10.0 * np.log10(np.mean(asc[:3]) / (np.mean(asc[-3:]) + 1e-12)), 0.0, 3.0))
+        else:
+            mdl = 0.0
+        pdl = 4.343 * (2.0 * np.pi / (wavelength_nm * 1e-3)) * 1e-5 * L
+        return {"IL": float(np.clip(il, 0.0, 8.0)), "MDL": float(np.clip(mdl, 0.0, 3.0)), "PDL": float(np.clip(pdl, 0.01, 2.0))}
+
+    @staticmethod
+    def _calculate_mmf_section(modes: List[Dict], geometry, design_params, wavelength_nm: float) -> Dict:
+        """``:327-358``: 0.2 dB/km of silica + 0.3 dB splice; MDL = PDL = 0.05."""
+        L = design_params.L_MMF
+        if L < 1.0:
+            return {"IL": 0.0, "MDL": 0.0, "PDL": 0.0}
+        return {"IL": float(np.clip(0.2 * (L * 1e-9) + 0.3, 0.0, 5.0)), "MDL": 0.05, "PDL": 0.05}
+
+    @staticmethod
+    def _calculate_global_metrics(polymer: Dict, taper: Dict, mmf: Dict, modes: List[Dict], geometry, design_params) -> Dict:
+        """``:364-439``: IL adds, MDL adds in quadrature, PDL adds; crosstalk, coupling degradation from the spread of the
+        FEM modes, packing / pitch penalties, radiation loss, mean confinement."""
+        il = polymer["IL"] + taper["IL"] + mmf["IL"]
+        mdl = np.sqrt(polymer["MDL"] ** 2 + taper["MDL"] ** 2 + mmf["MDL"] ** 2)
+        pdl = polymer["PDL"] + taper["PDL"] + mmf["PDL"]
+        xt = EnhancedLossCalculator._calculate_crosstalk(modes)
+        if len(modes) >= 2:
+            confs = np.array([m["confinement"] for m in modes])
+            n_effs = np.array([float(m["n_eff"]) for m in modes])
+            n_core = getattr(geometry, "core_index", getattr(geometry, "n_core", 1.53))
+            n_clad = getattr(geometry, "clad_index", getattr(geometry, "n_clad", 1.0))
+            cv = float(np.std(confs) / (np.mean(confs) + 1e-9))
+            spread = float(np.ptp(n_effs) / max(n_core - n_clad, 1e-6))
+            degradation = float(np.clip(cv * 1.5 + spread * 0.8 + float(max(0.0, 0.70 - float(np.min(confs)))) * 2.0, 0.0, 5.0))
+        else:
+            degradation = 5.0
+        packing, pitch_ratio = design_params.packing_efficiency, design_params.pitch_ratio
+        pack_pen = (0.5 - packing) * 3.0 if packing < 0.5 else ((packing - 0.85) * 2.0 if packing > 0.85 else 0.0)
+        geom_pen = pack_pen + abs(pitch_ratio - 3.5) * 0.2
+        valid = [m["confinement"] for m in modes if m["confinement"] > 0]
+        return {
+            "IL_total": float(np.clip(il, 0.0, 40.0)), "MDL_total": float(np.clip(mdl, 0.0, 10.0)),
+            "PDL_total": float(np.clip(pdl, 0.05, 10.0)), "Total_Loss": float(il),
+            "Efficiency": float(np.clip(10.0 ** (-il / 10.0), 0.0, 1.0)), "Crosstalk": float(xt),
+            "crosstalk_penalty": float(np.clip(max(0.0, -20.0 - xt) * 0.1, 0.0, 5.0)),
+            "coupling_degradation": float(np.clip(degradation, 0.0, 5.0)), "geometry_penalty": float(np.clip(geom_pen, 0.0, 5.0)),
+            "radiation_loss_dB_per_m": float(EnhancedLossCalculator._calculate_radiation_loss(modes, design_params.wavelength)),
+            "avg_confinement": float(np.mean(valid)) if valid else 0.0,
+        }
+
+    @staticmethod
+    def calculate_sectional_losses(modes: List[Dict], geometry, design_params, direction: str = "mux",
+                                   wavelength_nm: float = 1550.0) -> Dict:
+        """``:74-184``: losses per section and the cumulated metrics; errors come back as ``{'success': False, ...}``."""
+        if not modes:
+            return {"success": False, "error": "no modes"}
+        try:
+            E = EnhancedLossCalculator
+            po = E._calculate_polymer_section(modes, geometry, design_params, wavelength_nm)
+            ta = E._calculate_taper_section(modes, geometry, design_params, wavelength_nm)
+            mm = E._calculate_mmf_section(modes, geometry, design_params, wavelength_nm)
+            g = E._calculate_global_metrics(po, ta, mm, modes, geometry, design_params)
+            return {
+                "IL_polymer": po["IL"], "MDL_polymer": po["MDL"], "PDL_polymer": po["PDL"],
+                "IL_taper": ta["IL"], "MDL_taper": ta["MDL"], "PDL_taper": ta["PDL"],
+                "IL_MMF": mm["IL"], "MDL_MMF": mm["MDL"], "PDL_MMF": mm["PDL"],
+                "IL_total": g["IL_total"], "MDL_total": g["MDL_total"], "PDL_total": g["PDL_total"],
+                "Total_Loss": g["Total_Loss"], "Efficiency": g["Efficiency"], "Crosstalk": g["Crosstalk"],
+                "crosstalk_penalty": g["crosstalk_penalty"], "coupling_degradation": g["coupling_degradation"],
+                "geometry_penalty": g["geometry_penalty"], "radiation_loss_dB_per_m": g["radiation_loss_dB_per_m"],
+                "avg_confinement": g["avg_confinement"], "n_modes_used": len(modes), "direction": direction,
+                "wavelength_nm": float(wavelength_nm), "success": True,
+            }
+        except Exception as e:                                    # noqa: BLE001 - the reference reports, it does not raise (:182-184)
+            logger.error(f"Erreur calcul pertes sectionnées: {e}")
+            return {"error": str(e), "success": False}
+
+
 class VectorialLossCalculator:
     """Sectional losses (polymer, taper, MMF) with the PDL taken from the FEM powers P_x / P_y (``losses.py:996-1221``)."""
 
@@ -232,15 +367,23 @@ class VectorialLossCalculator:
 
 
 class LossCalculator(EnhancedLossCalculator):
-    """``calculate_physical_losses`` of the reference, vectorial route (``losses.py:742-825``).  Modes that are not
-    vectorial (``is_vectorial`` false) take the reference's scalar route through ``calculate_sectional_losses``,
-    which is outside this row: a ``NotImplementedError`` names it instead of returning numbers of another model."""
+    """``calculate_physical_losses`` of the reference: vectorial route (``losses.py:742-825``) for the records of
+    ``TrueVectorialMaxwellSolver``, scalar route (``:828-865``, through ``calculate_sectional_losses``) for the records of
+    ``ScalarHelmholtzSolver``."""
 
     @staticmethod
     def calculate_physical_losses(modes: List[Dict], geometry, direction: str = "mux", wavelength_nm: float = 1550.0) -> Dict:
         if not (modes and modes[0].get("is_vectorial", False)):
-            raise NotImplementedError("only the vectorial route (modes of TrueVectorialMaxwellSolver) is built; the scalar "
-                                      "route is EnhancedLossCalculator.calculate_sectional_losses of the reference")
+            # scalar route (``losses.py:828-865``): the records of ScalarHelmholtzSolver through the sectional model
+            params = LossCalculator._build_design_params(modes, geometry, wavelength_nm)
+            full = EnhancedLossCalculator.calculate_sectional_losses(modes, geometry, params, direction, wavelength_nm)
+            if not full.get("success", False):
+                return {"success": False, "error": full.get("error", "unknown")}
+            pdl = full["PDL_total"] * (1.02 if direction == "demux" else 1.0)
+            return {"IL_dB": full["IL_total"], "MDL_dB": full["MDL_total"], "PDL_dB": float(np.clip(pdl, 0.05, 10.0)),
+                    "crosstalk_dB": full["Crosstalk"], "radiation_loss_dB_per_m": full["radiation_loss_dB_per_m"],
+                    "avg_confinement": full["avg_confinement"], "n_modes_used": full["n_modes_used"], "direction": direction,
+                    "wavelength_nm": float(wavelength_nm), "is_vectorial": False, "success": True}
         params = LossCalculator._build_design_params(modes, geometry, wavelength_nm)
         res = VectorialLossCalculator.calculate_vectorial_losses(modes, geometry, params, direction, wavelength_nm)
         if not res.get("success", False):

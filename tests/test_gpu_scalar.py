@@ -87,6 +87,17 @@ def test_scalar_modes_match_oracle(arrangement, gpu_device, built_library):
     for a, b, single in zip(modes, ref, iso):
         if single:
             assert abs(a["confinement"] - b["confinement"]) < 1e-6 and a["core_overlap"] == a["confinement"]
+    # the records' consumer (row f2, scalar route: losses.py:828-865): same loss columns from the GPU records and from the
+    # oracle's.  (The crosstalk estimate of scalar records overlaps the raw field_vector arrays, whose sign and basis
+    # inside a degenerate pair are the eigensolver's choice: finite, not compared.)
+    from pl_fem_vectoriel_amd.losses import LossCalculator
+    got = LossCalculator.calculate_physical_losses(modes, g, "mux", 1550.0)
+    want = LossCalculator.calculate_physical_losses(ref, g, "mux", 1550.0)
+    assert got["success"] and got["is_vectorial"] is False and got["n_modes_used"] == len(modes)
+    if iso.all():
+        for key in ("IL_dB", "MDL_dB", "PDL_dB", "radiation_loss_dB_per_m", "avg_confinement"):
+            assert abs(got[key] - want[key]) <= 1e-6 * max(1.0, abs(want[key])), key
+    assert np.isfinite(got["crosstalk_dB"])
 
 
 def test_scalar_tiny_mesh_clamps_the_request(gpu_device, built_library):
