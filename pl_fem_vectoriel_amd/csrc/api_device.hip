@@ -1174,6 +1174,7 @@ extern "C" int plfem_profile_begin(plfem_ctx* c, int32_t max_ranges) {
   c->prof_max = max_ranges;                          // event pairs are created on demand at the launch site
   if (c->prof_ev.empty()) events_take(c->device, c->prof_ev);
   c->prof_n = 0;
+  c->prof_toggle = 0;
   c->prof_slot.clear();
   c->prof_rbytes.clear();
   c->prof_on = true;

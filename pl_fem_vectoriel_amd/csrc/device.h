@@ -120,6 +120,7 @@ struct plfem_ctx {
   hipEvent_t ev_step[2] = {nullptr, nullptr};   // block Lanczos: completion of the two block steps in flight
   // live kernel timing (plfem_profile_*): event pairs around every tile-form forward-sweep launch
   bool prof_on = false;
+  unsigned prof_toggle = 0;       // block solves alternate between timing whole sweeps and timing single launches
   int prof_n = 0, prof_max = 0;
   double prof_bytes = 0;
   std::vector<hipEvent_t> prof_ev;   // taken from the process-wide pool at profile_begin, handed back at profile_end

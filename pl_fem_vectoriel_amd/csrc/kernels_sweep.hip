@@ -600,7 +600,10 @@ void sweeps(plfem_ctx* c) {
   for (const LevelInfo& li : c->levels) sweep_total += li.sweep_bytes + 8.0 * (P - 1) * li.sweep_vec_doubles;
   // Kernel form by level: fwd_block_rows / bwd_block_rows (device.h); workgroups come from the compact launch
   // lists of the context (no empty workgroups, large fronts first).
-  const int pid_fwd = prof_open(c, PLFEM_PROF_FWD_SWEEP, sweep_total);
+  // live timing (plfem_profile_*): event records around single launches lengthen the sweep they sit in (~8 us each), so
+  // a profiled step times whole sweeps and single launches in ALTERNATE block solves, never nested
+  const bool time_launches = c->prof_on && (c->prof_toggle++ & 1);
+  const int pid_fwd = time_launches ? -1 : prof_open(c, PLFEM_PROF_FWD_SWEEP, sweep_total);
   for (int lev = c->L; lev >= 0; --lev) {
     const LevelInfo& li = c->levels[lev];
     if (li.fwd_n == 0) continue;
@@ -614,14 +617,14 @@ void sweeps(plfem_ctx* c) {
       hipLaunchKernelGGL((k_fwd_rows<P, 2>), dim3(li.fwd_n), dim3(512), lds, st, A);
     else {
       // optional live timing of this kernel (bench.py roofline): HIP events on the launch stream
-      const int pid = prof_open(c, PLFEM_PROF_KFWD, li.sweep_bytes + 8.0 * (P - 1) * li.sweep_vec_doubles);
+      const int pid = time_launches ? prof_open(c, PLFEM_PROF_KFWD, li.sweep_bytes + 8.0 * (P - 1) * li.sweep_vec_doubles) : -1;
       if (li.fwd_mixed) hipLaunchKernelGGL((k_fwd_mix<P>), dim3(li.fwd_n), dim3(256), lds, st, A);
       else hipLaunchKernelGGL((k_fwd<P>), dim3(li.fwd_n), dim3(256), lds, st, A);
       prof_close(c, pid);
     }
   }
   prof_close(c, pid_fwd);
-  const int pid_bwd = prof_open(c, PLFEM_PROF_BWD_SWEEP, sweep_total);
+  const int pid_bwd = time_launches ? -1 : prof_open(c, PLFEM_PROF_BWD_SWEEP, sweep_total);
   for (int lev = 0; lev <= c->L; ++lev) {
     const LevelInfo& li = c->levels[lev];
     if (li.bwd_n == 0) continue;

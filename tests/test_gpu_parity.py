@@ -323,15 +323,17 @@ def test_live_kernel_profile_hooks(small):
     P.ctx.factor(P.sigma)
     P.ctx.profile_begin(64)
     b = P.embed(np.random.default_rng(2).standard_normal(len(P.idx)))
-    for _ in range(3):
+    for _ in range(4):
         P.ctx.solve(b, 0)
     prof = P.ctx.profile_end()
     T = fe.FrontTree(P.sym)
     tile_levels = sum(1 for lev in range(T.L + 1) if (1 << lev) > 32)
-    assert prof["launches"] == 3 * tile_levels
+    # whole sweeps and single launches are timed in alternate solves (an event pair around a launch lengthens the sweep it
+    # sits in): solves 1 and 3 time the sweeps, solves 2 and 4 the tile-form launches
+    assert prof["launches"] == 2 * tile_levels
     assert prof["total_us"] > 0 and prof["bytes"] > 0
     sl = prof["slots"]
-    assert sl["fwd_sweep"]["ranges"] == sl["bwd_sweep"]["ranges"] == 3 and sl["spmv_b"]["ranges"] == 0
+    assert sl["fwd_sweep"]["ranges"] == sl["bwd_sweep"]["ranges"] == 2 and sl["spmv_b"]["ranges"] == 0
     assert sl["fwd_sweep"]["bytes"] == sl["bwd_sweep"]["bytes"] >= sl["k_fwd"]["bytes"] > 0
     assert sl["fwd_sweep"]["total_us"] >= sl["k_fwd"]["total_us"] > 0
     # algorithmic bytes of one backward sweep never exceed the bytes of the stored factors + vectors
