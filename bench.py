@@ -287,6 +287,9 @@ class Dist:
         if self.world != args.gpus:
             raise RuntimeError(f"--gpus {args.gpus} but WORLD_SIZE={self.world}: launch with `python bench.py --gpus N` "
                                f"or `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`")
+        if self.world > 1 and "PLFEM_HOST_THREADS" not in os.environ:
+            # every rank runs its own host analysis on a spin-waiting thread pool: share the host's cores between the ranks
+            os.environ["PLFEM_HOST_THREADS"] = str(max(4, min(16, (os.cpu_count() or 64) // self.world)))
         import torch
         self.torch = torch
         if not self.fake:
