@@ -112,8 +112,9 @@ def test_c4_full_multiband_sweep_on_one_gpu(gpu_device, built_library):
     from pl_fem_vectoriel_amd.sweep import multiband_sweep_items, run_sweep
     items = multiband_sweep_items()
     assert len(items) == 64
-    table, n_local = run_sweep(items, 0, 1, device=gpu_device)
-    assert n_local == 64 and sorted(table) == list(range(64))
+    from pl_fem_vectoriel_amd.losses import LossCalculator
+    table, n_local, losses = run_sweep(items, 0, 1, device=gpu_device, lanes=4, losses="mux")
+    assert n_local == 64 and sorted(table) == list(range(64)) and sorted(losses) == list(range(64))
     for i in range(64):
         assert 0 < len(table[i]) <= 22 and (np.diff(table[i]) <= 0).all()      # k = 22 requested per solve, descending n_eff
         assert (table[i] > 1.0).all() and (table[i] < 1.535).all()
@@ -124,6 +125,13 @@ def test_c4_full_multiband_sweep_on_one_gpu(gpu_device, built_library):
         direct = np.array([m["n_eff"] for m in solver.solve_vectorial_modes(mesh, it.n_modes)])
         assert solver.last_stats["true_residual"] < 1e-8 and solver.last_stats["refined"] is False
         assert len(direct) == len(table[it.index]) and np.abs(direct - table[it.index]).max() < 1e-10
+        # the loss columns formed from the gathered record = the consumer fed with the full mode dicts
+        want = LossCalculator.calculate_physical_losses(solver.solve_vectorial_modes(mesh, it.n_modes), g, "mux", 1e3 * it.wavelength_um)
+        got = losses[it.index]
+        assert got["success"] and set(got) == set(want)
+        for key, v in want.items():
+            if isinstance(v, float):
+                assert abs(got[key] - v) <= 1e-9 * max(1.0, abs(v)), (it.index, key)
         solver.clear_cache()
 
 
