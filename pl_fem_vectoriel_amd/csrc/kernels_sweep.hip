@@ -32,6 +32,9 @@
 #ifndef PLFEM_SWEEP_TB
 #define PLFEM_SWEEP_TB 8
 #endif
+#ifndef PLFEM_SWEEP_TB_FWD_TILE
+#define PLFEM_SWEEP_TB_FWD_TILE 8
+#endif
 #ifndef PLFEM_SWEEP_TB_BWD
 #define PLFEM_SWEEP_TB_BWD 8
 #endif
@@ -156,7 +159,7 @@ struct FwdOut {
 // ---- forward, tile form ------------------------------------------------------------------------------------------
 constexpr int SWEEP_ROW_JOB = 1 << 30;   // job.y flag of the mixed kernels: row-form workgroup (16 rows) instead of a tile (64 rows)
 constexpr int TB = PLFEM_SWEEP_TB;      // matrix loads in flight per lane and trip (a long front is a chain of such trips)
-template <int P, int NW>
+template <int P, int NW, int TBF = TB>
 __device__ __forceinline__ void fwd_tile_body(const SweepArgs& A, int f, int rb, double* __restrict__ sv, double* __restrict__ red) {
   const int m = A.fm[f], s2 = A.fs2[f];
   if (A.dbg && ((A.dbg == 1) == (s2 > 128))) return;
@@ -173,9 +176,9 @@ __device__ __forceinline__ void fwd_tile_body(const SweepArgs& A, int f, int rb,
   FwdStage<P> st;
   stage_fwd<P, false>(A, sv, np, need, NW * 64, tid, st);
   // first batch of this wave's columns (c == wave mod NW), requested before the staged vector is complete
-  double a0[TB];
+  double a0[TBF];
 #pragma unroll
-  for (int t = 0; t < TB; ++t) a0[t] = (wave + NW * t < ce) ? p[(int64_t)(wave + NW * t) * m] : 0.0;
+  for (int t = 0; t < TBF; ++t) a0[t] = (wave + NW * t < ce) ? p[(int64_t)(wave + NW * t) * m] : 0.0;
   if (tid < need) {
 #pragma unroll
     for (int u = 0; u < P; ++u) sv[tid * P + u] = st.value(u);
@@ -185,19 +188,19 @@ __device__ __forceinline__ void fwd_tile_body(const SweepArgs& A, int f, int rb,
 #pragma unroll
   for (int u = 0; u < P; ++u) acc[u] = 0.0;
 #pragma unroll
-  for (int t = 0; t < TB; ++t) {
+  for (int t = 0; t < TBF; ++t) {
     const int c = wave + NW * t;
     if (c < ce) {
 #pragma unroll
       for (int u = 0; u < P; ++u) acc[u] += a0[t] * sv[c * P + u];
     }
   }
-  for (int c = wave + NW * TB; c < ce; c += TB * NW) {
-    double a[TB];
+  for (int c = wave + NW * TBF; c < ce; c += TBF * NW) {
+    double a[TBF];
 #pragma unroll
-    for (int t = 0; t < TB; ++t) a[t] = (c + NW * t < ce) ? p[(int64_t)(c + NW * t) * m] : 0.0;
+    for (int t = 0; t < TBF; ++t) a[t] = (c + NW * t < ce) ? p[(int64_t)(c + NW * t) * m] : 0.0;
 #pragma unroll
-    for (int t = 0; t < TB; ++t) {
+    for (int t = 0; t < TBF; ++t) {
       if (c + NW * t < ce) {
 #pragma unroll
         for (int u = 0; u < P; ++u) acc[u] += a[t] * sv[(c + NW * t) * P + u];
@@ -538,7 +541,7 @@ __global__ __launch_bounds__(256) void k_fwd(SweepArgs A) {
   extern __shared__ double sv[];
   __shared__ double red[4 * P * 64];
   const int2 job = A.blk[blockIdx.x];
-  fwd_tile_body<P, 4>(A, job.x, job.y, sv, red);
+  fwd_tile_body<P, 4, PLFEM_SWEEP_TB_FWD_TILE>(A, job.x, job.y, sv, red);
 }
 
 template <int P>
