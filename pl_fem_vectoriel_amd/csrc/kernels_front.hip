@@ -198,12 +198,12 @@ __device__ __forceinline__ double lane_xor16(double v, bool odd_row) {
 
 // One pivot pair E = [[a, b], [b, c]] (the same bits in every thread: all operands come from LDS broadcasts) and what
 // this thread's row i does with it.  On entry y0, y1 = a[i][2q], a[i][2q+1] (zero for rows that are done), ra / rb = this
-// thread's four entries of rows 2q / 2q+1 as staged.  The three cases are wave-uniform branches, not selects: a step of
+// thread's four entries of rows 2q / 2q+1 as staged.  The two pivot kinds are wave-uniform branches, not selects: a step of
 // the pivot block costs what its waves issue (one wave per SIMD: ~5 clocks per instruction, 16 for v_rcp_f64) and a
 // compare -> select pair on the path costs 56 clocks against 7 for a dependent v_fma_f64 (scripts/micro/f64_latency.hip).
 // Vanishing pivots -- below thr = 1e-13 of the largest entry the pair's two rows had in the pivot block when the block
 // step began -- are perturbed statically (+-thr) and counted.
-//   dd, od: this pair's D^-1 (diagonal entry of row 2q + `second`, off-diagonal entry), for the panel and the sweeps.
+//   d0, d1, od: this pair's D^-1 (diagonal entries of rows 2q and 2q+1, off-diagonal entry), for the panel and the sweeps.
 __device__ __forceinline__ void pair_step(double a, double b, double c, double thr, bool past_first, bool past_second,
                                           double y0, double y1, const double (&ra)[4], const double (&rb)[4],
                                           double (&v)[4], double& d0, double& d1, double& od, int& nper) {
