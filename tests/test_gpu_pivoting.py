@@ -68,3 +68,37 @@ def test_random_coarse_cross_sections_factor_cleanly_and_match_the_oracle(chunk,
         worst_dn, worst_res = max(worst_dn, dn), max(worst_res, st["true_residual"])
         solver.clear_cache()
     print(f"chunk {chunk}: max |dn_eff| {worst_dn:.2e}, max first-pass residual {worst_res:.2e}")
+
+
+def test_random_cross_sections_of_the_scalar_pencil(gpu_device, built_library):
+    """The same for ``ScalarHelmholtzSolver`` (one unknown per node: a pivot pair is two neighbouring NODES, and two nodes
+    of one hull sliver make a pair with condition 1e9 -- the case that rules out 2 x 2 pivots through the explicit inverse
+    everywhere): 24 random cross-sections, raw eigenvalues against the oracle's."""
+    from scipy.sparse.linalg import eigsh
+    from oracle import scalar
+    from pl_fem_vectoriel_amd.solver_fem import ScalarHelmholtzSolver
+    worst = 0.0
+    for t, arr, pitch, lam, refinement in list(random_cross_sections(24, seed=7))[:24]:
+        n, variant = ARRANGEMENTS[arr]
+        g = MCFGeometry(n, pitch, 1.5, 1.535, 1.0, wavelength_um=lam, variant=variant)
+        mesh = generate_mesh(g, refinement, 0)
+        solver = ScalarHelmholtzSolver(g, device=gpu_device)
+        modes = solver.solve(mesh, n_modes_target=6)
+        st = solver.last_stats
+        case = (t, arr, round(pitch, 3), round(lam, 4), round(refinement, 3))
+        assert st["pivot_perturbations"] == 0 and st["refined"] is False, (case, st["pivot_perturbations"], st["true_residual_first"])
+        assert st["true_residual"] < ScalarHelmholtzSolver.RESIDUAL_TOL, (case, st["true_residual"])
+        ref, raw = scalar.solve(g, MeshTriLite(mesh.p, mesh.t), 6, return_raw=True)
+        # the wanted set (k = 14 nearest sigma) from a wider, tighter eigsh: see the vectorial test
+        wide = eigsh(raw["A"], k=20, M=raw["M"], sigma=raw["sigma"], which="LM", tol=1e-10, maxiter=6000, return_eigenvectors=False)
+        wide = wide[np.argsort(np.abs(wide - raw["sigma"]))][:14]
+        ne_want = np.sort(np.sqrt(-wide[wide < 0])) / g.k0
+        ne_want = ne_want[(ne_want > g.n_clad) & (ne_want < g.n_core * 1.005)][::-1]
+        got = np.array([m["n_eff"] for m in modes])
+        assert len(got) == len(ne_want) > 0, (case, len(got), len(ne_want))
+        dn = float(np.abs(got - ne_want).max())
+        assert dn < 1e-9, (case, dn)
+        worst = max(worst, dn)
+        solver.clear_cache()
+    print(f"scalar pencil, 24 cross-sections: max |dn_eff| {worst:.2e}")
+
