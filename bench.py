@@ -492,11 +492,24 @@ def run_sweep_config(args, D: Dist):
     for _ in range(args.warmup):
         table, n_local = run_sweep(items, D.rank, world, solve=solve, device=device, lanes=lanes)
     D.sync()
+    if hasattr(solve, "timeline"):
+        solve.timeline.clear()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         table, n_local = run_sweep(items, D.rank, world, solve=solve, device=device, lanes=lanes)
     D.sync()
     elapsed = D.max_over_ranks(time.perf_counter() - t0)
+    host = None
+    if hasattr(solve, "timeline") and solve.timeline:
+        # host-side picture of rank 0's lanes over the timed sweeps: share of the wall time a lane spends inside a solve call,
+        # and of that the wait for a mesh's analysis (prepared ahead by background threads) and the number of contexts made
+        tl = list(solve.timeline)
+        lanes_seen = sorted({t[0] for t in tl})
+        wall = time.perf_counter() - t0
+        host = {"lanes": len(lanes_seen),
+                "busy_fraction_per_lane": [round(sum(t[4] - t[2] for t in tl if t[0] == ln) / wall, 3) for ln in lanes_seen],
+                "analysis_wait_ms_total": round(1e3 * sum(t[3] - t[2] for t in tl), 2),
+                "contexts_created": int(sum(1 for t in tl if t[5])), "solves": len(tl)}
     # the same sweep with the mesh producer INSIDE the timed region (Delaunay + refinement per cross-section, overlapped
     # with the solves by the sweep's preparer thread): reported beside the headline, which keeps its inputs resident
     elapsed_mesh = None
@@ -524,6 +537,8 @@ def run_sweep_config(args, D: Dist):
                                      f"backend {D.backend}"},
            "sweep": {"solves": len(items), "solves_per_s": args.steps * len(items) / elapsed, "solves_rank0": n_local,
                      "n_eff_checksum": float(sum(float(np.sum(table[i])) for i in sorted(table)))}}
+    if host is not None:
+        out["sweep"]["host_timeline_rank0"] = host
     if elapsed_mesh is not None:
         out["sweep"]["with_mesh_production"] = {"ms_per_step": elapsed_mesh / args.steps * 1e3,
                                                 "value": args.steps * len(items) * N_MODES / elapsed_mesh, "unit": "modes/s",

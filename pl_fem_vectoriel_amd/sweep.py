@@ -117,8 +117,11 @@ def default_solve(device: Optional[int] = None, meshes: Optional[dict] = None) -
     from .mesh import generate_mesh
     from .solver_fem import TrueVectorialMaxwellSolver
 
+    import time as _time
+
     lock = threading.Lock()
     shared: Dict[tuple, dict] = {}          # mesh_key -> {"ready": Event, "mesh", "sym", "error"}
+    timeline: list = []                     # (lane thread id, item index, t_start, t_analysis_ready, t_end, new context?)
 
     def prepare(item: SweepItem) -> dict:
         with lock:
@@ -146,23 +149,28 @@ def default_solve(device: Optional[int] = None, meshes: Optional[dict] = None) -
             shared.pop(mesh_key, None)
 
     def solve(item: SweepItem, cache: dict) -> np.ndarray:
+        t_start = t_ready = _time.perf_counter()
         g = item.geometry()
         cur = cache.get("cur")
-        if cur is None or cur["key"] != item.mesh_key:
+        fresh = cur is None or cur["key"] != item.mesh_key
+        if fresh:
             if cur is not None:
                 cur["solver"].clear_cache()
                 cache.pop("cur")
             ent = prepare(item)
+            t_ready = _time.perf_counter()
             solver = TrueVectorialMaxwellSolver(g, device=device)
             solver.adopt_analysis(ent["mesh"], ent["sym"])
             cur = cache["cur"] = {"key": item.mesh_key, "mesh": ent["mesh"], "solver": solver}
         s = cur["solver"]
         s.geometry, s.k0 = g, g.k0
         modes = s.solve_vectorial_modes(cur["mesh"], item.n_modes)
+        timeline.append((threading.get_ident(), item.index, t_start, t_ready, _time.perf_counter(), fresh))
         return np.array([[m[f] for m in modes] for f in FIELDS], dtype=np.float64).reshape(NF, len(modes))
 
     solve.prepare = prepare
     solve.release = release
+    solve.timeline = timeline               # host-side picture of a sweep (bench.py --sweep reports lane utilisation)
     return solve
 
 
