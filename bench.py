@@ -465,6 +465,25 @@ def run_solve_config(args, D: Dist, levels: int, with_cpu_baseline: bool):
     return out
 
 
+def _host_picture(solve, wall):
+    """Host-side picture of rank 0's lanes over the timed sweeps: share of the wall time a lane spends inside a solve call,
+    of that the wait for a mesh's analysis (prepared ahead by background threads), the number of contexts made, and what
+    the preparers spent per mesh on the mesh itself and on its analysis."""
+    tl = list(solve.timeline)
+    if not tl:
+        return None
+    lanes_seen = sorted({t[0] for t in tl})
+    host = {"lanes": len(lanes_seen),
+            "busy_fraction_per_lane": [round(sum(t[4] - t[2] for t in tl if t[0] == ln) / wall, 3) for ln in lanes_seen],
+            "analysis_wait_ms_total": round(1e3 * sum(t[3] - t[2] for t in tl), 2),
+            "contexts_created": int(sum(1 for t in tl if t[5])), "solves": len(tl)}
+    pre = list(getattr(solve, "prepared", []))
+    if pre:
+        host["prepare_ms_per_mesh"] = {"mesh": round(1e3 * sum(p[2] - p[1] for p in pre) / len(pre), 2),
+                                       "analysis": round(1e3 * sum(p[3] - p[2] for p in pre) / len(pre), 2), "meshes": len(pre)}
+    return host
+
+
 def run_sweep_config(args, D: Dist):
     """BASELINE.json configs[3]: a step = the 64 (arrangement x wavelength) solves, sharded over the ranks by
     pl_fem_vectoriel_amd.sweep (4 wavelengths of a mesh on one rank), one all-gather of the records per step."""
@@ -494,25 +513,16 @@ def run_sweep_config(args, D: Dist):
     D.sync()
     if hasattr(solve, "timeline"):
         solve.timeline.clear()
+        solve.prepared.clear()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         table, n_local = run_sweep(items, D.rank, world, solve=solve, device=device, lanes=lanes)
     D.sync()
     elapsed = D.max_over_ranks(time.perf_counter() - t0)
-    host = None
-    if hasattr(solve, "timeline") and solve.timeline:
-        # host-side picture of rank 0's lanes over the timed sweeps: share of the wall time a lane spends inside a solve call,
-        # and of that the wait for a mesh's analysis (prepared ahead by background threads) and the number of contexts made
-        tl = list(solve.timeline)
-        lanes_seen = sorted({t[0] for t in tl})
-        wall = time.perf_counter() - t0
-        host = {"lanes": len(lanes_seen),
-                "busy_fraction_per_lane": [round(sum(t[4] - t[2] for t in tl if t[0] == ln) / wall, 3) for ln in lanes_seen],
-                "analysis_wait_ms_total": round(1e3 * sum(t[3] - t[2] for t in tl), 2),
-                "contexts_created": int(sum(1 for t in tl if t[5])), "solves": len(tl)}
+    host = _host_picture(solve, time.perf_counter() - t0) if hasattr(solve, "timeline") else None
     # the same sweep with the mesh producer INSIDE the timed region (Delaunay + refinement per cross-section, overlapped
-    # with the solves by the sweep's preparer thread): reported beside the headline, which keeps its inputs resident
-    elapsed_mesh = None
+    # with the solves by the sweep's preparer threads): reported beside the headline, which keeps its inputs resident
+    elapsed_mesh = host_mesh = None
     if not D.fake:
         solve_m = default_solve(D.local_rank, meshes=None)
         D.sync()
@@ -520,7 +530,8 @@ def run_sweep_config(args, D: Dist):
         for _ in range(args.steps):
             table_m, _n = run_sweep(items, D.rank, world, solve=solve_m, device=device, lanes=lanes)
         D.sync()
-        elapsed_mesh = D.max_over_ranks(time.perf_counter() - t1)
+        wall_m = time.perf_counter() - t1
+        elapsed_mesh, host_mesh = D.max_over_ranks(wall_m), _host_picture(solve_m, wall_m)
         if D.rank == 0:
             assert all(np.array_equal(table_m[i], table[i]) for i in table)
     if D.rank != 0:
@@ -542,8 +553,9 @@ def run_sweep_config(args, D: Dist):
     if elapsed_mesh is not None:
         out["sweep"]["with_mesh_production"] = {"ms_per_step": elapsed_mesh / args.steps * 1e3,
                                                 "value": args.steps * len(items) * N_MODES / elapsed_mesh, "unit": "modes/s",
+                                                "host_timeline_rank0": host_mesh,
                                                 "note": "MeshGenerator recipe (Delaunay + 1 refinement) of the 16 cross-sections inside the "
-                                                        "timed region, prepared ahead of the lanes on a host thread"}
+                                                        "timed region, prepared ahead of the lanes by up to 4 host threads"}
     return out
 
 

@@ -109,8 +109,10 @@ def default_solve(device: Optional[int] = None, meshes: Optional[dict] = None) -
     lane or background thread asks first (``solve.prepare(item)``), and shared by every lane: the four wavelengths of a
     cross-section can then run on four lanes, each with its own context on the one analysis.  ``meshes``: optional
     ``{item.mesh_key: TriMesh}`` of meshes produced beforehand (bench.py keeps the mesh producer, the step before the
-    path, outside its timed region); missing keys are generated on demand.  Mesh generation (SciPy Delaunay + native
-    refinement) and the analysis release the GIL, so a background ``prepare`` overlaps with the GPU solves."""
+    path, outside its timed region); missing keys are generated on demand.  Mesh generation (Qhull + native refinement)
+    and the analysis release the GIL, so a background ``prepare`` overlaps with the GPU solves: with the mesh producer
+    inside the timed region the 64-solve sweep takes 0.03-0.06 s longer (bench.py --sweep, ``with_mesh_production``; worker
+    processes for the Delaunay stage were tried and measured the same as the threads)."""
     import threading
 
     from . import _native
@@ -122,6 +124,7 @@ def default_solve(device: Optional[int] = None, meshes: Optional[dict] = None) -
     lock = threading.Lock()
     shared: Dict[tuple, dict] = {}          # mesh_key -> {"ready": Event, "mesh", "sym", "error"}
     timeline: list = []                     # (lane thread id, item index, t_start, t_analysis_ready, t_end, new context?)
+    prepared: list = []                     # (mesh_key, t_start, t_mesh_ready, t_analysis_ready) of every mesh made here
 
     def prepare(item: SweepItem) -> dict:
         with lock:
@@ -131,10 +134,13 @@ def default_solve(device: Optional[int] = None, meshes: Optional[dict] = None) -
                 ent = shared[item.mesh_key] = {"ready": threading.Event(), "error": None}
         if mine:
             try:
+                t0 = _time.perf_counter()
                 mesh = (meshes or {}).get(item.mesh_key)
                 if mesh is None:
                     mesh = generate_mesh(item.geometry(), item.mesh_refinement, item.mesh_levels)
+                t1 = _time.perf_counter()
                 ent["mesh"], ent["sym"] = mesh, _native.Symbolic(mesh.p, mesh.t)
+                prepared.append((item.mesh_key, t0, t1, _time.perf_counter()))
             except Exception as exc:            # noqa: BLE001 - every waiter sees it
                 ent["error"] = exc
             ent["ready"].set()
@@ -171,6 +177,7 @@ def default_solve(device: Optional[int] = None, meshes: Optional[dict] = None) -
     solve.prepare = prepare
     solve.release = release
     solve.timeline = timeline               # host-side picture of a sweep (bench.py --sweep reports lane utilisation)
+    solve.prepared = prepared
     return solve
 
 
