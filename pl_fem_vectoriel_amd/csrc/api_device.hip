@@ -297,6 +297,12 @@ int create_impl(plfem_ctx* c, const plfem_symbolic* sym, int device, void* strea
         else
           pos += (int64_t)nt * (nt + 1) / 2;
       };
+      auto block_rows = [&](int f) {                     // (f, kb) for the block rows kb >= 1 of F11, last (longest) first
+        for (int kb = cdiv(fs2[f], plfem::NB) - 1; kb >= 1; --kb) {
+          if (out) out[pos] = make_int2(f, kb);
+          ++pos;
+        }
+      };
       for (int lev = 0; lev <= S.L; ++lev) {
         LevelInfo& li = c->levels[lev];
         const int32_t* o = forder.data() + li.first;
@@ -313,15 +319,18 @@ int create_impl(plfem_ctx* c, const plfem_symbolic* sym, int device, void* strea
             const int f = o[q];
             const int t0 = k0 + std::min(plfem::NB, fs2[f] - k0);
             const int nt = cdiv(fm[f] - t0, 64);
-            // even step of a front that has a next one: only the block column of its next pivot block (k_ldl_update<0>)
-            if ((kb & 1) == 0 && t0 < fs2[f]) rect(f, nt, std::min(nt, 1));
-            else lower(f, nt);
+            // even step of a front that has a next one: nothing (the columns of its next pivot block are the column
+            // workgroups' job, the rest waits for the rank-64 pass of the odd step: k_ldl_update)
+            if (!((kb & 1) == 0 && t0 < fs2[f])) lower(f, nt);
           }
           c->upd_n.push_back((int)(pos - c->upd_off.back()));
         }
         li.formz_off = pos;
         for (int q = 0; q < li.count; ++q) rect(o[q], cdiv(fm[o[q]] - fs2[o[q]], 64), cdiv(fs2[o[q]], 64));
         li.formz_n = (int)(pos - li.formz_off);
+        li.mirrorx_off = pos;
+        for (int q = 0; q < li.count; ++q) block_rows(o[q]);
+        li.mirrorx_n = (int)(pos - li.mirrorx_off);
       }
       // the same Z blocks once more as ONE list over all levels, root first: nothing in the factorisation reads Z, so
       // a complete run forms it for every front in a single launch at the end (the per-level lists above serve
@@ -333,6 +342,14 @@ int create_impl(plfem_ctx* c, const plfem_symbolic* sym, int device, void* strea
         for (int q = 0; q < li.count; ++q) rect(o[q], cdiv(fm[o[q]] - fs2[o[q]], 64), cdiv(fs2[o[q]], 64));
       }
       c->formz_all_n = (int)(pos - c->formz_all_off);
+      // block rows >= 1 of every F11 (k_mirror_x), largest first within a level
+      c->mirrorx_all_off = pos;
+      for (int lev = 0; lev <= S.L; ++lev) {
+        const LevelInfo& li = c->levels[lev];
+        const int32_t* o = forder.data() + li.first;
+        for (int q = 0; q < li.count; ++q) block_rows(o[q]);
+      }
+      c->mirrorx_all_n = (int)(pos - c->mirrorx_all_off);
       ntiles = pos;
     }
     if (size_only) tiles.resize((size_t)ntiles);          // only its size matters to the placement pass
@@ -377,7 +394,6 @@ int create_impl(plfem_ctx* c, const plfem_symbolic* sym, int device, void* strea
   const int64_t fnodes_total = S.fnode_ptr[S.nfronts];
   TRY(dalloc(c, &c->d_front, (size_t)S.foff[S.nfronts]));
   c->arena_doubles = (S.arena_doubles + 31) & ~(int64_t)31;
-  TRY(dalloc(c, &c->d_schur, (size_t)2 * c->arena_doubles));
   TRY(dalloc(c, &c->d_fvec, (size_t)2 * fnodes_total * plfem::BLOCK_P));
   c->fnodes_total = fnodes_total;
   // panel / block-row scratch of the factorisation: one tree level is in flight at a time, so these are sized by the
@@ -388,21 +404,28 @@ int create_impl(plfem_ctx* c, const plfem_symbolic* sym, int device, void* strea
     level_nodes = std::max(level_nodes, S.fnode_ptr[last] - S.fnode_ptr[first]);
   }
   c->level_nodes_max = level_nodes;
-  TRY(dalloc(c, &c->d_wbuf, (size_t)4 * level_nodes * plfem::NB));   // two halves: panels of even / odd block steps
-  TRY(dalloc(c, &c->d_rbuf, (size_t)4 * level_nodes * plfem::NB));
+  // What only the factorisation needs (Schur arenas, panels) and what only the Lanczos drivers need (the bases V, B V and
+  // their restart copies) are never alive at the same time -- a context factorises, then iterates, on one stream -- and
+  // share one region of the workspace.
+  const size_t union_start = c->slab_off;
+  TRY(dalloc(c, &c->d_schur, (size_t)2 * c->arena_doubles));
+  TRY(dalloc(c, &c->d_wbuf, (size_t)6 * level_nodes * plfem::NB));   // three thirds: panels of block steps kb mod 3
+  TRY(dalloc(c, &c->d_rbuf, (size_t)6 * level_nodes * plfem::NB));
+  const size_t factor_end = c->slab_off;
+  const size_t n2 = (size_t)c->n2, nc1 = (size_t)max_ncv + 1 + plfem::BLOCK_P;
+  c->slab_off = union_start;
+  TRY(dalloc(c, &c->d_V, n2 * nc1));
+  TRY(dalloc(c, &c->d_BV, n2 * nc1));
+  TRY(dalloc(c, &c->d_V2, n2 * nc1));
+  TRY(dalloc(c, &c->d_BV2, n2 * nc1));
+  c->slab_off = std::max(c->slab_off, factor_end);
   TRY(dalloc(c, &c->d_dinv, (size_t)2 * S.nfronts * plfem::NB * plfem::NB));   // X of the pivot blocks, by block-step parity
   TRY(dalloc(c, &c->d_delta, (size_t)4 * fnodes_total));   // D^-1: (diagonal, off-diagonal) per front row
-  TRY(dalloc(c, &c->d_tbuf, (size_t)2 * level_nodes * plfem::NB));
   TRY(dalloc(c, &c->d_fvec2, (size_t)2 * fnodes_total * plfem::BLOCK_P));
   TRY(dalloc(c, &c->d_u0, (size_t)2 * fnodes_total * plfem::BLOCK_P));
   TRY(dalloc(c, &c->d_u1, (size_t)2 * fnodes_total * plfem::BLOCK_P));
   TRY(dalloc(c, &c->d_xl, (size_t)2 * fnodes_total * plfem::BLOCK_P));
   TRY(dalloc(c, &c->d_counters, 4));
-  const size_t n2 = (size_t)c->n2, nc1 = (size_t)max_ncv + 1 + plfem::BLOCK_P;
-  TRY(dalloc(c, &c->d_V, n2 * nc1));
-  TRY(dalloc(c, &c->d_BV, n2 * nc1));
-  TRY(dalloc(c, &c->d_V2, n2 * nc1));
-  TRY(dalloc(c, &c->d_BV2, n2 * nc1));
   TRY(dalloc(c, &c->d_w, n2 * plfem::BLOCK_P));
   TRY(dalloc(c, &c->d_bw, n2 * plfem::BLOCK_P));
   TRY(dalloc(c, &c->d_hblk, (nc1 + 8) * plfem::BLOCK_P));

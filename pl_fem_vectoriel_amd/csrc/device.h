@@ -36,8 +36,8 @@ struct LevelInfo {
   // fronts in order of decreasing work so that the long ones start first
   // factorisation: 64 x 64 tile lists (d_tiles) of the extend-add, of Z, and (per block step: upd_off / upd_n of
   // the context, index step0 + kb) of the trailing updates
-  int64_t gather_off = 0, formz_off = 0;
-  int gather_n = 0, formz_n = 0, step0 = 0;
+  int64_t gather_off = 0, formz_off = 0, mirrorx_off = 0;
+  int gather_n = 0, formz_n = 0, mirrorx_n = 0, step0 = 0;
   int fwd_rows = 0, bwd_rows = 0;      // rows per workgroup of the forward / backward kernel of this level
   bool fwd_mixed = false;              // tile-form level with at least one long front (row-form workgroups in the same launch)
   int64_t fwd_off = 0, bwd_off = 0;    // first entry in d_blk
@@ -69,6 +69,8 @@ struct plfem_ctx {
   std::vector<int> upd_n;
   int64_t formz_all_off = 0;      // d_tiles: the Z blocks of every front in one list (root first)
   int formz_all_n = 0;
+  int64_t mirrorx_all_off = 0;    // d_tiles: (front, block row >= 1) of every front, for k_mirror_x
+  int mirrorx_all_n = 0;
   int2* d_blk = nullptr;          // (front, row block) of every sweep workgroup, level by level
   int32_t *d_tsorted = nullptr, *d_edof = nullptr, *d_rowptr = nullptr, *d_colind = nullptr;
   int32_t *d_slot_row = nullptr, *d_nptr = nullptr, *d_nadj = nullptr, *d_interior = nullptr;
@@ -95,7 +97,6 @@ struct plfem_ctx {
   double *d_wbuf = nullptr, *d_rbuf = nullptr;   // per-front panels m x NB of the level in flight, offset 2*(fnode_ptr[f] - fnode_ptr[level first])*NB
   double* d_dinv = nullptr;       // 2 x per-front NB x NB (inverse of the unit-lower pivot block of even / odd block steps)
   double* d_delta = nullptr;      // per-front D^-1 of the block LDL^T: (diagonal, off-diagonal of the node pair) per row, offset 2 * (2*fnode_ptr[f])
-  double* d_tbuf = nullptr;       // per-front NB x s2 scratch (block row of L11) of the level in flight, same offsets
   double* d_fvec2 = nullptr;      // forward-sweep results of the owned rows (t = L11^-1 r; the backward sweep applies D^-1), front order
   int32_t* d_counters = nullptr;  // [0] pivot perturbations
   // ---- Lanczos workspace

@@ -353,111 +353,32 @@ __device__ __forceinline__ void store_pivot_results(int f, int k0, int nbk, cons
     reinterpret_cast<double2*>(delta)[2 * fnode_ptr[f] + k0 + threadIdx.x] = make_double2(sDd[threadIdx.x], sDo[threadIdx.x]);
 }
 
-// Launch A of a block step: pivot block + panel.  At the FIRST step of a level every panel workgroup (64 rows below the
-// pivot block, 4 waves of 16 rows) factorises the pivot block itself -- the same arithmetic in every workgroup, so the same
-// bits -- while its panel operands are in flight (workgroup 0 of the front stores X in dinv and D^-1 in delta).  At every
-// later step the pivot block was factorised one launch EARLIER, by a look-ahead workgroup of the previous update launch,
-// where its chain of 16 dependent pair steps (7 us) runs beside the trailing update instead of in front of the panel: the
-// panel workgroups only load X and D^-1.  Nobody writes the pivot block in this launch (it is written back into F by the
-// next launch).  Panel: Y = R X^T (= R L^-T), W = Y D^-1 (= the L panel; D^-1 couples the two columns of a
-// node pair: the partner column of an accumulator register sits in lane ^ 16); W, Y are saved for the update kernel and
-// W replaces R in F (a workgroup reads and writes its own rows only).
-// blockIdx.y < n_tb: these workgroups save the block row L[k, <k] of L11 for the triangular-inverse update (tbuf).
-__global__ __launch_bounds__(256) void k_ldl_pivot_panel(int n_tb, const int32_t* __restrict__ forder, int kb,
-                                                         const int32_t* __restrict__ fs2, const int32_t* __restrict__ fm,
-                                                         const int64_t* __restrict__ foff, const int64_t* __restrict__ fnode_ptr,
-                                                         double* __restrict__ front, double* __restrict__ dinv,
-                                                         double* __restrict__ delta, double* __restrict__ tbuf,
-                                                         double* __restrict__ wbuf, double* __restrict__ rbuf,
-                                                         int32_t* __restrict__ counters) {
-  const int f = forder[blockIdx.x];
-  const int s2 = fs2[f];
-  const int k0 = kb * NB;
-  if (k0 >= s2) return;
-  const int nbk = min(NB, s2 - k0);
-  const int m = fm[f];
-  double* F = front + foff[f];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  if ((int)blockIdx.y < n_tb) {
-    // tbuf[q + j*NB] = L[k0+q, j] for the 64 columns j of this block, 16 per wave
-    const int jb = blockIdx.y * 64 + 16 * wave;
-    if (jb >= k0) return;
-    double* T = tbuf + 2 * fnode_ptr[f] * NB;
-    const int q = lane & 31, jh = lane >> 5;
-#pragma unroll
-    for (int jj = 0; jj < 16; jj += 2) {
-      const int j = jb + jj + jh;
-      if (j < k0) T[(int64_t)j * NB + q] = (q < nbk) ? F[(int64_t)j * m + (k0 + q)] : 0.0;
-    }
-    return;
-  }
-  // panel workgroup bx of this front takes the 64-row chunks bx, bx + n_pan, ... below the pivot block (n_pan workgroups
-  // per front: all chunks in parallel at the top of the tree, where the step is latency; at most two workgroups per
-  // front where a level has hundreds of fronts and every extra workgroup is one more redundant pivot factorisation)
-  const int bx = blockIdx.y - n_tb;
-  const int n_pan = gridDim.y - n_tb;
-  const int t0 = k0 + nbk;
-  if (bx > 0 && t0 + bx * 64 >= m) return;
-  __shared__ __attribute__((aligned(16))) PivotLds piv;
-  __shared__ double tile[NB][NB + 1];
-  __shared__ double sDd[NB], sDo[NB];
-  // this wave's 16 panel rows of the first chunk: B operand R^T (k = pivot column j, col = row i), requested before the
-  // pivot work
-  const int lr = lane & 15, lk = lane >> 4;
-  double b[NB / 4];
-  {
-    const int ibase = t0 + bx * 64 + 16 * wave;
+// The panel of a block step, 16 rows of a wave: Y = R X^T (= R L^-T), W = Y D^-1 (= the L panel; D^-1 couples the two
+// columns of a node pair: the partner column of an accumulator register sits in lane ^ 16).  W, Y are saved for the update
+// kernel and W replaces R in F (a wave reads and writes its own rows only).
+//   Y^T[c][i] = sum_j X[c][j] R[i][j] on v_mfma_f64_16x16x4_f64: A <- X (row c, k = j; xa0 / xa1 = rows lr / 16 + lr of the
+//   LDS tile), B <- R^T (b[kk] = R[i][4 kk + lk]); the accumulator register r of lane l is Y[i][c = 16 tc + (l >> 4) + 4 r]:
+//   128-B runs of W, Y and of the panel columns of F.
+struct PanelOperands {
+  double xa0[NB / 4], xa1[NB / 4], rdd[2][4], rdo[2][4];
+  __device__ __forceinline__ void load(const double (*tile)[NB + 1], const double* sDd, const double* sDo, int nbk, int lr, int lk) {
 #pragma unroll
     for (int kk = 0; kk < NB / 4; ++kk) {
-      const int jx = 4 * kk + lk;
-      b[kk] = (ibase < m && jx < nbk) ? F[(int64_t)(k0 + jx) * m + ibase + lr] : 0.0;
+      xa0[kk] = tile[lr][4 * kk + lk];
+      xa1[kk] = tile[16 + lr][4 * kk + lk];
     }
-  }
-  if (kb == 0) {
-    ldl_pivot_block(F + (int64_t)k0 * m + k0, m, nbk, threadIdx.x, tile, sDd, sDo, piv, bx == 0 ? counters : nullptr);
-    __syncthreads();
-    if (bx == 0) store_pivot_results(f, k0, nbk, fnode_ptr, dinv, delta, tile, sDd, sDo);
-  } else {
-    // the pivot block of this step was factorised by the look-ahead workgroup of the previous update launch
-    const double* D = dinv + (int64_t)f * NB * NB;
-    for (int e = threadIdx.x; e < NB * NB; e += 256) tile[e & (NB - 1)][e >> 5] = D[e];
-    if (threadIdx.x < NB) {
-      const double2 d = threadIdx.x < nbk ? reinterpret_cast<const double2*>(delta)[2 * fnode_ptr[f] + k0 + threadIdx.x] : make_double2(1.0, 0.0);
-      sDd[threadIdx.x] = d.x;
-      sDo[threadIdx.x] = d.y;
-    }
-    __syncthreads();
-  }
-  // Y^T[c][i] = sum_j X[c][j] R[i][j] on v_mfma_f64_16x16x4_f64: A <- X (row c, k = j), B <- R^T; the accumulator
-  // register r of lane l is Y[i = ibase + (l & 15)][c = 16 tc + (l >> 4) + 4 r]: 128-B runs of W, Y and of the panel
-  // columns of F.
-  double* W = wbuf + 2 * fnode_ptr[f] * NB;
-  double* Y = rbuf + 2 * fnode_ptr[f] * NB;
-  double xa0[NB / 4], xa1[NB / 4], rdd[2][4], rdo[2][4];
 #pragma unroll
-  for (int kk = 0; kk < NB / 4; ++kk) {
-    xa0[kk] = tile[lr][4 * kk + lk];
-    xa1[kk] = tile[16 + lr][4 * kk + lk];
-  }
+    for (int tc = 0; tc < 2; ++tc)
 #pragma unroll
-  for (int tc = 0; tc < 2; ++tc)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int c = 16 * tc + lk + 4 * r;
-      rdd[tc][r] = (c < nbk) ? sDd[c] : 0.0;
-      rdo[tc][r] = (c < nbk) ? sDo[c] : 0.0;
-    }
-  for (int ch = bx; t0 + ch * 64 < m; ch += n_pan) {
-    const int ibase = t0 + ch * 64 + 16 * wave;
-    if (ibase >= m) break;                                 // m is a multiple of 16: the wave's 16 rows are all valid
-    const int i = ibase + lr;
-    if (ch != bx) {
-#pragma unroll
-      for (int kk = 0; kk < NB / 4; ++kk) {
-        const int jx = 4 * kk + lk;
-        b[kk] = (jx < nbk) ? F[(int64_t)(k0 + jx) * m + i] : 0.0;
+      for (int r = 0; r < 4; ++r) {
+        const int c = 16 * tc + lk + 4 * r;
+        rdd[tc][r] = (c < nbk) ? sDd[c] : 0.0;
+        rdo[tc][r] = (c < nbk) ? sDo[c] : 0.0;
       }
-    }
+  }
+  // kcol: first column of the pivot block in the front; i: this lane's row
+  __device__ __forceinline__ void rows(const double (&b)[NB / 4], int nbk, int kcol, int64_t m, int i, int lk,
+                                       double* __restrict__ W, double* __restrict__ Y, double* __restrict__ F) const {
     v4d y0 = (v4d){0.0, 0.0, 0.0, 0.0}, y1 = (v4d){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int kk = 0; kk < NB / 4; ++kk) {
@@ -473,25 +394,88 @@ __global__ __launch_bounds__(256) void k_ldl_pivot_panel(int n_tb, const int32_t
         const double w = fma(y, rdd[tc][r], lane_xor16(y, lk & 1) * rdo[tc][r]);   // (the pair's other column: lane ^ 16)
         W[(int64_t)c * m + i] = w;
         Y[(int64_t)c * m + i] = y;
-        if (c < nbk) F[(int64_t)(k0 + c) * m + i] = w;
+        if (c < nbk) F[(int64_t)(kcol + c) * m + i] = w;
       }
   }
-  // (no mirrored copy L^T in the rows of the pivot block: those entries are overwritten -- by the triangular-inverse
-  // update inside F11, by Z^T in F12 -- before anything reads them)
+};
+
+// First launch of a LEVEL: pivot block + panel of block step 0 (every later step's pivot block and panel come out of the
+// update launch of the step before it, ldl_column_block).  Every panel workgroup (64 rows below the pivot block, 4 waves
+// of 16 rows) factorises the pivot block itself -- the same arithmetic in every workgroup, so the same bits -- while its
+// panel operands are in flight; workgroup 0 of the front stores X in dinv and D^-1 in delta.  Nobody writes the pivot block
+// in this launch (it is written back into F by the next one).
+// (no mirrored copy L^T in the rows of the pivot block: those entries are overwritten -- by the triangular-inverse
+// update inside F11, by Z^T in F12 -- before anything reads them)
+__global__ __launch_bounds__(256) void k_ldl_first_panel(const int32_t* __restrict__ forder, const int32_t* __restrict__ fs2,
+                                                         const int32_t* __restrict__ fm, const int64_t* __restrict__ foff,
+                                                         const int64_t* __restrict__ fnode_ptr, double* __restrict__ front,
+                                                         double* __restrict__ dinv, double* __restrict__ delta,
+                                                         double* __restrict__ wbuf, double* __restrict__ rbuf,
+                                                         int32_t* __restrict__ counters) {
+  const int f = forder[blockIdx.x];
+  const int s2 = fs2[f];
+  const int nbk = min(NB, s2);
+  const int m = fm[f];
+  double* F = front + foff[f];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  // panel workgroup bx of this front takes the 64-row chunks bx, bx + n_pan, ... below the pivot block (n_pan workgroups
+  // per front: all chunks in parallel at the top of the tree, where the step is latency; at most two workgroups per
+  // front where a level has hundreds of fronts and every extra workgroup is one more redundant pivot factorisation)
+  const int bx = blockIdx.y;
+  const int n_pan = gridDim.y;
+  const int t0 = nbk;
+  if (bx > 0 && t0 + bx * 64 >= m) return;
+  __shared__ __attribute__((aligned(16))) PivotLds piv;
+  __shared__ double tile[NB][NB + 1];
+  __shared__ double sDd[NB], sDo[NB];
+  // this wave's 16 panel rows of the first chunk, requested before the pivot work
+  const int lr = lane & 15, lk = lane >> 4;
+  double b[NB / 4];
+  {
+    const int ibase = t0 + bx * 64 + 16 * wave;
+#pragma unroll
+    for (int kk = 0; kk < NB / 4; ++kk) {
+      const int jx = 4 * kk + lk;
+      b[kk] = (ibase < m && jx < nbk) ? F[(int64_t)jx * m + ibase + lr] : 0.0;
+    }
+  }
+  ldl_pivot_block(F, m, nbk, threadIdx.x, tile, sDd, sDo, piv, bx == 0 ? counters : nullptr);
+  __syncthreads();
+  if (bx == 0) store_pivot_results(f, 0, nbk, fnode_ptr, dinv, delta, tile, sDd, sDo);
+  double* W = wbuf + 2 * fnode_ptr[f] * NB;
+  double* Y = rbuf + 2 * fnode_ptr[f] * NB;
+  PanelOperands po;
+  po.load(tile, sDd, sDo, nbk, lr, lk);
+  for (int ch = bx; t0 + ch * 64 < m; ch += n_pan) {
+    const int ibase = t0 + ch * 64 + 16 * wave;
+    if (ibase >= m) break;                                 // m is a multiple of 16: the wave's 16 rows are all valid
+    const int i = ibase + lr;
+    if (ch != bx) {
+#pragma unroll
+      for (int kk = 0; kk < NB / 4; ++kk) {
+        const int jx = 4 * kk + lk;
+        b[kk] = (jx < nbk) ? F[(int64_t)jx * m + i] : 0.0;
+      }
+    }
+    po.rows(b, nbk, 0, m, i, lk, W, Y, F);
+  }
 }
 
 // Triangular-inverse update: with X<k the inverse of the leading k0 x k0 block of L11,
 //   X[k, <k] = -X[k,k] * ( L[k, <k] * X<k ).
 // One workgroup per 16 columns c, both products on v_mfma_f64_16x16x4_f64:
-//   T (32 x 16) = L[k, j>=c0] (A: tbuf, contiguous in q) * X<k[j, c] (B: upper mirror, contiguous in c);
+//   T (32 x 16) = L[k, j>=c0] (A: rows k of the panel columns j in F, contiguous in q) * X<k[j, c] (B: upper mirror,
+//   contiguous in c);
 //   the accumulator register r of lane (lr, lk) holds T[lk + 4 r][lr], which is exactly the B operand
 //   of k-step r of the second product  Xnew = -X[k,k] * T  -- no cross-lane movement.
+// During the factorisation X lives in the UPPER triangle of F11 only (X^T: all that later block rows and k_form_z read):
+// the lower triangle keeps L, which the other workgroups of this block row are still reading, and receives X at the very
+// end (k_mirror_x) for the forward sweep.
 // The 4 waves split the j range (late steps of a long front: k0 / 32 dependent memory round trips for one wave) and
 // their partial T meet in LDS in a fixed order; wave 0 finishes.
 __device__ __forceinline__ void ldl_invrow_block(int f, int bx, int kb, const int32_t* __restrict__ fs2,
                                                  const int32_t* __restrict__ fm, const int64_t* __restrict__ foff,
-                                                 const int64_t* __restrict__ fnode_ptr, double* __restrict__ front,
-                                                 const double* __restrict__ dinv, const double* __restrict__ tbuf,
+                                                 double* __restrict__ front, const double* __restrict__ dinv,
                                                  double* __restrict__ part /* LDS [3][8][64] */) {
   const int s2 = fs2[f];
   const int k0 = kb * NB;
@@ -502,7 +486,6 @@ __device__ __forceinline__ void ldl_invrow_block(int f, int bx, int kb, const in
   const int nbk = min(NB, s2 - k0);
   const int m = fm[f];
   double* F = front + foff[f];
-  const double* T = tbuf + 2 * fnode_ptr[f] * NB;      // T[q + j*NB] = L[k0+q, j]
   const double* D = dinv + (int64_t)f * NB * NB;       // D[r + q*NB] = X[k,k][r][q]
   const int lr = lane & 15, lk = lane >> 4;
   const int c = c0 + lr;
@@ -516,8 +499,8 @@ __device__ __forceinline__ void ldl_invrow_block(int f, int bx, int kb, const in
 #pragma unroll
     for (int t = 0; t < 4 * G; ++t) {
       const int j = j0 + 4 * t + lk;
-      a0[t] = T[(int64_t)j * NB + lr];
-      a1[t] = T[(int64_t)j * NB + 16 + lr];
+      a0[t] = F[(int64_t)j * m + k0 + lr];                        // L[k0 + lr, j] (rows past nbk belong to F21)
+      a1[t] = (nbk > 16) ? F[(int64_t)j * m + k0 + 16 + lr] : 0.0;
       b[t] = (j >= c) ? F[(int64_t)j * m + c] : 0.0;            // X<k[j, c] (unit diagonal stored)
     }
 #pragma unroll
@@ -560,14 +543,8 @@ __device__ __forceinline__ void ldl_invrow_block(int f, int bx, int kb, const in
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int r0 = lk + 4 * r, r1 = 16 + lk + 4 * r;
-    if (r0 < nbk) {
-      F[(int64_t)c * m + (k0 + r0)] = x0[r];
-      F[(int64_t)(k0 + r0) * m + c] = x0[r];
-    }
-    if (r1 < nbk) {
-      F[(int64_t)c * m + (k0 + r1)] = x1[r];
-      F[(int64_t)(k0 + r1) * m + c] = x1[r];
-    }
+    if (r0 < nbk) F[(int64_t)(k0 + r0) * m + c] = x0[r];
+    if (r1 < nbk) F[(int64_t)(k0 + r1) * m + c] = x1[r];
   }
 }
 
@@ -577,11 +554,13 @@ __device__ __forceinline__ void ldl_invrow_block(int f, int bx, int kb, const in
 // (i) the accumulator register r of lane l is F[i0 + (l&15), j0 + (l>>4) + 4 r]: 128-B runs.
 // The read-modify-write of the trailing matrix is what bounds this kernel (2 flop/B at rank 32), so block
 // steps are paired and the matrix is rewritten once per PAIR:
-//   MODE 0, after an even step: a front that has a next step only updates the 32 columns of its next pivot
-//           block (all the next diag / panel kernels read); a front on its last step updates everything.
+//   MODE 0, after an even step: a front that has a next step leaves its trailing matrix alone (the columns of its next
+//           pivot block -- all the next step reads -- are the column workgroups' job, ldl_column_block); a front on its
+//           last step updates everything.
 //   MODE 1, after an odd step: rank-64 update of the trailing matrix with the panels of both steps
-//           (W0/Y0: the even step's, still valid for every row below the odd pivot block).
-// The panel kernel stores all NB columns of W and Y (zeros past nbk): fixed trip counts, and every operand
+//           (W0/Y0: the even step's, still valid for every row below the odd pivot block), again without the columns
+//           of the next pivot block.
+// The panel code stores all NB columns of W and Y (zeros past nbk): fixed trip counts, and every operand
 // of a rank-32 batch (32 loads) plus the 16 loads of the tile itself are requested before the first MFMA.
 template <int MODE>
 __device__ __forceinline__ void ldl_update_tile(const int2 job, int kb, const int32_t* __restrict__ fs2,
@@ -606,15 +585,16 @@ __device__ __forceinline__ void ldl_update_tile(const int2 job, int kb, const in
   // blocks are diagonal 32 x 32 blocks, panels lie below them, the extend-add swaps its indices), so the blocks
   // strictly above the diagonal are never updated
   if (i0 < j0) return;
-  // MODE 0 and a next step exists: only the columns of its pivot block now (32, or 16 if it is the front's
-  // last, partial block) -- everything to their right is updated once, by the rank-64 pass after that step
-  const bool next_only = MODE == 0 && t0 < s2;
-  if (next_only && j0 != t0) return;
+  // A next step exists: the columns of its pivot block (32, or 16 if it is the front's last, partial block) belong to the
+  // column workgroups of this launch (update + pivot + panel in one go).  MODE 0: everything to their right is updated
+  // once, by the rank-64 pass after that step.
+  const int ncol = (t0 < s2 && j0 == t0) ? min(NB, s2 - t0) : 0;
+  if ((MODE == 0 && t0 < s2) || ncol == NB) return;
   double* F = front + foff[f];                          // columns < s2 (all rows)
   double* S = schur_of(f, soff, schur, arena);          // columns >= s2, rows >= s2
   const int b2 = m - s2;
   const int lr = lane & 15, lk = lane >> 4;
-  const bool iv1 = i0 + 16 < m, jv1 = j0 + 16 < m && !(next_only && s2 - t0 <= 16);
+  const bool iv1 = i0 + 16 < m, jv1 = j0 + 16 < m;
   // a 16 x 16 quadrant lies on one side of s2 in either direction (s2, i0, j0 are multiples of 16); rows < s2 <= columns
   // is F12, which is not stored (it can only come up in the quadrant above the diagonal of a diagonal tile)
   auto quad_ok = [&](int tj, int ti) { return (tj == 0 || jv1) && (ti == 0 || iv1) && !(j0 + 16 * tj >= s2 && i0 + 16 * ti < s2); };
@@ -655,107 +635,175 @@ __device__ __forceinline__ void ldl_update_tile(const int2 job, int kb, const in
       acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[it], b1[it], acc[1][1], 0, 0, 0);
     }
   }
-  // the pivot block of the NEXT step (rows and columns [t0, t0 + nbn)) is updated, and factorised, by the look-ahead
-  // workgroup of this launch: nothing else reads it before the write-back of the next update launch replaces it
-  const int nbn = (i0 == t0 && j0 == t0 && t0 < s2) ? min(NB, s2 - t0) : 0;
 #pragma unroll
   for (int tj = 0; tj < 2; ++tj) {
 #pragma unroll
     for (int ti = 0; ti < 2; ++ti) {
       if (!quad_ok(tj, ti)) continue;
-      if (16 * tj < nbn && 16 * ti < nbn) continue;
+      if (16 * tj < ncol) continue;                      // (ncol = 16: the other 16 columns lie past s2, in S)
 #pragma unroll
       for (int r = 0; r < 4; ++r) *addr(tj, ti, r) = fv[tj][ti][r] - acc[tj][ti][r];
     }
   }
 }
 
-// Look-ahead workgroup of launch B: the pivot block of the front's NEXT block step -- rows and columns [t0, t0 + nbn) of
-// the trailing matrix -- receives this step's update here (wave w = quadrant (w & 1, w >> 1); rank 32 after an even
-// step, rank 64 with the panels of both steps after an odd one, exactly as ldl_update_tile would have done it), goes to
-// LDS instead of back to F, and is factorised on the spot: X -> dinv of the next step's parity, D^-1 -> delta.
+// Column workgroups of an update launch: everything the front's NEXT block step needs, so that the next launch can be that
+// step's update right away (one launch per block step; the first step of a level has k_ldl_first_panel).  With t0 the first
+// index behind this step's pivot block and nbn the order of the next one:
+//   1. the next pivot block -- rows and columns [t0, t0 + nbn) of the trailing matrix -- receives this step's update
+//      (wave w = quadrant (w & 1, w >> 1); rank 32 after an even step, rank 64 with the panels of both steps after an odd
+//      one, the arithmetic of ldl_update_tile), goes to LDS instead of back to F and is factorised on the spot.  Every
+//      column workgroup of the front does this for itself (same arithmetic, same bits); workgroup 0 stores X -> dinv of the
+//      next step's parity and D^-1 -> delta.  The chain of 16 dependent pair steps (7 us) runs beside the trailing update
+//      of the other workgroups.
+//   2. rows below it, 64 per workgroup and trip (chunks bx, bx + n_pan, ...), 16 per wave: columns [t0, t0 + nbn) get the
+//      same update in registers -- the accumulator layout of the update IS the B operand layout of the panel product
+//      (register r of quadrant tj = column 4 (r + 4 tj) + lk) -- and go through the panel code at once: W, Y into the
+//      buffers of the next step, W into F.  The first chunk's update is computed before the pivot chain starts.
 template <int MODE>
-__device__ __forceinline__ void ldl_lookahead_block(int f, int kb, const int32_t* __restrict__ fs2, const int32_t* __restrict__ fm,
-                                                    const int64_t* __restrict__ foff, const int64_t* __restrict__ fnode_ptr,
-                                                    const double* __restrict__ front, double* __restrict__ dinv_next,
-                                                    double* __restrict__ delta, const double* __restrict__ wbuf,
-                                                    const double* __restrict__ rbuf, const double* __restrict__ wbuf_prev,
-                                                    const double* __restrict__ rbuf_prev, int32_t* __restrict__ counters) {
+__device__ __forceinline__ void ldl_column_block(int f, int bx, int n_pan, int kb, const int32_t* __restrict__ fs2,
+                                                 const int32_t* __restrict__ fm, const int64_t* __restrict__ foff,
+                                                 const int64_t* __restrict__ fnode_ptr, double* __restrict__ front,
+                                                 double* __restrict__ dinv_next, double* __restrict__ delta,
+                                                 const double* __restrict__ wbuf, const double* __restrict__ rbuf,
+                                                 const double* __restrict__ wbuf_prev, const double* __restrict__ rbuf_prev,
+                                                 double* __restrict__ wbuf_next, double* __restrict__ rbuf_next,
+                                                 int32_t* __restrict__ counters) {
   const int s2 = fs2[f];
   const int k0 = kb * NB;
   const int t0 = k0 + NB;                      // (a front with a next step has a full block now)
   if (t0 >= s2) return;
   const int nbn = min(NB, s2 - t0);
   const int m = fm[f];
-  const double* F = front + foff[f];
+  const int t1 = t0 + nbn;                     // first row below the next pivot block
+  if (bx > 0 && t1 + bx * 64 >= m) return;
+  double* F = front + foff[f];
   __shared__ __attribute__((aligned(16))) PivotLds piv;
   __shared__ double tile[NB][NB + 1];
   __shared__ double sDd[NB], sDo[NB];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int lr = lane & 15, lk = lane >> 4;
-  const int ti = wave & 1, tj = wave >> 1;
-  if (16 * ti < nbn && 16 * tj < nbn) {
-    double fv[4];
+  const int64_t pbase = 2 * fnode_ptr[f] * NB;
+  const bool full = nbn > 16;
+  // One pass over the panels of this step (MODE 1: and of the step before) for 16 rows of this wave -- columns
+  // [t0, t0 + nbn) of rows ibase .. after the update, as B operand bq of the panel product -- and, with QUAD, for this wave's
+  // quadrant of the next pivot block as well.  The A operands (the rows of Y that belong to the next pivot block's columns)
+  // are asked for pass by pass and not kept: registers are what bounds the workgroups per CU of this kernel.
+  const int qi = wave & 1, qj = wave >> 1;
+  const bool quad_on = 16 * qi < nbn && 16 * qj < nbn;
+  auto strip = [&](int ibase, double (&bq)[NB / 4], auto QUAD_, int m, int64_t pbase) {
+    constexpr bool QUAD = decltype(QUAD_)::value;
+    const bool rows_on = ibase < m;
+    const int i = (rows_on ? ibase : t0) + lr;           // (no rows: a valid address, the result is dropped)
+    double fv[2][4], qv[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) fv[r] = F[(int64_t)(t0 + 16 * tj + lk + 4 * r) * m + (t0 + 16 * ti + lr)];
-    v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
+    for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) fv[tj][r] = (tj == 0 || full) ? F[(int64_t)(t0 + 16 * tj + lk + 4 * r) * m + i] : 0.0;
+    if (QUAD) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) qv[r] = quad_on ? F[(int64_t)(t0 + 16 * qj + lk + 4 * r) * m + (t0 + 16 * qi + lr)] : 0.0;
+    }
+    v4d acc[2] = {(v4d){0.0, 0.0, 0.0, 0.0}, (v4d){0.0, 0.0, 0.0, 0.0}};
+    v4d qacc = (v4d){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int pass = 0; pass <= MODE; ++pass) {
-      const double* W = (pass == 0 ? wbuf : wbuf_prev) + 2 * fnode_ptr[f] * NB;
-      const double* Y = (pass == 0 ? rbuf : rbuf_prev) + 2 * fnode_ptr[f] * NB;
-      double a[NB / 4], b[NB / 4];
+      const double* W = (pass == 0 ? wbuf : wbuf_prev) + pbase;
+      const double* Y = (pass == 0 ? rbuf : rbuf_prev) + pbase;
+      double ya[2][NB / 4], b[NB / 4], qb[NB / 4];
 #pragma unroll
       for (int it = 0; it < NB / 4; ++it) {
         const int64_t col = (int64_t)(4 * it + lk) * m;
-        a[it] = Y[col + t0 + 16 * tj + lr];
-        b[it] = W[col + t0 + 16 * ti + lr];
+        ya[0][it] = Y[col + t0 + lr];
+        ya[1][it] = full ? Y[col + t0 + 16 + lr] : 0.0;
+        b[it] = W[col + i];
+        if (QUAD) qb[it] = W[col + t0 + 16 * qi + lr];
       }
 #pragma unroll
-      for (int it = 0; it < NB / 4; ++it) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[it], b[it], acc, 0, 0, 0);
+      for (int it = 0; it < NB / 4; ++it) {
+        acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(ya[0][it], b[it], acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(ya[1][it], b[it], acc[1], 0, 0, 0);
+        if (QUAD) qacc = __builtin_amdgcn_mfma_f64_16x16x4f64(qj == 0 ? ya[0][it] : ya[1][it], qb[it], qacc, 0, 0, 0);
+      }
     }
-    // tile[c][i] = a[i][c]: column-major with leading dimension NB + 1, what ldl_pivot_block reads as src[i + c ld]
 #pragma unroll
-    for (int r = 0; r < 4; ++r) tile[16 * tj + lk + 4 * r][16 * ti + lr] = fv[r] - acc[r];
+    for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) bq[r + 4 * tj] = (tj == 0 || full) ? fv[tj][r] - acc[tj][r] : 0.0;
+    if (QUAD && quad_on) {
+      // tile[c][i] = a[i][c]: column-major with leading dimension NB + 1, what ldl_pivot_block reads as src[i + c ld]
+#pragma unroll
+      for (int r = 0; r < 4; ++r) tile[16 * qj + lk + 4 * r][16 * qi + lr] = qv[r] - qacc[r];
+    }
+  };
+  double bq[NB / 4];
+  const int ibase0 = t1 + bx * 64 + 16 * wave;
+  // 1. the next pivot block, and the first chunk's rows on the way
+  strip(ibase0, bq, std::true_type(), m, pbase);
+  __syncthreads();
+  ldl_pivot_block(&tile[0][0], NB + 1, nbn, threadIdx.x, tile, sDd, sDo, piv, bx == 0 ? counters : nullptr);
+  __syncthreads();
+  if (bx == 0) store_pivot_results(f, t0, nbn, fnode_ptr, dinv_next, delta, tile, sDd, sDo);
+  // 2. the panel of the next step (X and D^-1 are read from LDS again for every further chunk instead of being carried
+  // through its update: 64 registers)
+  double* Wn = wbuf_next + pbase;
+  double* Yn = rbuf_next + pbase;
+  if (ibase0 >= m) return;                                 // m is a multiple of 16: a wave's 16 rows are all valid
+  {
+    PanelOperands po;
+    po.load(tile, sDd, sDo, nbn, lr, lk);
+    po.rows(bq, nbn, t0, m, ibase0 + lr, lk, Wn, Yn, F);
   }
-  __syncthreads();
-  ldl_pivot_block(&tile[0][0], NB + 1, nbn, threadIdx.x, tile, sDd, sDo, piv, counters);
-  __syncthreads();
-  store_pivot_results(f, t0, nbn, fnode_ptr, dinv_next, delta, tile, sDd, sDo);
+  for (int ibase = ibase0 + n_pan * 64; ibase < m; ibase += n_pan * 64) {
+    // (m and the panel offset pass through an empty asm in every trip: as loop invariants the 40-odd addresses derived
+    // from them would be computed once and held in registers for the whole loop)
+    int ml = m;
+    int64_t pl = pbase;
+    asm volatile("" : "+s"(ml), "+s"(pl) : : "memory");
+    strip(ibase, bq, std::false_type(), ml, pl);
+    asm volatile("" ::: "memory");
+    PanelOperands po;
+    po.load(tile, sDd, sDo, nbn, lr, lk);
+    po.rows(bq, nbn, t0, ml, ibase + lr, lk, wbuf_next + pl, rbuf_next + pl, F);
+  }
 }
 
-// Launch B of a block step: the trailing update (workgroups [0, un): the step's tile list) and, for every active
-// front, the triangular-inverse update of the block row (n_inv workgroups) plus one workgroup that writes the pivot
-// block of this step (lower X, upper X^T, from dinv) back into F -- all independent of one another: the update touches
-// rows / columns behind the pivot block, the inverse update rows of the pivot block in earlier columns.
+// The launch of a block step (after the level's first panel there is ONE per step).  Workgroups, in this order:
+//   [0, n_look n_pan)  column workgroups of the fronts that have a next step (a prefix of the launch order): next pivot block
+//                      + next panel (ldl_column_block) -- the longest chain of the launch, so they start first;
+//   un                 trailing update, the step's tile list;
+//   nact (n_inv + 1)   per active front the triangular-inverse update of the block row (n_inv workgroups) plus one workgroup
+//                      that writes the pivot block of this step (lower X, upper X^T, from dinv) back into F
+// -- all independent of one another: the update touches rows / columns behind the next pivot block's columns, the column
+// workgroups those columns, the inverse update reads rows of this step's pivot block in earlier columns and writes their
+// mirror image.  W / Y of three consecutive steps are in flight (read: this step's and, rank 64, the one before;
+// written: the next step's), X of the pivot blocks of two.
 template <int MODE>
-__global__ __launch_bounds__(256) void k_ldl_update(int un, int n_inv, int n_look, const int2* __restrict__ tiles,
-                                                    const int32_t* __restrict__ forder, int kb, const int32_t* __restrict__ fs2,
-                                                    const int32_t* __restrict__ fm, const int64_t* __restrict__ foff,
-                                                    const int64_t* __restrict__ soff, const int64_t* __restrict__ fnode_ptr,
-                                                    double* __restrict__ front, double* __restrict__ schur, int64_t arena,
-                                                    const double* __restrict__ dinv, double* __restrict__ dinv_next,
-                                                    double* __restrict__ delta, const double* __restrict__ tbuf,
-                                                    const double* __restrict__ wbuf, const double* __restrict__ rbuf,
-                                                    const double* __restrict__ wbuf_prev, const double* __restrict__ rbuf_prev,
-                                                    int32_t* __restrict__ counters) {
-  // look-ahead workgroups first: theirs is the longest chain of the launch (the fronts with a next step are a prefix of
-  // the launch order)
-  if ((int)blockIdx.x < n_look) {
-    ldl_lookahead_block<MODE>(forder[blockIdx.x], kb, fs2, fm, foff, fnode_ptr, front, dinv_next, delta, wbuf, rbuf, wbuf_prev,
-                              rbuf_prev, counters);
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_ldl_update(
+    int un, int n_inv, int n_look, int n_pan, const int2* __restrict__ tiles, const int32_t* __restrict__ forder, int kb,
+    const int32_t* __restrict__ fs2, const int32_t* __restrict__ fm, const int64_t* __restrict__ foff,
+    const int64_t* __restrict__ soff, const int64_t* __restrict__ fnode_ptr, double* __restrict__ front,
+    double* __restrict__ schur, int64_t arena, const double* __restrict__ dinv, double* __restrict__ dinv_next,
+    double* __restrict__ delta, const double* __restrict__ wbuf, const double* __restrict__ rbuf,
+    const double* __restrict__ wbuf_prev, const double* __restrict__ rbuf_prev, double* __restrict__ wbuf_next,
+    double* __restrict__ rbuf_next, int32_t* __restrict__ counters) {
+  int bid = blockIdx.x;
+  if (bid < n_look * n_pan) {
+    ldl_column_block<MODE>(forder[bid / n_pan], bid % n_pan, n_pan, kb, fs2, fm, foff, fnode_ptr, front, dinv_next, delta, wbuf,
+                           rbuf, wbuf_prev, rbuf_prev, wbuf_next, rbuf_next, counters);
     return;
   }
-  const int bid = blockIdx.x - n_look;
+  bid -= n_look * n_pan;
   if (bid < un) {
     ldl_update_tile<MODE>(tiles[bid], kb, fs2, fm, foff, soff, fnode_ptr, front, schur, arena, wbuf, rbuf, wbuf_prev, rbuf_prev);
     return;
   }
-  const int e = bid - un;
-  const int f = forder[e / (n_inv + 1)];
-  const int sub = e % (n_inv + 1);
+  bid -= un;
+  const int f = forder[bid / (n_inv + 1)];
+  const int sub = bid % (n_inv + 1);
   if (sub < n_inv) {
     __shared__ double part[3 * 8 * 64];
-    ldl_invrow_block(f, sub, kb, fs2, fm, foff, fnode_ptr, front, dinv, tbuf, part);
+    ldl_invrow_block(f, sub, kb, fs2, fm, foff, front, dinv, part);
     return;
   }
   const int s2 = fs2[f];
@@ -768,6 +816,28 @@ __global__ __launch_bounds__(256) void k_ldl_update(int un, int n_inv, int n_loo
   for (int q = threadIdx.x; q < NB * NB; q += 256) {
     const int i = q & (NB - 1), c = q >> 5;
     if (i < nbk && c < nbk) F[(int64_t)(k0 + c) * m + (k0 + i)] = (i >= c) ? D[i + c * NB] : D[c + i * NB];
+  }
+}
+
+// lower(F11) = L11^-1 from its transpose in the upper triangle, once the front is factorised: the block row k (rows
+// [k0, k0 + 32), columns < k0) of one front per workgroup, 32 x 32 tiles through LDS.  job = (front, kb).
+__global__ __launch_bounds__(256) void k_mirror_x(const int2* __restrict__ jobs, const int32_t* __restrict__ fs2,
+                                                  const int32_t* __restrict__ fm, const int64_t* __restrict__ foff,
+                                                  double* __restrict__ front) {
+  const int2 job = jobs[blockIdx.x];
+  const int f = job.x, k0 = job.y * NB;
+  const int m = fm[f], s2 = fs2[f];
+  const int nbk = min(NB, s2 - k0);
+  double* F = front + foff[f];
+  __shared__ double tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+  for (int c0 = 0; c0 < k0; c0 += 32) {
+    for (int yy = ty; yy < 32; yy += 8)                     // X^T: column k0 + yy, rows c0 + tx (contiguous)
+      tile[yy][tx] = (yy < nbk) ? F[(int64_t)(k0 + yy) * m + c0 + tx] : 0.0;
+    __syncthreads();
+    for (int yy = ty; yy < 32; yy += 8)                     // X: column c0 + yy, rows k0 + tx (contiguous)
+      if (tx < nbk) F[(int64_t)(c0 + yy) * m + k0 + tx] = tile[tx][yy];
+    __syncthreads();
   }
 }
 
@@ -855,7 +925,8 @@ __global__ __launch_bounds__(256) void k_mirror_z(const int2* __restrict__ tiles
 
 void launch_factor(plfem_ctx* c, double sigma, int stop_level, int stop_step, int stop_stage) {
   // stop_*: debugging aid (plfem_debug_factor_until); stop_level < 0 = run to completion.
-  // stages: 0 assembled, 1 or 2 pivot + panel (launch A), 3 or 4 update + inverse row + pivot write-back (launch B), 5 level done
+  // stages: 0 assembled, 1 or 2 pivot block + panel of the step done (its own launch for step 0, the launch of the step before
+  // otherwise), 3 or 4 the step's launch done (update + inverse row + pivot write-back; next pivot block + panel), 5 level done
   hipStream_t st = c->stream;
   (void)hipMemsetAsync(c->d_counters, 0, 4 * sizeof(int32_t), st);
   for (int lev = c->L; lev >= 0; --lev) {
@@ -904,32 +975,37 @@ void launch_factor(plfem_ctx* c, double sigma, int stop_level, int stop_step, in
         nact = lo;
       }
       if (nact == 0) break;
-      const int max_trail = hpm[nact - 1] - k0 - 16;   // upper bound of the trailing order after this step
-      // W / Y of even and odd steps live in separate halves of wbuf / rbuf (see ldl_update_tile)
+      // W / Y of three consecutive steps live in separate thirds of wbuf / rbuf, X of the pivot blocks of two steps in
+      // halves of dinv (see k_ldl_update)
       // (the kernels address these buffers by 2 fnode_ptr[f] NB: the pointers handed to them are shifted back by the
       // offset of the level's first front, so that the level in flight starts at the beginning of the buffer)
-      const size_t half = (size_t)2 * c->level_nodes_max * NB;
+      const size_t third = (size_t)2 * c->level_nodes_max * NB;
       const int64_t base = 2 * c->S->fnode_ptr[li.first] * NB;
       double* wb0 = c->d_wbuf - base;
       double* rb0 = c->d_rbuf - base;
-      double* tb0 = c->d_tbuf - base;
-      double* wb = wb0 + (kb & 1) * half;
-      double* rb = rb0 + (kb & 1) * half;
-      // launch A: pivot block + panel (+ the copy of the block row of L11 for the triangular-inverse update)
-      const int n_tb = (k0 + 63) / 64;
-      // panel workgroups per front: all 64-row chunks in parallel where the level is a latency chain (few fronts), at
-      // most two where it is throughput (hundreds of fronts, each workgroup a redundant pivot factorisation);
-      // workgroup 0 always exists: it owns the pivot results
-      int n_pan = std::max(1, max_trail > 0 ? (max_trail + 63) / 64 : 0);
-      if (li.count > 64) n_pan = std::min(n_pan, 2);
-      // X of the pivot blocks: two buffers by the parity of the block step (the look-ahead of step kb writes the one
-      // step kb + 1 reads while step kb's inverse-row / write-back workgroups still read theirs)
+      double* wb = wb0 + (kb % 3) * third;
+      double* rb = rb0 + (kb % 3) * third;
+      double* wb_prev = wb0 + ((kb + 2) % 3) * third;
+      double* rb_prev = rb0 + ((kb + 2) % 3) * third;
+      double* wb_next = wb0 + ((kb + 1) % 3) * third;
+      double* rb_next = rb0 + ((kb + 1) % 3) * third;
       double* dinv_cur = c->d_dinv + (size_t)(kb & 1) * c->nfronts * NB * NB;
       double* dinv_nxt = c->d_dinv + (size_t)((kb + 1) & 1) * c->nfronts * NB * NB;
-      hipLaunchKernelGGL(k_ldl_pivot_panel, dim3(nact, n_tb + n_pan), dim3(256), 0, st, n_tb, ford, kb, c->d_fs2, c->d_fm,
-                         c->d_foff, c->d_fnode_ptr, c->d_front, dinv_cur, c->d_delta, tb0, wb, rb, c->d_counters);
+      // panel / column workgroups per front: all 64-row chunks in parallel where the level is a latency chain (few fronts);
+      // where it is throughput every extra workgroup is one more redundant pivot factorisation: at most `cap`
+      auto panel_wgs = [&](int rows_below, int cap) {
+        int n = std::max(1, rows_below > 0 ? (rows_below + 63) / 64 : 0);
+        return li.count > 64 ? std::min(n, cap) : n;
+      };
+      if (kb == 0) {
+        // first launch of the level: pivot block + panel of step 0
+        const int n_pan0 = panel_wgs(hpm[nact - 1] - 16, 2);
+        hipLaunchKernelGGL(k_ldl_first_panel, dim3(nact, n_pan0), dim3(256), 0, st, ford, c->d_fs2, c->d_fm, c->d_foff,
+                           c->d_fnode_ptr, c->d_front, dinv_cur, c->d_delta, wb, rb, c->d_counters);
+      }
       if (stop_here && stop_stage >= 1 && stop_stage <= 2) return;
-      // launch B: trailing update + triangular-inverse update + write-back of the pivot block
+      // the step's launch: trailing update + triangular-inverse update + write-back of the pivot block, and for the
+      // fronts with a next step its pivot block, its panel and the copy of its block row
       const int un = c->upd_n[li.step0 + kb];                  // 64 x 64 blocks of this step's trailing updates
       const int n_inv = kb > 0 ? (k0 + 15) / 16 : 0;        // one workgroup per 16 columns of the block row
       const int2* ut = c->d_tiles + c->upd_off[li.step0 + kb];
@@ -939,30 +1015,44 @@ void launch_factor(plfem_ctx* c, double sigma, int stop_level, int stop_step, in
         while (lo < hi) { int mid = (lo + hi) / 2; if (hs2[mid] > k0 + NB) lo = mid + 1; else hi = mid; }
         n_look = lo;
       }
-      const unsigned gridB = (unsigned)(n_look + un + nact * (n_inv + 1));
+      // (measured on C1, level of 2048 / 1024 / 512 / 256 / 128 fronts: 678 / 257 / 399 / 539 / 441 us with one column
+      // workgroup per front, 749 / 256 / 332 / 383 / 321 us with up to four)
+      static const int col_cap = getenv("PLFEM_COLUMN_WGS_CAP") ? std::max(1, atoi(getenv("PLFEM_COLUMN_WGS_CAP"))) : 0;
+      const int cap = col_cap > 0 ? col_cap : (li.count >= 1024 ? 1 : 4);
+      const int n_pan = n_look > 0 ? panel_wgs(hpm[n_look - 1] - (k0 + NB) - 16, cap) : 1;
+      const unsigned gridB = (unsigned)(n_look * n_pan + un + nact * (n_inv + 1));
       if ((kb & 1) == 0)
-        hipLaunchKernelGGL(k_ldl_update<0>, dim3(gridB), dim3(256), 0, st, un, n_inv, n_look, ut, ford, kb, c->d_fs2, c->d_fm,
-                           c->d_foff, c->d_soff, c->d_fnode_ptr, c->d_front, c->d_schur, c->arena_doubles, dinv_cur, dinv_nxt,
-                           c->d_delta, tb0, wb, rb, wb, rb, c->d_counters);
+        hipLaunchKernelGGL(k_ldl_update<0>, dim3(gridB), dim3(256), 0, st, un, n_inv, n_look, n_pan, ut, ford, kb, c->d_fs2,
+                           c->d_fm, c->d_foff, c->d_soff, c->d_fnode_ptr, c->d_front, c->d_schur, c->arena_doubles, dinv_cur,
+                           dinv_nxt, c->d_delta, wb, rb, wb, rb, wb_next, rb_next, c->d_counters);
       else
-        hipLaunchKernelGGL(k_ldl_update<1>, dim3(gridB), dim3(256), 0, st, un, n_inv, n_look, ut, ford, kb, c->d_fs2, c->d_fm,
-                           c->d_foff, c->d_soff, c->d_fnode_ptr, c->d_front, c->d_schur, c->arena_doubles, dinv_cur, dinv_nxt,
-                           c->d_delta, tb0, wb, rb, wb0, rb0, c->d_counters);
+        hipLaunchKernelGGL(k_ldl_update<1>, dim3(gridB), dim3(256), 0, st, un, n_inv, n_look, n_pan, ut, ford, kb, c->d_fs2,
+                           c->d_fm, c->d_foff, c->d_soff, c->d_fnode_ptr, c->d_front, c->d_schur, c->arena_doubles, dinv_cur,
+                           dinv_nxt, c->d_delta, wb, rb, wb_prev, rb_prev, wb_next, rb_next, c->d_counters);
       if (stop_here && (stop_stage == 3 || stop_stage == 4)) return;
     }
-    if (li.formz_n > 0 && stop_level >= 0) {          // (debug run that stops after a level: its Z now)
-      const int2* zt = c->d_tiles + li.formz_off;
-      hipLaunchKernelGGL(k_form_z, dim3(li.formz_n), dim3(256), 0, st, zt, c->d_fs2, c->d_fm, c->d_foff, c->d_front);
-      hipLaunchKernelGGL(k_mirror_z, dim3(li.formz_n, 4), dim3(256), 0, st, zt, c->d_fs2, c->d_fm, c->d_foff, c->d_front);
+    if (stop_level >= 0) {                             // (debug run that stops after a level: its Z and lower(F11) now)
+      if (li.formz_n > 0) {
+        const int2* zt = c->d_tiles + li.formz_off;
+        hipLaunchKernelGGL(k_form_z, dim3(li.formz_n), dim3(256), 0, st, zt, c->d_fs2, c->d_fm, c->d_foff, c->d_front);
+        hipLaunchKernelGGL(k_mirror_z, dim3(li.formz_n, 4), dim3(256), 0, st, zt, c->d_fs2, c->d_fm, c->d_foff, c->d_front);
+      }
+      if (li.mirrorx_n > 0)
+        hipLaunchKernelGGL(k_mirror_x, dim3(li.mirrorx_n), dim3(256), 0, st, c->d_tiles + li.mirrorx_off, c->d_fs2, c->d_fm,
+                           c->d_foff, c->d_front);
     }
     if (lev == stop_level && stop_stage == 5) return;
   }
-  // Z = L21 L11^-1 and its mirror for every front at once: only the solve sweeps read them
+  // Z = L21 L11^-1 and its mirror, and lower(F11) = the mirror of upper(F11), for every front at once: only the solve
+  // sweeps read them (k_form_z itself reads the upper triangle)
   if (stop_level < 0 && c->formz_all_n > 0) {
     const int2* zt = c->d_tiles + c->formz_all_off;
     hipLaunchKernelGGL(k_form_z, dim3(c->formz_all_n), dim3(256), 0, st, zt, c->d_fs2, c->d_fm, c->d_foff, c->d_front);
     hipLaunchKernelGGL(k_mirror_z, dim3(c->formz_all_n, 4), dim3(256), 0, st, zt, c->d_fs2, c->d_fm, c->d_foff, c->d_front);
   }
+  if (stop_level < 0 && c->mirrorx_all_n > 0)
+    hipLaunchKernelGGL(k_mirror_x, dim3(c->mirrorx_all_n), dim3(256), 0, st, c->d_tiles + c->mirrorx_all_off, c->d_fs2, c->d_fm,
+                       c->d_foff, c->d_front);
 }
 
 }  // namespace plfem

@@ -10,7 +10,7 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 agg = collections.defaultdict(lambda: [0, 0])
 nf = 0
 for r in rows:
-    m = re.search(r"(k_ldl_\w+(?:<\d>)?|k_front_gather|k_form_z|k_mirror_z|k_leaf_assemble)", r["Kernel_Name"])
+    m = re.search(r"(k_ldl_\w+(?:<\d>)?|k_front_gather|k_form_z|k_mirror_z|k_mirror_x|k_leaf_assemble)", r["Kernel_Name"])
     if not m:
         continue
     d = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
@@ -27,7 +27,7 @@ print(f"total {tot:.1f} us per factorisation")
 # per tree level of the LAST factorisation in the trace: a level starts at k_leaf_assemble / k_front_gather
 seq = []
 for r in sorted(rows, key=lambda r: int(r["Start_Timestamp"])):
-    m = re.search(r"(k_ldl_\w+(?:<\d>)?|k_front_gather|k_form_z|k_mirror_z|k_leaf_assemble)", r["Kernel_Name"])
+    m = re.search(r"(k_ldl_\w+(?:<\d>)?|k_front_gather|k_form_z|k_mirror_z|k_mirror_x|k_leaf_assemble)", r["Kernel_Name"])
     if m:
         seq.append((m.group(1), int(r["Start_Timestamp"]), int(r["End_Timestamp"]), int(r["Grid_Size_X"]) // max(int(r["Workgroup_Size_X"]), 1)))
 last = max(i for i, s in enumerate(seq) if s[0] == "k_leaf_assemble")

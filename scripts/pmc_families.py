@@ -25,9 +25,9 @@ FAMILIES = [
     ("k_bwd (leaf level)", r"k_bwd<4", None, "launch"),
     ("k_spmv_b_block", r"k_spmv_b_block", None, "launch"),
     ("assembly (k_element_matrices + k_csr_gather)", r"k_element_matrices|k_csr_gather", r"k_csr_gather", "assembly"),
-    ("k_ldl_pivot_panel", r"k_ldl_pivot_panel", None, "launch"),
+    ("k_ldl_first_panel", r"k_ldl_first_panel", None, "launch"),
     ("k_ldl_update", r"k_ldl_update", None, "launch"),
-    ("factorisation (all kernels)", r"k_ldl_|k_front_gather|k_leaf_assemble|k_form_z|k_mirror_z", r"k_leaf_assemble", "factorisation"),
+    ("factorisation (all kernels)", r"k_ldl_|k_front_gather|k_leaf_assemble|k_form_z|k_mirror_z|k_mirror_x", r"k_leaf_assemble", "factorisation"),
 ]
 
 
