@@ -257,8 +257,9 @@ int plfem_profile_end(plfem_ctx* ctx, double* out_host /* [PLFEM_PROF_COUNT][3] 
 
 /* ---------------------------------------------------------------------------------------------
  * Debugging aids for the test-suite (no reference counterpart): run the factorisation only up to
- * a given (tree level, block step, stage: 0 assembled, 1 or 2 pivot block + panel (launch A), 3 or 4 trailing
- * update + inverse row + pivot write-back (launch B), 5 level done), and copy a slice of a named device workspace
+ * a given (tree level, block step, stage: 0 assembled, 1 or 2 pivot block + panel of the step done (its own launch for
+ * step 0 of a level, the launch of the step before otherwise), 3 or 4 the step's launch done: trailing update + inverse
+ * row + pivot write-back, next pivot block + panel; 5 level done), and copy a slice of a named device workspace
  * ("front","fvec","fvec2","xl","wbuf","rbuf","dinv","delta","elem"; "colind","slot_row": the device-built CSR index
  * arrays, converted to double).
  * plfem_debug_symeig: the host eigensolver of the Lanczos drivers (projected matrices of order

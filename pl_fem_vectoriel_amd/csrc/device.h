@@ -94,7 +94,9 @@ struct plfem_ctx {
   double* d_xl = nullptr;         // complete local solution of every front (backward sweep)
   int32_t* d_npos = nullptr;      // [N] node -> front-order offset of its component 0: 2 fnode_ptr[owner] + dpn * local index, -1 = Dirichlet
   int32_t* d_prow = nullptr;      // per local node of a front: local node index in the PARENT front, -1 = none / padding
-  double *d_wbuf = nullptr, *d_rbuf = nullptr;   // per-front panels m x NB of the level in flight, offset 2*(fnode_ptr[f] - fnode_ptr[level first])*NB
+  double *d_wbuf = nullptr, *d_rbuf = nullptr;   // per-front panels m x NB of the level in flight, offset 2*(fnode_ptr[f] - fnode_ptr[level first])*NB;
+                                                 // three thirds (block steps mod 3).  d_schur, d_wbuf, d_rbuf (alive during a factorisation
+                                                 // only) share their part of the workspace with d_V, d_BV, d_V2, d_BV2 (alive during a Lanczos run only)
   double* d_dinv = nullptr;       // 2 x per-front NB x NB (inverse of the unit-lower pivot block of even / odd block steps)
   double* d_delta = nullptr;      // per-front D^-1 of the block LDL^T: (diagonal, off-diagonal of the node pair) per row, offset 2 * (2*fnode_ptr[f])
   double* d_fvec2 = nullptr;      // forward-sweep results of the owned rows (t = L11^-1 r; the backward sweep applies D^-1), front order
