@@ -265,6 +265,12 @@ int create_impl(plfem_ctx* c, const plfem_symbolic* sym, int device, void* strea
       li.bwd_n = (int)(blk.size() - li.bwd_off);
     }
   }
+  std::vector<plfem::SweepJob> jobs(size_only ? 0 : blk.size());
+  for (size_t q = 0; q < jobs.size(); ++q) {
+    const int f = blk[q].x;
+    jobs[q] = plfem::SweepJob{f, blk[q].y, fm[f], fs2[f], S.fnode_ptr[f], f > 0 ? S.fnode_ptr[(f - 1) >> 1] : 0, S.foff[f], 0};
+  }
+  if (size_only) jobs.resize(blk.size());                // (only the size matters)
   // 64 x 64 tile lists of the factorisation kernels: only workgroups with work are launched (a dense
   // (tiles of the largest front)^2 x fronts grid is 85-90 % empty workgroups, which cost ~3 ns each)
   std::vector<int2> tiles;
@@ -361,7 +367,7 @@ int create_impl(plfem_ctx* c, const plfem_symbolic* sym, int device, void* strea
   c->slab_off = 0;
   items.clear();
   TRY(upload(c, items, &c->d_tsorted, S.tsorted));
-  TRY(upload(c, items, &c->d_blk, blk));
+  TRY(upload(c, items, &c->d_blk, jobs));
   TRY(upload(c, items, &c->d_tiles, tiles));
   TRY(upload(c, items, &c->d_forder, forder));
   TRY(upload(c, items, &c->d_edof, S.edof));

@@ -19,6 +19,16 @@ constexpr int ROW_FORM_MAX_FRONTS = 32;   // levels with at most this many front
 // launch -- tiles of 64 rows, row-form workgroups of 16 rows for the fronts with more than MIX_BIG_S2 owned DOFs)
 constexpr int MIX_BIG_S2 = 192;
 constexpr int SWEEP_ROW_JOB_FLAG = 1 << 30;
+// One workgroup of a sweep kernel: the front, its row block and everything the workgroup would otherwise look up by
+// front number (one dependent memory round trip less in front of every launch of a latency-bound level)
+struct alignas(16) SweepJob {
+  int32_t f, rb;          // front, row block (| SWEEP_ROW_JOB_FLAG in the mixed forward kernel)
+  int32_t m, s2;          // order of the front, owned DOFs
+  int64_t np, npp;        // fnode_ptr of the front and of its parent
+  int64_t foff;           // offset of the front in d_front
+  int64_t reserved;
+};
+static_assert(sizeof(SweepJob) == 48, "SweepJob layout");
 inline int fwd_block_rows(int count) { return count <= 8 ? 8 : count <= ROW_FORM_MAX_FRONTS ? 16 : 64; }
 // (round 3 re-measured the tile form at the two levels above the leaves: 28.1 / 25.5 us against 22.3 / 21.5 us in row form)
 inline int bwd_block_rows(int count, bool leaf) { return leaf ? 64 : count <= ROW_FORM_MAX_FRONTS ? 8 : 16; }
@@ -71,7 +81,7 @@ struct plfem_ctx {
   int formz_all_n = 0;
   int64_t mirrorx_all_off = 0;    // d_tiles: (front, block row >= 1) of every front, for k_mirror_x
   int mirrorx_all_n = 0;
-  int2* d_blk = nullptr;          // (front, row block) of every sweep workgroup, level by level
+  plfem::SweepJob* d_blk = nullptr;   // one entry per sweep workgroup, level by level
   int32_t *d_tsorted = nullptr, *d_edof = nullptr, *d_rowptr = nullptr, *d_colind = nullptr;
   int32_t *d_slot_row = nullptr, *d_nptr = nullptr, *d_nadj = nullptr, *d_interior = nullptr;
   uint8_t* d_nloc = nullptr;

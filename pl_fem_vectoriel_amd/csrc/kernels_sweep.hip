@@ -46,13 +46,11 @@ namespace plfem {
 namespace {
 
 struct SweepArgs {
-  const int2* blk;
+  const SweepJob* blk;
   int leaf_level;
   int dbg;                         // timing experiments only (plfem_debug_solve_block): 1 skip fronts with s2 > 128, 2 only those
   int ldv;                         // row forms: leading dimension of the staged vector in LDS (component-major [u][i])
   int sh;                          // unknowns per node - 1: node of a local DOF = i >> sh, component = i & sh
-  const int32_t *fs2, *fm;
-  const int64_t *foff, *fnode_ptr;
   const int32_t *cinv0, *cinv1, *prow;
   const double* front;
   const double2* dinv2;             // D^-1 of every front row: (diagonal, off-diagonal entry of the row's node pair)
@@ -137,7 +135,7 @@ struct FwdOut {
   double w0[P], w1[P];
   int c0, c1;
   int64_t dst;
-  __device__ __forceinline__ void request(const SweepArgs& A, int f, int64_t np, int s2, int m, int r) {
+  __device__ __forceinline__ void request(const SweepArgs& A, int64_t npp, int64_t np, int s2, int m, int r) {
     c0 = c1 = -1;
     dst = -1;
 #pragma unroll
@@ -151,28 +149,28 @@ struct FwdOut {
 #pragma unroll
       for (int u = 0; u < P; ++u) { w0[u] = A.u0[e + u]; w1[u] = A.u1[e + u]; }
     }
-    if (pr >= 0) dst = (2 * A.fnode_ptr[(f - 1) >> 1] + (pr << A.sh) + (r & A.sh)) * P;
+    if (pr >= 0) dst = (2 * npp + (pr << A.sh) + (r & A.sh)) * P;
   }
   __device__ __forceinline__ double w(int u) const { return (c0 >= 0 ? w0[u] : 0.0) + (c1 >= 0 ? w1[u] : 0.0); }
 };
 
 // ---- forward, tile form ------------------------------------------------------------------------------------------
-constexpr int SWEEP_ROW_JOB = 1 << 30;   // job.y flag of the mixed kernels: row-form workgroup (16 rows) instead of a tile (64 rows)
+// (SweepJob.rb carries SWEEP_ROW_JOB_FLAG in the mixed kernels: row-form workgroup (16 rows) instead of a tile (64 rows))
 constexpr int TB = PLFEM_SWEEP_TB;      // matrix loads in flight per lane and trip (a long front is a chain of such trips)
 template <int P, int NW, int TBF = TB>
-__device__ __forceinline__ void fwd_tile_body(const SweepArgs& A, int f, int rb, double* __restrict__ sv, double* __restrict__ red) {
-  const int m = A.fm[f], s2 = A.fs2[f];
+__device__ __forceinline__ void fwd_tile_body(const SweepArgs& A, const SweepJob& J, double* __restrict__ sv, double* __restrict__ red) {
+  const int f = J.f, m = J.m, s2 = J.s2;
   if (A.dbg && ((A.dbg == 1) == (s2 > 128))) return;
-  const int r0 = rb * 64;
-  const int64_t np = A.fnode_ptr[f];
+  const int r0 = (J.rb & ~SWEEP_ROW_JOB_FLAG) * 64;
+  const int64_t np = J.np;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int need = (r0 + 64 <= s2) ? r0 + 64 : s2;
   const int r = r0 + lane;
   const bool valid = r < m;
   const int ce = valid ? ((r < s2) ? r + 1 : s2) : 0;               // rows of L11^-1 are lower triangular
-  const double* p = A.front + A.foff[f] + r;
+  const double* p = A.front + J.foff + r;
   FwdOut<P> out;
-  if (wave == 0) out.request(A, f, np, s2, m, r);
+  if (wave == 0) out.request(A, J.npp, np, s2, m, r);
   FwdStage<P> st;
   stage_fwd<P, false>(A, sv, np, need, NW * 64, tid, st);
   // first batch of this wave's columns (c == wave mod NW), requested before the staged vector is complete
@@ -232,15 +230,15 @@ __device__ __forceinline__ void fwd_tile_body(const SweepArgs& A, int f, int rb,
 
 // ---- forward, row form -------------------------------------------------------------------------------------------
 template <int P, int NW, int R>
-__device__ __forceinline__ void fwd_rows_body(const SweepArgs& A, int f, int rb, double* __restrict__ sv) {
+__device__ __forceinline__ void fwd_rows_body(const SweepArgs& A, const SweepJob& J, double* __restrict__ sv) {
   constexpr int RB = NW * R, UNR = PLFEM_SWEEP_ROWLOADS / R, V = R * P;
-  const int m = A.fm[f], s2 = A.fs2[f];
+  const int f = J.f, m = J.m, s2 = J.s2;
   if (A.dbg && ((A.dbg == 1) == (s2 > 128))) return;
-  const int j0 = rb * RB;
-  const int64_t np = A.fnode_ptr[f];
+  const int j0 = (J.rb & ~SWEEP_ROW_JOB_FLAG) * RB;
+  const int64_t np = J.np;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int need = min(s2, j0 + RB);                      // rows < s2 only read r[0 .. row]
-  const double* F = A.front + A.foff[f];
+  const double* F = A.front + J.foff;
   // row r of [L11^-1; Z] as a contiguous run: r < s2 -> column r of [F11; F21] (the upper mirror of L11^-1), r >= s2 ->
   // column r - s2 of Z^T (s2 x b2, stored behind [F11; F21])
   int ce[R], cmax = 0;
@@ -256,7 +254,7 @@ __device__ __forceinline__ void fwd_rows_body(const SweepArgs& A, int f, int rb,
   const int oidx = multi_reduce_index<V>(lane & (V - 1));
   const int orow = j0 + wave + NW * (oidx / P);
   FwdOut<P> out;
-  out.request(A, f, np, s2, m, lane < V ? orow : m);
+  out.request(A, J.npp, np, s2, m, lane < V ? orow : m);
   FwdStage<P> st;
   stage_fwd<P, true>(A, sv, np, need, NW * 64, tid, st);
   double a0[UNR][R];
@@ -372,12 +370,12 @@ __device__ __forceinline__ void stage_bwd_rest(const SweepArgs& A, double* sv, i
 }
 
 template <int P, int NW>
-__device__ __forceinline__ void bwd_tile_body(const SweepArgs& A, int f, int rb, double* __restrict__ sv, double* __restrict__ red) {
-  const int m = A.fm[f], s2 = A.fs2[f];
+__device__ __forceinline__ void bwd_tile_body(const SweepArgs& A, const SweepJob& J, double* __restrict__ sv, double* __restrict__ red) {
+  const int rb = J.rb, m = J.m, s2 = J.s2;
   if (A.dbg && ((A.dbg == 1) == (s2 > 128))) return;
   const int r0 = rb * 64;
-  const int64_t np = A.fnode_ptr[f];
-  const int64_t npp = f > 0 ? A.fnode_ptr[(f - 1) >> 1] : 0;
+  const int64_t np = J.np;
+  const int64_t npp = J.npp;
   constexpr int TBB = PLFEM_SWEEP_TB_BWD;   // matrix loads in flight per lane and trip (leaf fronts: ~20 columns per wave)
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const bool publish = rb == 0 && !A.leaf_level;
@@ -387,8 +385,8 @@ __device__ __forceinline__ void bwd_tile_body(const SweepArgs& A, int f, int rb,
   const bool valid = r < s2;
   // element (j = r, i) of [L11^-T | Z^T]: column i of [F11; F21] at row r for i < s2 (upper mirror), of Z^T (leading
   // dimension s2, behind [F11; F21]) for i >= s2
-  const double* p = A.front + A.foff[f] + r;
-  const double* pz = A.front + A.foff[f] + (int64_t)m * s2 + r - (int64_t)s2 * s2;     // pz[i s2] for i >= s2
+  const double* p = A.front + J.foff + r;
+  const double* pz = A.front + J.foff + (int64_t)m * s2 + r - (int64_t)s2 * s2;     // pz[i s2] for i >= s2
   auto entry = [&](int i) { return i < s2 ? p[(int64_t)i * m] : pz[(int64_t)i * s2]; };
   const int cb = valid ? r : m, ce = m;
   const int cstart = cb + ((wave - cb) & (NW - 1));
@@ -440,19 +438,19 @@ __device__ __forceinline__ void bwd_tile_body(const SweepArgs& A, int f, int rb,
 // Column j of the lower storage is contiguous in i, so a wave reads 512-byte runs; a wave owns R rows
 // (j0 + wave + NW q) and keeps R x 8/R loads in flight; a block (NW waves) shares one staged vector for NW R rows.
 template <int P, int NW, int R>
-__device__ __forceinline__ void bwd_rows_body(const SweepArgs& A, int f, int rb, double* __restrict__ sv) {
+__device__ __forceinline__ void bwd_rows_body(const SweepArgs& A, const SweepJob& J, double* __restrict__ sv) {
   constexpr int RB = NW * R, UNR = PLFEM_SWEEP_ROWLOADS / R, V = R * P;
-  const int m = A.fm[f], s2 = A.fs2[f];
+  const int rb = J.rb, m = J.m, s2 = J.s2;
   if (A.dbg && ((A.dbg == 1) == (s2 > 128))) return;
   const int j0 = rb * RB;
-  const int64_t np = A.fnode_ptr[f];
-  const int64_t npp = f > 0 ? A.fnode_ptr[(f - 1) >> 1] : 0;
+  const int64_t np = J.np;
+  const int64_t npp = J.npp;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const bool publish = rb == 0 && !A.leaf_level;
   const int lo = j0 & ~63;
   BwdStage<P> st;
   st.request_index(A, np, s2, lo + tid, lo + tid < m);
-  const double* F = A.front + A.foff[f];
+  const double* F = A.front + J.foff;
   int jq[R];
 #pragma unroll
   for (int q = 0; q < R; ++q) {
@@ -524,15 +522,15 @@ __device__ __forceinline__ void bwd_rows_body(const SweepArgs& A, int f, int rb,
 template <int P, int R>
 __global__ __launch_bounds__(512) void k_fwd_rows(SweepArgs A) {
   extern __shared__ double sv[];
-  const int2 job = A.blk[blockIdx.x];
-  fwd_rows_body<P, 8, R>(A, job.x, job.y, sv);
+  const SweepJob job = A.blk[blockIdx.x];
+  fwd_rows_body<P, 8, R>(A, job, sv);
 }
 
 template <int P, int R>
 __global__ __launch_bounds__(512) void k_bwd_rows(SweepArgs A) {
   extern __shared__ double sv[];
-  const int2 job = A.blk[blockIdx.x];
-  bwd_rows_body<P, 8, R>(A, job.x, job.y, sv);
+  const SweepJob job = A.blk[blockIdx.x];
+  bwd_rows_body<P, 8, R>(A, job, sv);
 }
 
 // forward, tile form only (levels without a long front: the mixed kernel's register budget costs occupancy there)
@@ -540,17 +538,17 @@ template <int P>
 __global__ __launch_bounds__(256) void k_fwd(SweepArgs A) {
   extern __shared__ double sv[];
   __shared__ double red[4 * P * 64];
-  const int2 job = A.blk[blockIdx.x];
-  fwd_tile_body<P, 4, PLFEM_SWEEP_TB_FWD_TILE>(A, job.x, job.y, sv, red);
+  const SweepJob job = A.blk[blockIdx.x];
+  fwd_tile_body<P, 4, PLFEM_SWEEP_TB_FWD_TILE>(A, job, sv, red);
 }
 
 template <int P>
 __global__ __launch_bounds__(256) void k_fwd_mix(SweepArgs A) {
   extern __shared__ double sv[];
   __shared__ double red[4 * P * 64];
-  const int2 job = A.blk[blockIdx.x];
-  if (job.y & SWEEP_ROW_JOB) fwd_rows_body<P, 4, 4>(A, job.x, job.y & ~SWEEP_ROW_JOB, sv);
-  else fwd_tile_body<P, 4>(A, job.x, job.y, sv, red);
+  const SweepJob job = A.blk[blockIdx.x];
+  if (job.rb & SWEEP_ROW_JOB_FLAG) fwd_rows_body<P, 4, 4>(A, job, sv);
+  else fwd_tile_body<P, 4>(A, job, sv, red);
 }
 
 // backward, leaf level: tile form (leaf fronts have about as many owned rows as boundary columns)
@@ -558,8 +556,8 @@ template <int P>
 __global__ __launch_bounds__(512) void k_bwd(SweepArgs A) {
   extern __shared__ double sv[];
   __shared__ double red[8 * P * 64];
-  const int2 job = A.blk[blockIdx.x];
-  bwd_tile_body<P, 8>(A, job.x, job.y, sv, red);
+  const SweepJob job = A.blk[blockIdx.x];
+  bwd_tile_body<P, 8>(A, job, sv, red);
 }
 
 // ---- global order <-> front order ---------------------------------------------------------------------------------
@@ -595,7 +593,6 @@ void sweeps(plfem_ctx* c) {
   SweepArgs A;
   A.sh = c->sh;
   A.dbg = c->debug_sweep_filter;
-  A.fs2 = c->d_fs2; A.fm = c->d_fm; A.foff = c->d_foff; A.fnode_ptr = c->d_fnode_ptr;
   A.cinv0 = c->d_cinv0; A.cinv1 = c->d_cinv1; A.prow = c->d_prow;
   A.front = c->d_front; A.dinv2 = reinterpret_cast<const double2*>(c->d_delta);
   A.fr = c->d_fvec; A.u0 = c->d_u0; A.u1 = c->d_u1; A.ys = c->d_fvec2; A.xl = c->d_xl;
