@@ -271,6 +271,12 @@ int create_impl(plfem_ctx* c, const plfem_symbolic* sym, int device, void* strea
     jobs[q] = plfem::SweepJob{f, blk[q].y, fm[f], fs2[f], S.fnode_ptr[f], f > 0 ? S.fnode_ptr[(f - 1) >> 1] : 0, S.foff[f], 0};
   }
   if (size_only) jobs.resize(blk.size());                // (only the size matters)
+  std::vector<plfem::FrontRec> frec(S.nfronts);          // the fronts in launch order, with their parameters
+  if (!size_only)
+    for (int q = 0; q < S.nfronts; ++q) {
+      const int f = forder[q];
+      frec[q] = plfem::FrontRec{f, fm[f], fs2[f], 0, S.foff[f], S.fnode_ptr[f]};
+    }
   // 64 x 64 tile lists of the factorisation kernels: only workgroups with work are launched (a dense
   // (tiles of the largest front)^2 x fronts grid is 85-90 % empty workgroups, which cost ~3 ns each)
   std::vector<int2> tiles;
@@ -370,6 +376,7 @@ int create_impl(plfem_ctx* c, const plfem_symbolic* sym, int device, void* strea
   TRY(upload(c, items, &c->d_blk, jobs));
   TRY(upload(c, items, &c->d_tiles, tiles));
   TRY(upload(c, items, &c->d_forder, forder));
+  TRY(upload(c, items, &c->d_frec, frec));
   TRY(upload(c, items, &c->d_edof, S.edof));
   TRY(upload(c, items, &c->d_rowptr, S.rowptr));
   TRY(upload(c, items, &c->d_nptr, S.nptr));

@@ -29,6 +29,12 @@ struct alignas(16) SweepJob {
   int64_t reserved;
 };
 static_assert(sizeof(SweepJob) == 48, "SweepJob layout");
+// A front as the factorisation's chain workgroups (first panel, column workgroups) see it, in launch order (d_forder)
+struct alignas(16) FrontRec {
+  int32_t f, m, s2, reserved;
+  int64_t foff, np;       // offset in d_front, fnode_ptr
+};
+static_assert(sizeof(FrontRec) == 32, "FrontRec layout");
 inline int fwd_block_rows(int count) { return count <= 8 ? 8 : count <= ROW_FORM_MAX_FRONTS ? 16 : 64; }
 // (round 3 re-measured the tile form at the two levels above the leaves: 28.1 / 25.5 us against 22.3 / 21.5 us in row form)
 inline int bwd_block_rows(int count, bool leaf) { return leaf ? 64 : count <= ROW_FORM_MAX_FRONTS ? 8 : 16; }
@@ -73,6 +79,7 @@ struct plfem_ctx {
   std::vector<plfem::LevelInfo> levels;
   // ---- index structures on the device
   int32_t* d_forder = nullptr;    // [nfronts] per level: front ids in order of decreasing s2 (factorisation launches)
+  plfem::FrontRec* d_frec = nullptr;   // the same order, with the front's parameters
   std::vector<int> forder_s2, forder_maxm;   // host: s2 in that order, running max of m in that order
   int2* d_tiles = nullptr;        // (front, tx | ty << 16) of every useful 64 x 64 workgroup of the factorisation
   std::vector<int64_t> upd_off;   // per (level, block step): first entry / entries of the trailing-update list

@@ -343,14 +343,14 @@ __device__ __forceinline__ void ldl_pivot_block(const double* src, int64_t ld, i
 }
 
 // X = L^-1 of the pivot block -> dinv (D[r + c*NB] = X[r][c]), its D^-1 -> delta ((diagonal, off-diagonal) of every row)
-__device__ __forceinline__ void store_pivot_results(int f, int k0, int nbk, const int64_t* __restrict__ fnode_ptr,
+__device__ __forceinline__ void store_pivot_results(int f, int k0, int nbk, int64_t np,
                                                     double* __restrict__ dinv, double* __restrict__ delta,
                                                     double (*tile)[NB + 1], const double* __restrict__ sDd,
                                                     const double* __restrict__ sDo) {
   double* D = dinv + (int64_t)f * NB * NB;
   for (int e = threadIdx.x; e < NB * NB; e += 256) D[e] = tile[e & (NB - 1)][e >> 5];
   if ((int)threadIdx.x < nbk)
-    reinterpret_cast<double2*>(delta)[2 * fnode_ptr[f] + k0 + threadIdx.x] = make_double2(sDd[threadIdx.x], sDo[threadIdx.x]);
+    reinterpret_cast<double2*>(delta)[2 * np + k0 + threadIdx.x] = make_double2(sDd[threadIdx.x], sDo[threadIdx.x]);
 }
 
 // The panel of a block step, 16 rows of a wave: Y = R X^T (= R L^-T), W = Y D^-1 (= the L panel; D^-1 couples the two
@@ -406,17 +406,16 @@ struct PanelOperands {
 // in this launch (it is written back into F by the next one).
 // (no mirrored copy L^T in the rows of the pivot block: those entries are overwritten -- by the triangular-inverse
 // update inside F11, by Z^T in F12 -- before anything reads them)
-__global__ __launch_bounds__(256) void k_ldl_first_panel(const int32_t* __restrict__ forder, const int32_t* __restrict__ fs2,
-                                                         const int32_t* __restrict__ fm, const int64_t* __restrict__ foff,
-                                                         const int64_t* __restrict__ fnode_ptr, double* __restrict__ front,
+__global__ __launch_bounds__(256) void k_ldl_first_panel(const FrontRec* __restrict__ frec, double* __restrict__ front,
                                                          double* __restrict__ dinv, double* __restrict__ delta,
                                                          double* __restrict__ wbuf, double* __restrict__ rbuf,
                                                          int32_t* __restrict__ counters) {
-  const int f = forder[blockIdx.x];
-  const int s2 = fs2[f];
+  const FrontRec R = frec[blockIdx.x];                       // (one record instead of front number -> four lookups)
+  const int f = R.f;
+  const int s2 = R.s2;
   const int nbk = min(NB, s2);
-  const int m = fm[f];
-  double* F = front + foff[f];
+  const int m = R.m;
+  double* F = front + R.foff;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   // panel workgroup bx of this front takes the 64-row chunks bx, bx + n_pan, ... below the pivot block (n_pan workgroups
   // per front: all chunks in parallel at the top of the tree, where the step is latency; at most two workgroups per
@@ -441,9 +440,9 @@ __global__ __launch_bounds__(256) void k_ldl_first_panel(const int32_t* __restri
   }
   ldl_pivot_block(F, m, nbk, threadIdx.x, tile, sDd, sDo, piv, bx == 0 ? counters : nullptr);
   __syncthreads();
-  if (bx == 0) store_pivot_results(f, 0, nbk, fnode_ptr, dinv, delta, tile, sDd, sDo);
-  double* W = wbuf + 2 * fnode_ptr[f] * NB;
-  double* Y = rbuf + 2 * fnode_ptr[f] * NB;
+  if (bx == 0) store_pivot_results(f, 0, nbk, R.np, dinv, delta, tile, sDd, sDo);
+  double* W = wbuf + 2 * R.np * NB;
+  double* Y = rbuf + 2 * R.np * NB;
   PanelOperands po;
   po.load(tile, sDd, sDo, nbk, lr, lk);
   for (int ch = bx; t0 + ch * 64 < m; ch += n_pan) {
@@ -661,29 +660,27 @@ __device__ __forceinline__ void ldl_update_tile(const int2 job, int kb, const in
 //      (register r of quadrant tj = column 4 (r + 4 tj) + lk) -- and go through the panel code at once: W, Y into the
 //      buffers of the next step, W into F.  The first chunk's update is computed before the pivot chain starts.
 template <int MODE>
-__device__ __forceinline__ void ldl_column_block(int f, int bx, int n_pan, int kb, const int32_t* __restrict__ fs2,
-                                                 const int32_t* __restrict__ fm, const int64_t* __restrict__ foff,
-                                                 const int64_t* __restrict__ fnode_ptr, double* __restrict__ front,
+__device__ __forceinline__ void ldl_column_block(const FrontRec& R, int bx, int n_pan, int kb, double* __restrict__ front,
                                                  double* __restrict__ dinv_next, double* __restrict__ delta,
                                                  const double* __restrict__ wbuf, const double* __restrict__ rbuf,
                                                  const double* __restrict__ wbuf_prev, const double* __restrict__ rbuf_prev,
                                                  double* __restrict__ wbuf_next, double* __restrict__ rbuf_next,
                                                  int32_t* __restrict__ counters) {
-  const int s2 = fs2[f];
+  const int f = R.f, s2 = R.s2;
   const int k0 = kb * NB;
   const int t0 = k0 + NB;                      // (a front with a next step has a full block now)
   if (t0 >= s2) return;
   const int nbn = min(NB, s2 - t0);
-  const int m = fm[f];
+  const int m = R.m;
   const int t1 = t0 + nbn;                     // first row below the next pivot block
   if (bx > 0 && t1 + bx * 64 >= m) return;
-  double* F = front + foff[f];
+  double* F = front + R.foff;
   __shared__ __attribute__((aligned(16))) PivotLds piv;
   __shared__ double tile[NB][NB + 1];
   __shared__ double sDd[NB], sDo[NB];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int lr = lane & 15, lk = lane >> 4;
-  const int64_t pbase = 2 * fnode_ptr[f] * NB;
+  const int64_t pbase = 2 * R.np * NB;
   const bool full = nbn > 16;
   // One pass over the panels of this step (MODE 1: and of the step before) for 16 rows of this wave -- columns
   // [t0, t0 + nbn) of rows ibase .. after the update, as B operand bq of the panel product -- and, with QUAD, for this wave's
@@ -743,7 +740,7 @@ __device__ __forceinline__ void ldl_column_block(int f, int bx, int n_pan, int k
   __syncthreads();
   ldl_pivot_block(&tile[0][0], NB + 1, nbn, threadIdx.x, tile, sDd, sDo, piv, bx == 0 ? counters : nullptr);
   __syncthreads();
-  if (bx == 0) store_pivot_results(f, t0, nbn, fnode_ptr, dinv_next, delta, tile, sDd, sDo);
+  if (bx == 0) store_pivot_results(f, t0, nbn, R.np, dinv_next, delta, tile, sDd, sDo);
   // 2. the panel of the next step (X and D^-1 are read from LDS again for every further chunk instead of being carried
   // through its update: 64 registers)
   double* Wn = wbuf_next + pbase;
@@ -780,7 +777,8 @@ __device__ __forceinline__ void ldl_column_block(int f, int bx, int n_pan, int k
 // written: the next step's), X of the pivot blocks of two.
 template <int MODE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_ldl_update(
-    int un, int n_inv, int n_look, int n_pan, const int2* __restrict__ tiles, const int32_t* __restrict__ forder, int kb,
+    int un, int n_inv, int n_look, int n_pan, const int2* __restrict__ tiles, const int32_t* __restrict__ forder,
+    const FrontRec* __restrict__ frec, int kb,
     const int32_t* __restrict__ fs2, const int32_t* __restrict__ fm, const int64_t* __restrict__ foff,
     const int64_t* __restrict__ soff, const int64_t* __restrict__ fnode_ptr, double* __restrict__ front,
     double* __restrict__ schur, int64_t arena, const double* __restrict__ dinv, double* __restrict__ dinv_next,
@@ -789,8 +787,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     double* __restrict__ rbuf_next, int32_t* __restrict__ counters) {
   int bid = blockIdx.x;
   if (bid < n_look * n_pan) {
-    ldl_column_block<MODE>(forder[bid / n_pan], bid % n_pan, n_pan, kb, fs2, fm, foff, fnode_ptr, front, dinv_next, delta, wbuf,
-                           rbuf, wbuf_prev, rbuf_prev, wbuf_next, rbuf_next, counters);
+    const FrontRec R = frec[bid / n_pan];
+    ldl_column_block<MODE>(R, bid % n_pan, n_pan, kb, front, dinv_next, delta, wbuf, rbuf, wbuf_prev, rbuf_prev, wbuf_next,
+                           rbuf_next, counters);
     return;
   }
   bid -= n_look * n_pan;
@@ -963,6 +962,7 @@ void launch_factor(plfem_ctx* c, double sigma, int stop_level, int stop_step, in
     // prefix of that order, so every launch only covers them and is sized by the largest ACTIVE front.
     const int steps = (li.max_s2 + NB - 1) / NB;
     const int32_t* ford = c->d_forder + li.first;
+    const FrontRec* frec = c->d_frec + li.first;
     const int* hs2 = c->forder_s2.data() + li.first;          // s2 in that order (descending)
     const int* hpm = c->forder_maxm.data() + li.first;        // running maximum of m in that order
     for (int kb = 0; kb < steps; ++kb) {
@@ -1000,8 +1000,8 @@ void launch_factor(plfem_ctx* c, double sigma, int stop_level, int stop_step, in
       if (kb == 0) {
         // first launch of the level: pivot block + panel of step 0
         const int n_pan0 = panel_wgs(hpm[nact - 1] - 16, 2);
-        hipLaunchKernelGGL(k_ldl_first_panel, dim3(nact, n_pan0), dim3(256), 0, st, ford, c->d_fs2, c->d_fm, c->d_foff,
-                           c->d_fnode_ptr, c->d_front, dinv_cur, c->d_delta, wb, rb, c->d_counters);
+        hipLaunchKernelGGL(k_ldl_first_panel, dim3(nact, n_pan0), dim3(256), 0, st, frec, c->d_front, dinv_cur, c->d_delta, wb, rb,
+                           c->d_counters);
       }
       if (stop_here && stop_stage >= 1 && stop_stage <= 2) return;
       // the step's launch: trailing update + triangular-inverse update + write-back of the pivot block, and for the
@@ -1022,11 +1022,11 @@ void launch_factor(plfem_ctx* c, double sigma, int stop_level, int stop_step, in
       const int n_pan = n_look > 0 ? panel_wgs(hpm[n_look - 1] - (k0 + NB) - 16, cap) : 1;
       const unsigned gridB = (unsigned)(n_look * n_pan + un + nact * (n_inv + 1));
       if ((kb & 1) == 0)
-        hipLaunchKernelGGL(k_ldl_update<0>, dim3(gridB), dim3(256), 0, st, un, n_inv, n_look, n_pan, ut, ford, kb, c->d_fs2,
+        hipLaunchKernelGGL(k_ldl_update<0>, dim3(gridB), dim3(256), 0, st, un, n_inv, n_look, n_pan, ut, ford, frec, kb, c->d_fs2,
                            c->d_fm, c->d_foff, c->d_soff, c->d_fnode_ptr, c->d_front, c->d_schur, c->arena_doubles, dinv_cur,
                            dinv_nxt, c->d_delta, wb, rb, wb, rb, wb_next, rb_next, c->d_counters);
       else
-        hipLaunchKernelGGL(k_ldl_update<1>, dim3(gridB), dim3(256), 0, st, un, n_inv, n_look, n_pan, ut, ford, kb, c->d_fs2,
+        hipLaunchKernelGGL(k_ldl_update<1>, dim3(gridB), dim3(256), 0, st, un, n_inv, n_look, n_pan, ut, ford, frec, kb, c->d_fs2,
                            c->d_fm, c->d_foff, c->d_soff, c->d_fnode_ptr, c->d_front, c->d_schur, c->arena_doubles, dinv_cur,
                            dinv_nxt, c->d_delta, wb, rb, wb_prev, rb_prev, wb_next, rb_next, c->d_counters);
       if (stop_here && (stop_stage == 3 || stop_stage == 4)) return;
