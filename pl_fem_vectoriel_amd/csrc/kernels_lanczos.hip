@@ -90,24 +90,16 @@ __global__ __launch_bounds__(256) void k_scale(int64_t n, double a, double* __re
 // partial[(c*P + q) * nchunks + chunk] = sum_{i in chunk} Pm[i, c] * W[i, q].  One wave per (chunk, 4 columns):
 // the P values of W are loaded once for four columns of the panel (a wave per column re-read W from L2 ncols
 // times, which cost more than streaming the panel itself), two row groups per iteration = 16 loads in flight.
-// SPLIT (panels of at most 8 columns: the local orthogonalisation pass and the Gram matrix of a block step): the 4 waves of
-// a workgroup would otherwise be one or two -- 178 or 356 waves on 256 CUs -- so they share the chunk's rows instead
-// (halves or quarters, contiguous) and their sums meet in LDS in a fixed order.
-template <int P, bool SPLIT>
+template <int P>
 __global__ __launch_bounds__(256) void k_panel_dot_p(int64_t n, int ncols, int nchunks, const double* __restrict__ Pm,
                                                      const double* __restrict__ W, int64_t ldw,
                                                      double* __restrict__ partial) {
   constexpr int CW = 4;                                  // columns per wave
-  const int wave = threadIdx.x >> 6;
-  const int groups = SPLIT ? (ncols + CW - 1) / CW : 4;  // column groups of this workgroup (SPLIT: 1 or 2)
-  const int parts = 4 / groups;                          // waves per column group
-  const int c0 = SPLIT ? (wave % groups) * CW : (blockIdx.y * 4 + wave) * CW;
-  const int part = SPLIT ? wave / groups : 0;
-  if (!SPLIT && c0 >= ncols) return;
+  const int c0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * CW;
+  if (c0 >= ncols) return;
   const int lane = threadIdx.x & 63;
-  const int64_t ic = (int64_t)blockIdx.x * CHUNK;
-  const int64_t i0 = ic + (SPLIT ? part * (CHUNK / parts) : 0);
-  const int64_t i1 = min(n, SPLIT ? i0 + CHUNK / parts : ic + CHUNK);
+  const int64_t i0 = (int64_t)blockIdx.x * CHUNK;
+  const int64_t i1 = min(n, i0 + CHUNK);
   const double* col[CW];
 #pragma unroll
   for (int t = 0; t < CW; ++t) col[t] = Pm + (int64_t)min(c0 + t, ncols - 1) * n;   // clamped: result discarded
@@ -144,29 +136,13 @@ __global__ __launch_bounds__(256) void k_panel_dot_p(int64_t n, int ncols, int n
       for (int q = 0; q < P; ++q) acc[t][q] += a * w[q];
     }
   }
-  __shared__ double red[SPLIT ? 4 * CW * P : 1];
 #pragma unroll
   for (int t = 0; t < CW; ++t) {
 #pragma unroll
     for (int q = 0; q < P; ++q) {
       double v = acc[t][q];
       for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
-      if (SPLIT) {
-        if (lane == 0) red[(wave * CW + t) * P + q] = v;
-      } else if (lane == 0 && c0 + t < ncols) {
-        partial[((int64_t)(c0 + t) * P + q) * nchunks + blockIdx.x] = v;
-      }
-    }
-  }
-  if (SPLIT) {
-    __syncthreads();
-    const int e = threadIdx.x;                           // entry (group, t, q) of the workgroup's result
-    if (e < groups * CW * P) {
-      const int g = e / (CW * P), tq = e % (CW * P);
-      double v = 0.0;
-      for (int pp = 0; pp < parts; ++pp) v += red[((pp * groups + g) * CW) * P + tq];   // wave = pp * groups + g
-      const int c = g * CW + tq / P;
-      if (c < ncols) partial[((int64_t)c * P + tq % P) * nchunks + blockIdx.x] = v;
+      if (lane == 0 && c0 + t < ncols) partial[((int64_t)(c0 + t) * P + q) * nchunks + blockIdx.x] = v;
     }
   }
 }
@@ -588,12 +564,8 @@ void launch_panel_dot_block(plfem_ctx* c, const double* Pm, int ncols, const dou
                             double* hacc, int ldacc) {
   constexpr int P = BLOCK_P;
   const int nchunks = c->npartial;
-  if (ncols <= 8)
-    hipLaunchKernelGGL((k_panel_dot_p<P, true>), dim3(nchunks, 1), dim3(256), 0, c->stream, c->n2, ncols, nchunks, Pm, W, ldw,
-                       c->d_partial);
-  else
-    hipLaunchKernelGGL((k_panel_dot_p<P, false>), dim3(nchunks, (ncols + 15) / 16), dim3(256), 0, c->stream, c->n2, ncols, nchunks,
-                       Pm, W, ldw, c->d_partial);
+  hipLaunchKernelGGL(k_panel_dot_p<P>, dim3(nchunks, (ncols + 15) / 16), dim3(256), 0, c->stream, c->n2, ncols, nchunks,
+                     Pm, W, ldw, c->d_partial);
   hipLaunchKernelGGL(k_panel_dot_finish_p, dim3(ncols * P), dim3(64), 0, c->stream, P, nchunks, c->d_partial, h, ldh,
                      hacc, ldacc);
 }
@@ -619,7 +591,7 @@ void launch_chol_block(plfem_ctx* c, const double* G, int ldg, double* Tblk, int
 void launch_gram_chol_block(plfem_ctx* c, const double* W, const double* BW, int64_t ldw, double* Tblk, int ldT, double* Rinv) {
   constexpr int P = BLOCK_P;
   const int nchunks = c->npartial;
-  hipLaunchKernelGGL((k_panel_dot_p<P, true>), dim3(nchunks, 1), dim3(256), 0, c->stream, c->n2, P, nchunks, W, BW, ldw, c->d_partial);
+  hipLaunchKernelGGL(k_panel_dot_p<P>, dim3(nchunks, 1), dim3(256), 0, c->stream, c->n2, P, nchunks, W, BW, ldw, c->d_partial);
   hipLaunchKernelGGL(k_chol_small<P>, dim3(1), dim3(64 * P * P), 0, c->stream, (const double*)nullptr, 0, c->d_partial, nchunks,
                      Tblk, ldT, Rinv, c->d_counters);
 }
