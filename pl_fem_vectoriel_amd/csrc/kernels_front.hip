@@ -165,7 +165,8 @@ __global__ __launch_bounds__(256) void k_front_gather(
 }
 
 // ------------------------------------------------------------------------------------------------
-// block LDL^T, step kb of a level:  launch A (pivot block + panel) -> launch B (update + inverse row)
+// block LDL^T of a level:  k_ldl_first_panel (pivot block + panel of step 0), then ONE launch per block step
+// (k_ldl_update: update + inverse row + write-back, and the pivot block + panel of the next step)
 // ------------------------------------------------------------------------------------------------
 // The pivots are taken NODE PAIR by node pair: local DOFs (2q, 2q+1) of a front are the two field components of one P2
 // node (scalar pencil: two neighbouring nodes), and a step of the LDL^T eliminates such a pair -- Bunch-Kaufman's choice
@@ -267,7 +268,7 @@ struct PivotLds {
   double rmax[NB];            // largest entry of every row pair of the block on arrival
 };
 
-// src: the block itself, src[i + c * ld] = a[i][c] -- the front in global memory (ld = m) or an LDS tile (look-ahead).
+// src: the block itself, src[i + c * ld] = a[i][c] -- the front in global memory (ld = m) or an LDS tile (column workgroups).
 __device__ __forceinline__ void ldl_pivot_block(const double* src, int64_t ld, int nbk, int tid,
                                                 double (*tile)[NB + 1], double* __restrict__ sDd, double* __restrict__ sDo,
                                                 PivotLds& S, int32_t* __restrict__ counters) {
