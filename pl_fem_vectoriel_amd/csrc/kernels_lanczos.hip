@@ -359,48 +359,78 @@ __global__ __launch_bounds__(256) void k_core_mask(int N, const double* __restri
 // [4] vx.Dxx vx + 2 vx.Dxy vy + vy.Dyy vy.   8 lanes per row.
 constexpr int POST_ROWS = 256;   // rows per block
 // DPN = 1 (scalar solver, solver_fem.py:268-271): [0] sum v^2, [2] core v^2, [4] v.M v with M in the dxx argument
+// MB modes per workgroup (blockIdx.y = group of MB): the matrix entries and column indices of a row are read once for
+// MB vectors instead of once per vector (the 22 eigenvectors of C1 read the three D blocks 22 times: 167 us); each mode's
+// sums are formed in the order of the one-mode kernel, so the results are the same bits.
+constexpr int POST_MB = 4;
 template <int DPN>
-__global__ __launch_bounds__(256) void k_post_sums(int N, int nblocks, const int32_t* __restrict__ rowptr,
+__global__ __launch_bounds__(256) void k_post_sums(int N, int k, int nblocks, const int32_t* __restrict__ rowptr,
                                                    const int32_t* __restrict__ colind, const double* __restrict__ dxx,
                                                    const double* __restrict__ dxy, const double* __restrict__ dyy,
                                                    const uint8_t* __restrict__ mask, const double* __restrict__ evecs,
                                                    double* __restrict__ partial) {
-  const int mode = blockIdx.y;
-  const double* vx = evecs + (int64_t)mode * DPN * N;
-  const double* vy = vx + (DPN == 2 ? N : 0);
-  __shared__ double red[4][5];
-  double acc[5] = {0, 0, 0, 0, 0};
+  constexpr int MB = POST_MB;
+  const int mode0 = blockIdx.y * MB;
+  const int nm = min(MB, k - mode0);
+  const double* vx[MB];
+#pragma unroll
+  for (int j = 0; j < MB; ++j) vx[j] = evecs + (int64_t)min(mode0 + j, k - 1) * DPN * N;     // (clamped: result dropped)
+  const int64_t yoff = DPN == 2 ? N : 0;
+  __shared__ double red[4][MB][5];
+  double acc[MB][5];
+#pragma unroll
+  for (int j = 0; j < MB; ++j)
+#pragma unroll
+    for (int t = 0; t < 5; ++t) acc[j][t] = 0.0;
   const int sub = threadIdx.x & 7;
   for (int rr = threadIdx.x >> 3; rr < POST_ROWS; rr += 32) {
     int row = blockIdx.x * POST_ROWS + rr;
     if (row >= N) break;
-    double px = 0, py = 0;   // (Dxx vx + Dxy vy)_row, (Dyy vy)_row
+    double px[MB], py[MB];   // (Dxx vx + Dxy vy)_row, (Dyy vy)_row
+#pragma unroll
+    for (int j = 0; j < MB; ++j) { px[j] = 0.0; py[j] = 0.0; }
     int q1 = rowptr[row + 1];
     for (int q = rowptr[row] + sub; q < q1; q += 8) {
       int c = colind[q];
-      if (DPN == 1) { px += dxx[q] * vx[c]; continue; }
-      double ux = vx[c], uy = vy[c];
-      px += dxx[q] * ux + 2.0 * dxy[q] * uy;
-      py += dyy[q] * uy;
+      const double a = dxx[q];
+      if (DPN == 1) {
+#pragma unroll
+        for (int j = 0; j < MB; ++j) px[j] += a * vx[j][c];
+        continue;
+      }
+      const double b = dxy[q], d = dyy[q];
+#pragma unroll
+      for (int j = 0; j < MB; ++j) {
+        double ux = vx[j][c], uy = vx[j][yoff + c];
+        px[j] += a * ux + 2.0 * b * uy;
+        py[j] += d * uy;
+      }
     }
-    double x = vx[row], y = DPN == 2 ? vy[row] : 0.0;
-    acc[4] += x * px + y * py;
-    if (sub == 0) {
-      acc[0] += x * x;
-      acc[1] += y * y;
-      if (mask[row]) { acc[2] += x * x; acc[3] += y * y; }
+    const bool msk = mask[row] != 0;
+#pragma unroll
+    for (int j = 0; j < MB; ++j) {
+      double x = vx[j][row], y = DPN == 2 ? vx[j][yoff + row] : 0.0;
+      acc[j][4] += x * px[j] + y * py[j];
+      if (sub == 0) {
+        acc[j][0] += x * x;
+        acc[j][1] += y * y;
+        if (msk) { acc[j][2] += x * x; acc[j][3] += y * y; }
+      }
     }
   }
 #pragma unroll
-  for (int k = 0; k < 5; ++k) {
-    double v = acc[k];
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][k] = v;
-  }
+  for (int j = 0; j < MB; ++j)
+#pragma unroll
+    for (int t = 0; t < 5; ++t) {
+      double v = acc[j][t];
+      for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+      if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][j][t] = v;
+    }
   __syncthreads();
-  if (threadIdx.x < 5)
-    partial[((int64_t)mode * nblocks + blockIdx.x) * 5 + threadIdx.x] =
-        red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+  if ((int)threadIdx.x < 5 * nm) {
+    const int j = threadIdx.x / 5, t = threadIdx.x % 5;
+    partial[((int64_t)(mode0 + j) * nblocks + blockIdx.x) * 5 + t] = red[0][j][t] + red[1][j][t] + red[2][j][t] + red[3][j][t];
+  }
 }
 
 // one wave per (mode, quantity): lane l adds blocks l, l + 64, ... in order, then a fixed-order lane reduction
@@ -440,51 +470,79 @@ __global__ __launch_bounds__(256) void k_gather_interior(int N, int nsolve, int 
 // ---- a-posteriori residuals: per (row chunk, vector) partial sums [0] sum |A v - lambda B v|^2, [1] sum |A v|^2
 // over the interior rows; 8 lanes per scalar row, both field components in one pass over the shared pattern.
 template <int DPN>
-__global__ __launch_bounds__(256) void k_resid_sums(int N, int nblocks, const int32_t* __restrict__ rowptr,
+__global__ __launch_bounds__(256) void k_resid_sums(int N, int k, int nblocks, const int32_t* __restrict__ rowptr,
                                                     const int32_t* __restrict__ colind, const uint8_t* __restrict__ bmask,
                                                     const double* __restrict__ vxx, const double* __restrict__ vxy,
                                                     const double* __restrict__ vyx, const double* __restrict__ vyy,
                                                     const double* __restrict__ vm, const double* __restrict__ lam,
                                                     const double* __restrict__ evecs, double* __restrict__ partial) {
-  const int mode = blockIdx.y;
-  const double* vx = evecs + (int64_t)mode * DPN * N;
-  const double* vy = vx + (DPN == 2 ? N : 0);
-  const double l = lam[mode];
-  __shared__ double red[4][2];
-  double r2 = 0.0, a2 = 0.0;
+  constexpr int MB = POST_MB;                           // modes per workgroup, as in k_post_sums
+  const int mode0 = blockIdx.y * MB;
+  const int nm = min(MB, k - mode0);
+  const double* vx[MB];
+  double l[MB];
+#pragma unroll
+  for (int j = 0; j < MB; ++j) {
+    const int mode = min(mode0 + j, k - 1);
+    vx[j] = evecs + (int64_t)mode * DPN * N;
+    l[j] = lam[mode];
+  }
+  const int64_t yoff = DPN == 2 ? N : 0;
+  __shared__ double red[4][MB][2];
+  double r2[MB], a2[MB];
+#pragma unroll
+  for (int j = 0; j < MB; ++j) { r2[j] = 0.0; a2[j] = 0.0; }
   const int sub = threadIdx.x & 7;
   for (int rr = threadIdx.x >> 3; rr < POST_ROWS; rr += 32) {
     const int row = blockIdx.x * POST_ROWS + rr;
     if (row >= N) break;
     if (bmask[row]) continue;
-    double ax = 0, ay = 0, bx = 0, by = 0;
+    double ax[MB], ay[MB], bx[MB], by[MB];
+#pragma unroll
+    for (int j = 0; j < MB; ++j) { ax[j] = 0; ay[j] = 0; bx[j] = 0; by[j] = 0; }
     const int q1 = rowptr[row + 1];
     for (int q = rowptr[row] + sub; q < q1; q += 8) {
       const int c = colind[q];
-      if (DPN == 1) { ax += vxx[q] * vx[c]; bx += vm[q] * vx[c]; continue; }
-      const double ux = vx[c], uy = vy[c], m = vm[q];
-      ax += vxx[q] * ux + vxy[q] * uy;
-      ay += vyx[q] * ux + vyy[q] * uy;
-      bx += m * ux;
-      by += m * uy;
+      const double axx = vxx[q], m = vm[q];
+      if (DPN == 1) {
+#pragma unroll
+        for (int j = 0; j < MB; ++j) { const double ux = vx[j][c]; ax[j] += axx * ux; bx[j] += m * ux; }
+        continue;
+      }
+      const double axy = vxy[q], ayx = vyx[q], ayy = vyy[q];
+#pragma unroll
+      for (int j = 0; j < MB; ++j) {
+        const double ux = vx[j][c], uy = vx[j][yoff + c];
+        ax[j] += axx * ux + axy * uy;
+        ay[j] += ayx * ux + ayy * uy;
+        bx[j] += m * ux;
+        by[j] += m * uy;
+      }
     }
 #pragma unroll
-    for (int off = 4; off >= 1; off >>= 1) {
-      ax += __shfl_xor(ax, off, 8); ay += __shfl_xor(ay, off, 8);
-      bx += __shfl_xor(bx, off, 8); by += __shfl_xor(by, off, 8);
-    }
-    if (sub == 0) {
-      const double rx = ax - l * bx, ry = ay - l * by;
-      r2 += rx * rx + ry * ry;
-      a2 += ax * ax + ay * ay;
+    for (int j = 0; j < MB; ++j) {
+#pragma unroll
+      for (int off = 4; off >= 1; off >>= 1) {
+        ax[j] += __shfl_xor(ax[j], off, 8); ay[j] += __shfl_xor(ay[j], off, 8);
+        bx[j] += __shfl_xor(bx[j], off, 8); by[j] += __shfl_xor(by[j], off, 8);
+      }
+      if (sub == 0) {
+        const double rx = ax[j] - l[j] * bx[j], ry = ay[j] - l[j] * by[j];
+        r2[j] += rx * rx + ry * ry;
+        a2[j] += ax[j] * ax[j] + ay[j] * ay[j];
+      }
     }
   }
-  for (int off = 32; off >= 1; off >>= 1) { r2 += __shfl_xor(r2, off); a2 += __shfl_xor(a2, off); }
-  if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][0] = r2; red[threadIdx.x >> 6][1] = a2; }
+#pragma unroll
+  for (int j = 0; j < MB; ++j) {
+    for (int off = 32; off >= 1; off >>= 1) { r2[j] += __shfl_xor(r2[j], off); a2[j] += __shfl_xor(a2[j], off); }
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][j][0] = r2[j]; red[threadIdx.x >> 6][j][1] = a2[j]; }
+  }
   __syncthreads();
-  if (threadIdx.x < 2)
-    partial[((int64_t)mode * nblocks + blockIdx.x) * 2 + threadIdx.x] =
-        red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+  if ((int)threadIdx.x < 2 * nm) {
+    const int j = threadIdx.x >> 1, t = threadIdx.x & 1;
+    partial[((int64_t)(mode0 + j) * nblocks + blockIdx.x) * 2 + t] = red[0][j][t] + red[1][j][t] + red[2][j][t] + red[3][j][t];
+  }
 }
 
 __global__ __launch_bounds__(64) void k_resid_finish(int nblocks, const double* __restrict__ partial, double* __restrict__ out) {
@@ -508,11 +566,11 @@ void launch_residuals(plfem_ctx* c, int k, const double* lam_host, const double*
   double* partial = c->d_post;                       // [k][nblocks][2]
   double* sums = c->d_post + (int64_t)k * nblocks * 2;
   if (c->dpn == 1)
-    hipLaunchKernelGGL(k_resid_sums<1>, dim3(nblocks, k), dim3(256), 0, st, N, nblocks, c->d_rowptr, c->d_colind, c->d_bmask,
+    hipLaunchKernelGGL(k_resid_sums<1>, dim3(nblocks, (k + POST_MB - 1) / POST_MB), dim3(256), 0, st, N, k, nblocks, c->d_rowptr, c->d_colind, c->d_bmask,
                        c->d_vals[PLFEM_BLK_AXX], c->d_vals[PLFEM_BLK_AXY], c->d_vals[PLFEM_BLK_AYX], c->d_vals[PLFEM_BLK_AYY],
                        c->d_vals[PLFEM_BLK_MINV], c->d_hacc, evecs, partial);
   else
-    hipLaunchKernelGGL(k_resid_sums<2>, dim3(nblocks, k), dim3(256), 0, st, N, nblocks, c->d_rowptr, c->d_colind, c->d_bmask,
+    hipLaunchKernelGGL(k_resid_sums<2>, dim3(nblocks, (k + POST_MB - 1) / POST_MB), dim3(256), 0, st, N, k, nblocks, c->d_rowptr, c->d_colind, c->d_bmask,
                        c->d_vals[PLFEM_BLK_AXX], c->d_vals[PLFEM_BLK_AXY], c->d_vals[PLFEM_BLK_AYX], c->d_vals[PLFEM_BLK_AYY],
                        c->d_vals[PLFEM_BLK_MINV], c->d_hacc, evecs, partial);
   hipLaunchKernelGGL(k_resid_finish, dim3(2 * k), dim3(64), 0, st, nblocks, partial, sums);
@@ -657,11 +715,11 @@ void launch_post(plfem_ctx* c, int k, double* evecs, int ncore, double* out_host
   double* partial = c->d_post;                       // [k][nblocks][5]
   double* sums = c->d_post + (int64_t)k * nblocks * 5;   // [k][5]
   if (c->dpn == 1)      // scalar solver: v.M v with M = the MINV slot
-    hipLaunchKernelGGL(k_post_sums<1>, dim3(nblocks, k), dim3(256), 0, st, N, nblocks, c->d_rowptr, c->d_colind,
+    hipLaunchKernelGGL(k_post_sums<1>, dim3(nblocks, (k + POST_MB - 1) / POST_MB), dim3(256), 0, st, N, k, nblocks, c->d_rowptr, c->d_colind,
                        c->d_vals[PLFEM_BLK_MINV], c->d_vals[PLFEM_BLK_DXY], c->d_vals[PLFEM_BLK_DYY], c->d_coremask, evecs,
                        partial);
   else
-    hipLaunchKernelGGL(k_post_sums<2>, dim3(nblocks, k), dim3(256), 0, st, N, nblocks, c->d_rowptr, c->d_colind,
+    hipLaunchKernelGGL(k_post_sums<2>, dim3(nblocks, (k + POST_MB - 1) / POST_MB), dim3(256), 0, st, N, k, nblocks, c->d_rowptr, c->d_colind,
                        c->d_vals[PLFEM_BLK_DXX], c->d_vals[PLFEM_BLK_DXY], c->d_vals[PLFEM_BLK_DYY], c->d_coremask, evecs,
                        partial);
   hipLaunchKernelGGL(k_post_finish, dim3(k * 5), dim3(64), 0, st, k, nblocks, partial, sums);
