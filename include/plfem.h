@@ -260,8 +260,9 @@ int plfem_profile_end(plfem_ctx* ctx, double* out_host /* [PLFEM_PROF_COUNT][3] 
  * a given (tree level, block step, stage: 0 assembled, 1 or 2 pivot block + panel of the step done (its own launch for
  * step 0 of a level, the launch of the step before otherwise), 3 or 4 the step's launch done: trailing update + inverse
  * row + pivot write-back, next pivot block + panel; 5 level done), and copy a slice of a named device workspace
- * ("front","fvec","fvec2","xl","wbuf","rbuf","dinv","delta","elem"; "colind","slot_row": the device-built CSR index
- * arrays, converted to double).
+ * ("front","schur","fvec","fvec2","xl","wbuf","rbuf","dinv","delta","elem"; "colind","slot_row": the device-built CSR
+ * index arrays, converted to double).  "schur", "wbuf" and "rbuf" -- scratch of the factorisation -- share their part of the
+ * workspace with the Lanczos bases: copy them before the next plfem_lanczos_shift_invert / plfem_solve of the context.
  * plfem_debug_symeig: the host eigensolver of the Lanczos drivers (projected matrices of order
  * <= ~200; needs no GPU).  a_host: n x n symmetric.  last_rows < 0: v_out[i*n + k] = component k of
  * eigenvector i; last_rows = p >= 0: v_out[i*p + a] = component n-p+a of eigenvector i only (the
