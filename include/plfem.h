@@ -230,8 +230,8 @@ int plfem_postprocess(plfem_ctx* ctx, int32_t k, double* evecs_dev, const double
 int plfem_residuals(plfem_ctx* ctx, int32_t k, const double* evals_host, const double* evecs_dev, double* out_host);
 
 /* Options by name: "refine_steps" (iterative-refinement passes inside every OP application of
- * plfem_lanczos_shift_invert, default 0), "debug_perturb" (test hook: relative perturbation applied to
- * the root front's D after every factorisation, default 0 = off).  PLFEM_EINVAL for unknown names. */
+ * plfem_lanczos_shift_invert, default 0).  PLFEM_EINVAL for unknown names.  (No option alters a result in any other
+ * way: the fault-injection hook of the test-suite is not in this library, see PLFEM_TEST_HOOKS below.) */
 int plfem_set_option(plfem_ctx* ctx, const char* name, double value);
 
 /* timings of the last calls in microseconds (HIP events on the context's stream):
@@ -255,7 +255,12 @@ enum { PLFEM_PROF_KFWD = 0, PLFEM_PROF_FWD_SWEEP, PLFEM_PROF_BWD_SWEEP, PLFEM_PR
 int plfem_profile_begin(plfem_ctx* ctx, int32_t max_ranges);
 int plfem_profile_end(plfem_ctx* ctx, double* out_host /* [PLFEM_PROF_COUNT][3] */);
 
+#ifdef PLFEM_TEST_HOOKS
 /* ---------------------------------------------------------------------------------------------
+ * TEST HOOKS -- NOT exported by libplfem_hip.so.  They live in the add-on libplfem_testhooks.so (csrc/api_debug.hip,
+ * built next to the product library and linked against it), which only tests/ and scripts/ load; define
+ * PLFEM_TEST_HOOKS before including this header to see the declarations.  They take contexts created by the product
+ * library and run the product library's own kernels.
  * Debugging aids for the test-suite (no reference counterpart): run the factorisation only up to
  * a given (tree level, block step, stage: 0 assembled, 1 or 2 pivot block + panel of the step done (its own launch for
  * step 0 of a level, the launch of the step before otherwise), 3 or 4 the step's launch done: trailing update + inverse
@@ -278,6 +283,10 @@ int plfem_debug_copy(plfem_ctx* ctx, const char* name, int64_t offset, int64_t c
 int plfem_debug_solve_block(plfem_ctx* ctx, int32_t reps, int32_t filter);
 int plfem_debug_symeig(int32_t n, const double* a_host, int32_t last_rows, double* w_out, double* v_out);
 int plfem_debug_symeig_band(int32_t n, int32_t b, const double* a_host, int32_t nsel, double* w_out, double* v_out);
+/* fault injection for the a-posteriori guard: from the next plfem_factor on, D^-1 of the root front is scaled by
+ * 1 + value after every factorisation (0 = off) */
+int plfem_debug_set_perturb(plfem_ctx* ctx, double value);
+#endif /* PLFEM_TEST_HOOKS */
 
 #ifdef __cplusplus
 }

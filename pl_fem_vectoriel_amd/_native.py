@@ -16,6 +16,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libplfem_hip.so")
+HOOKS_PATH = os.path.join(_HERE, "libplfem_testhooks.so")
 
 PLFEM_OK = 0
 PLFEM_EINVAL, PLFEM_EMESH, PLFEM_EHIP, PLFEM_ENOCONV, PLFEM_ESTATE, PLFEM_ESINGULAR = -1, -2, -3, -4, -5, -6
@@ -31,11 +32,13 @@ EXPORTS = (
     "plfem_symbolic_get", "plfem_workspace_bytes", "plfem_create", "plfem_destroy", "plfem_last_error", "plfem_synchronize",
     "plfem_assemble_hfield", "plfem_block_values_dev", "plfem_block_values_host", "plfem_spmv", "plfem_factor",
     "plfem_solve", "plfem_lanczos_shift_invert", "plfem_postprocess", "plfem_timings",
-    "plfem_debug_factor_until", "plfem_debug_copy", "plfem_profile_begin", "plfem_profile_end",
-    "plfem_mesh_edge_count", "plfem_mesh_refine", "plfem_debug_symeig", "plfem_debug_symeig_band",
+    "plfem_profile_begin", "plfem_profile_end",
+    "plfem_mesh_edge_count", "plfem_mesh_refine",
     "plfem_residuals", "plfem_set_option", "plfem_symbolic_create_ex", "plfem_assemble_scalar", "plfem_cmt_coupling",
-    "plfem_debug_solve_block",
 )
+# the test hooks (include/plfem.h under PLFEM_TEST_HOOKS): exported by the add-on libplfem_testhooks.so ONLY
+TEST_HOOK_EXPORTS = ("plfem_debug_factor_until", "plfem_debug_copy", "plfem_debug_solve_block", "plfem_debug_symeig",
+                     "plfem_debug_symeig_band", "plfem_debug_set_perturb")
 MAX_NCV = 320                       # PLFEM_MAX_NCV of include/plfem.h
 PROF_SLOTS = ("k_fwd", "fwd_sweep", "bwd_sweep", "spmv_b")
 
@@ -62,6 +65,7 @@ class ArpackLikeNoConvergence(_ArpackNoConvergence, RuntimeError):
 
 
 _lib = None
+_hooks = None
 
 
 def _tune_host_allocator(_force: bool = False) -> None:
@@ -138,10 +142,6 @@ def load_library() -> ctypes.CDLL:
     lib.plfem_postprocess.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p,
                                       ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
     lib.plfem_timings.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
-    lib.plfem_debug_factor_until.argtypes = [ctypes.c_void_p, ctypes.c_double, ctypes.c_int32, ctypes.c_int32,
-                                             ctypes.c_int32]
-    lib.plfem_debug_copy.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p]
-    lib.plfem_debug_solve_block.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32]
     lib.plfem_mesh_edge_count.argtypes = [ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p,
                                           ctypes.POINTER(ctypes.c_int32), ctypes.c_char_p, ctypes.c_int32]
     lib.plfem_mesh_refine.argtypes = [ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p,
@@ -179,18 +179,38 @@ def mesh_refine(p, t):
     return p2, t2
 
 
+def load_test_hooks() -> ctypes.CDLL:
+    """Load the add-on ``libplfem_testhooks.so`` (``plfem_debug_*``; tests and scripts only -- the product library
+    exports none of them).  It links against ``libplfem_hip.so``, which is loaded first, so its entry points run the
+    product library's own kernels on contexts the product library created."""
+    global _hooks
+    if _hooks is not None:
+        return _hooks
+    load_library()
+    if not os.path.exists(HOOKS_PATH):
+        raise RuntimeError(f"{HOOKS_PATH} not found -- build it with `python -c 'import __graft_entry__ as g; g.build()'`")
+    h = ctypes.CDLL(HOOKS_PATH)
+    h.plfem_debug_factor_until.argtypes = [ctypes.c_void_p, ctypes.c_double, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]
+    h.plfem_debug_copy.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p]
+    h.plfem_debug_solve_block.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32]
+    h.plfem_debug_set_perturb.argtypes = [ctypes.c_void_p, ctypes.c_double]
+    h.plfem_debug_symeig.argtypes = [ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]
+    h.plfem_debug_symeig_band.argtypes = [ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32,
+                                          ctypes.c_void_p, ctypes.c_void_p]
+    _hooks = h
+    return h
+
+
 def debug_symeig(a, last_rows: int = -1):
-    """Host eigensolver of the Lanczos drivers (``plfem_debug_symeig``): returns ``(w, V)`` with eigenvector i
+    """Host eigensolver of the Lanczos drivers (test hook ``plfem_debug_symeig``): returns ``(w, V)`` with eigenvector i
     in row i of V — all n components, or only the last ``last_rows`` ones."""
-    lib = load_library()
+    lib = load_test_hooks()
     a = np.ascontiguousarray(np.asarray(a, dtype=np.float64))
     n = a.shape[0]
     if a.shape != (n, n):
         raise ValueError("square matrix expected")
     w = np.empty(n, dtype=np.float64)
     v = np.empty((n, n if last_rows < 0 else last_rows), dtype=np.float64)
-    lib.plfem_debug_symeig.argtypes = [ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]
-    lib.plfem_debug_symeig.restype = ctypes.c_int
     rc = lib.plfem_debug_symeig(n, _ptr(a), int(last_rows), _ptr(w), _ptr(v))
     if rc != PLFEM_OK:
         raise ValueError(f"plfem_debug_symeig failed ({rc})")
@@ -198,18 +218,15 @@ def debug_symeig(a, last_rows: int = -1):
 
 
 def debug_symeig_band(a, b: int, nsel: int):
-    """Band path of the host eigensolver (``plfem_debug_symeig_band``): ``(w, V)`` with w ascending and the
+    """Band path of the host eigensolver (test hook ``plfem_debug_symeig_band``): ``(w, V)`` with w ascending and the
     eigenvector of ``w[i]`` in row i of V for the ``nsel`` eigenvalues of largest magnitude (zero rows elsewhere)."""
-    lib = load_library()
+    lib = load_test_hooks()
     a = np.ascontiguousarray(np.asarray(a, dtype=np.float64))
     n = a.shape[0]
     if a.shape != (n, n):
         raise ValueError("square matrix expected")
     w = np.empty(n, dtype=np.float64)
     v = np.empty((n, n), dtype=np.float64)
-    lib.plfem_debug_symeig_band.argtypes = [ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32,
-                                            ctypes.c_void_p, ctypes.c_void_p]
-    lib.plfem_debug_symeig_band.restype = ctypes.c_int
     rc = lib.plfem_debug_symeig_band(n, int(b), _ptr(a), int(nsel), _ptr(w), _ptr(v))
     if rc != PLFEM_OK:
         raise ValueError(f"plfem_debug_symeig_band failed ({rc})")
@@ -415,18 +432,23 @@ class Context:
         return {"assemble_us": t[0], "factor_us": t[1], "lanczos_us": t[2], "post_us": t[3], "upload_us": t[4],
                 "pivot_perturbations": int(t[5])}
 
+    # -- test hooks (libplfem_testhooks.so; not in the product library) ---------------------------------------------
     def debug_factor_until(self, sigma, level, step, stage):
-        self._check(self._lib.plfem_debug_factor_until(self._h, float(sigma), int(level), int(step), int(stage)),
+        self._check(load_test_hooks().plfem_debug_factor_until(self._h, float(sigma), int(level), int(step), int(stage)),
                     "plfem_debug_factor_until")
 
     def debug_copy(self, name: str, offset: int, count: int) -> np.ndarray:
         out = np.empty(int(count), dtype=np.float64)
-        self._check(self._lib.plfem_debug_copy(self._h, name.encode(), ctypes.c_int64(int(offset)),
-                                               ctypes.c_int64(int(count)), _ptr(out)), "plfem_debug_copy")
+        self._check(load_test_hooks().plfem_debug_copy(self._h, name.encode(), ctypes.c_int64(int(offset)),
+                                                       ctypes.c_int64(int(count)), _ptr(out)), "plfem_debug_copy")
         return out
 
     def debug_solve_block(self, reps: int = 1, front_filter: int = 0):
-        self._check(self._lib.plfem_debug_solve_block(self._h, int(reps), int(front_filter)), "plfem_debug_solve_block")
+        self._check(load_test_hooks().plfem_debug_solve_block(self._h, int(reps), int(front_filter)), "plfem_debug_solve_block")
+
+    def debug_set_perturb(self, value: float):
+        """Fault injection: D^-1 of the root front scaled by ``1 + value`` after every factorisation (0 = off)."""
+        self._check(load_test_hooks().plfem_debug_set_perturb(self._h, float(value)), "plfem_debug_set_perturb")
 
     def profile_begin(self, max_launches: int = 4096):
         self._check(self._lib.plfem_profile_begin(self._h, int(max_launches)), "plfem_profile_begin")

@@ -672,8 +672,7 @@ extern "C" int plfem_factor(plfem_ctx* c, double sigma) {
   HIP_TRY(c, hipEventRecord(c->ev[1][0], c->stream));
   HIP_TRY(c, hipMemsetAsync(c->d_fvec, 0, sizeof(double) * 2 * c->fnodes_total * plfem::BLOCK_P, c->stream));   // (see plfem_create)
   plfem::launch_factor(c, sigma);
-  if (c->debug_perturb != 0.0)   // test hook (plfem_set_option "debug_perturb"): a slightly wrong factor
-    plfem::launch_scale(c, (int64_t)2 * c->dpn * c->S->fs[0], 1.0 + c->debug_perturb, c->d_delta);
+  if (c->test_post_factor) c->test_post_factor(c);   // null unless the test-hook add-on library installed one (api_debug.hip)
   HIP_TRY(c, hipEventRecord(c->ev[1][1], c->stream));
   c->ev_used[1] = true;
   TRY(check_launch(c, "factor"));
@@ -1151,58 +1150,6 @@ extern "C" int plfem_timings(plfem_ctx* c, double* out_host) {
   return PLFEM_OK;
 }
 
-// ---- debugging aids (used by tests/ only; not part of the reference-facing surface) --------------
-extern "C" int plfem_debug_factor_until(plfem_ctx* c, double sigma, int32_t level, int32_t step, int32_t stage) {
-  if (!c) return PLFEM_EINVAL;
-  if (!c->assembled) { c->err = "debug factor before assemble"; return PLFEM_ESTATE; }
-  plfem::launch_factor(c, sigma, level, step, stage);
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
-  return check_launch(c, "debug factor");
-}
-
-// timing aid: reps block solves (BLOCK_P right-hand sides out of the Lanczos work buffers) with an optional front
-// filter (0 all fronts, 1 skip fronts with more than 128 owned DOFs, 2 only those: wrong results, kernel times only)
-extern "C" int plfem_debug_solve_block(plfem_ctx* c, int32_t reps, int32_t filter) {
-  if (!c || reps < 1) return PLFEM_EINVAL;
-  if (!c->factored) { c->err = "debug solve before factor"; return PLFEM_ESTATE; }
-  if (c->max_block_p < plfem::BLOCK_P) { c->err = "plfem_debug_solve_block: the LDS budget of this context allows one right-hand side per sweep only"; return PLFEM_EINVAL; }
-  HIP_TRY(c, hipSetDevice(c->device));
-  HIP_TRY(c, hipMemsetAsync(c->d_bw, 0, sizeof(double) * c->n2 * plfem::BLOCK_P, c->stream));
-  c->debug_sweep_filter = filter;
-  for (int r = 0; r < reps; ++r) plfem::launch_solve_block(c, c->d_bw, c->d_w, c->n2, false);
-  c->debug_sweep_filter = 0;
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
-  return check_launch(c, "debug solve block");
-}
-
-extern "C" int plfem_debug_copy(plfem_ctx* c, const char* name, int64_t offset, int64_t count, double* out_host) {
-  if (!c || !name || !out_host || offset < 0 || count < 0) return PLFEM_EINVAL;
-  std::string n(name);
-  const double* src = nullptr;
-  if (n == "front") src = c->d_front;
-  else if (n == "schur") src = c->d_schur;            // (arena of level l starts at (l & 1) * arena_doubles)
-  else if (n == "fvec") src = c->d_fvec;
-  else if (n == "wbuf") src = c->d_wbuf;
-  else if (n == "rbuf") src = c->d_rbuf;
-  else if (n == "dinv") src = c->d_dinv;
-  else if (n == "delta") src = c->d_delta;
-  else if (n == "fvec2") src = c->d_fvec2;
-  else if (n == "xl") src = c->d_xl;
-  else if (n == "elem") src = c->d_elem;
-  else if (n == "colind" || n == "slot_row") {            // int32 index arrays, delivered as doubles
-    if (offset + count > c->nnz) return PLFEM_EINVAL;
-    std::vector<int32_t> tmp((size_t)count);
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    HIP_TRY(c, hipMemcpy(tmp.data(), (n == "colind" ? c->d_colind : c->d_slot_row) + offset, sizeof(int32_t) * count, hipMemcpyDeviceToHost));
-    for (int64_t q = 0; q < count; ++q) out_host[q] = (double)tmp[q];
-    return PLFEM_OK;
-  }
-  else return PLFEM_EINVAL;
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
-  HIP_TRY(c, hipMemcpy(out_host, src + offset, sizeof(double) * count, hipMemcpyDeviceToHost));
-  return PLFEM_OK;
-}
-
 // ---- live kernel timing for bench.py's roofline object -------------------------------------------
 extern "C" int plfem_profile_begin(plfem_ctx* c, int32_t max_ranges) {
   if (!c || max_ranges < 1) return PLFEM_EINVAL;
@@ -1254,9 +1201,6 @@ extern "C" int plfem_set_option(plfem_ctx* c, const char* name, double value) {
   if (n == "refine_steps") {
     if (value < 0 || value > 8) { c->err = "refine_steps must be in [0, 8]"; return PLFEM_EINVAL; }
     c->refine_steps = (int)value;
-  } else if (n == "debug_perturb") {
-    c->debug_perturb = value;
-    c->factored = false;              // takes effect at the next plfem_factor
   } else {
     c->err = "plfem_set_option: unknown option '" + n + "'";
     return PLFEM_EINVAL;

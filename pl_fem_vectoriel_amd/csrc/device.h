@@ -149,7 +149,10 @@ struct plfem_ctx {
   std::vector<double> prof_rbytes;   // algorithmic bytes of every timed range
   // options (plfem_set_option)
   int refine_steps = 0;           // iterative-refinement passes inside every OP application of the Lanczos drivers
-  double debug_perturb = 0.0;     // test hook: relative perturbation of the root front's D after every factorisation
+  // Test hooks: nothing in libplfem_hip.so sets these (no option, no export).  The add-on libplfem_testhooks.so
+  // (api_debug.hip, plfem_debug_*) installs them on a context the tests hand it.
+  void (*test_post_factor)(plfem_ctx*) = nullptr;   // called at the end of every plfem_factor
+  double test_perturb = 0.0;      // plfem_debug_set_perturb: relative perturbation of the root front's D^-1
   int debug_sweep_filter = 0;     // plfem_debug_solve_block: timing experiments (results are wrong when set)
   int max_block_p = plfem::BLOCK_P;   // right-hand sides per sweep the LDS budget allows (BLOCK_P or 1)
   int lds_limit = 0;              // bytes of LDS one workgroup may use on this device

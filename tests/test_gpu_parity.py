@@ -494,7 +494,7 @@ def test_a_posteriori_guard_fires_on_a_bad_factor(small, gpu_device):
     st = solver.last_stats
     assert st["refined"] is False and st["true_residual"] < 1e-8
     ctx = next(iter(solver._cache.values()))["ctx"]
-    ctx.set_option("debug_perturb", 1e-4)
+    ctx.debug_set_perturb(1e-4)
     try:
         modes = solver.solve_vectorial_modes(small.mesh, 6)
         st = solver.last_stats
@@ -505,11 +505,11 @@ def test_a_posteriori_guard_fires_on_a_bad_factor(small, gpu_device):
         assert mode_field_errors(modes, clean).max() < FIELD_TOL
         # a factor too wrong for one refinement pass to repair: an error (inaccurate factor, or no convergence of the
         # refined operator -- both RuntimeError), never a result
-        ctx.set_option("debug_perturb", 0.6)
+        ctx.debug_set_perturb(0.6)
         with pytest.raises(RuntimeError):
             solver.solve_vectorial_modes(small.mesh, 6)
     finally:
-        ctx.set_option("debug_perturb", 0.0)
+        ctx.debug_set_perturb(0.0)
     again = solver.solve_vectorial_modes(small.mesh, 6)
     assert solver.last_stats["refined"] is False
     for a, b in zip(again, clean):
