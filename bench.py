@@ -330,6 +330,28 @@ class Dist:
             self.dist.destroy_process_group()
 
 
+def phase_record(ls, step_ms):
+    """Where one cold step went, in ms; the entries (without ``sum`` / ``step``) add up to the step's wall time.
+    Host phases are wall-clock intervals of the Python layer, device phases HIP-event intervals inside the one
+    ``plfem_solve_modes`` call; ``call_gaps`` = that call's wall time minus its device phases (the wait for the index
+    upload to land, host work of the Lanczos driver between its steps' launches, the tail of the mode copy behind the
+    residual check); ``python`` = the rest of the step (solver construction, argument marshalling, the mode dicts and
+    filters, release of the previous step's context and mode list)."""
+    dev = {k: ls[k + "_us"] / 1e3 for k in ("upload", "assemble", "factor", "lanczos", "post", "residual")}
+    call = ls["t_call"] * 1e3
+    rec = {"symbolic_host": ls["t_symbolic"] * 1e3, "context": ls["t_context"] * 1e3, "pinned_alloc": ls["t_pinned"] * 1e3}
+    rec.update({"assemble": dev["assemble"], "factor": dev["factor"], "lanczos": dev["lanczos"], "post": dev["post"],
+                "residual_check": dev["residual"]})
+    # the index upload overlaps the host between plfem_create and the call; what of it the call still waits for is in call_gaps
+    rec["call_gaps"] = call - sum(rec[k] for k in ("assemble", "factor", "lanczos", "post", "residual_check"))
+    rec["python"] = step_ms - (rec["symbolic_host"] + rec["context"] + rec["pinned_alloc"] + call)
+    out = dict(rec)
+    out["sum"] = sum(out.values())
+    out["step"] = step_ms
+    out["index_upload_on_stream"] = dev["upload"]
+    return out
+
+
 def run_solve_config(args, D: Dist, levels: int, with_cpu_baseline: bool):
     """The headline configuration (cold C1 solve per step) or another rung of the ladder."""
     world = D.world
@@ -380,7 +402,8 @@ def run_solve_config(args, D: Dist, levels: int, with_cpu_baseline: bool):
     D.sync()
     kprof.update(launches=0, total_us=0.0, bytes=0.0, slots=None)
     # per-step wall times and host phases (diagnostics only: a shared host shows up as outliers in "context")
-    step_ms, host_ms = [], []
+    # and every phase of every step, so that "breakdown_ms" is the MEAN over the timed steps and adds up to ms_per_step
+    step_ms, host_ms, phases = [], [], []
     t0 = time.perf_counter()
     for it in range(args.steps):
         ts = time.perf_counter()
@@ -388,6 +411,7 @@ def run_solve_config(args, D: Dist, levels: int, with_cpu_baseline: bool):
         step_ms.append((time.perf_counter() - ts) * 1e3)
         ls = solver.last_stats
         host_ms.append((ls["t_symbolic"] * 1e3, ls["t_context"] * 1e3, ls.get("t_workspace", 0.0) * 1e3))
+        phases.append(phase_record(ls, step_ms[-1]))
     D.sync()
     elapsed = D.max_over_ranks(time.perf_counter() - t0)
     stats = dict(solver.last_stats)
@@ -440,10 +464,7 @@ def run_solve_config(args, D: Dist, levels: int, with_cpu_baseline: bool):
                                f"n={stats['n']}, 10 modes requested (k={stats['n_req']}, ncv={stats['ncv']})",
                    "step": "cold solve_vectorial_modes (symbolic + context + assembly + factor + Lanczos + residual check + post + D2H)",
                    "parallelism": f"{world} independent cross-sections, one per GPU"},
-        "breakdown_ms": {"symbolic_host": stats["t_symbolic"] * 1e3, "context": stats["t_context"] * 1e3,
-                         "assemble": stats["assemble_us"] / 1e3, "factor": stats["factor_us"] / 1e3,
-                         "lanczos": stats["lanczos_us"] / 1e3, "post": stats["post_us"] / 1e3,
-                         "copy_out": stats["t_copy_out"] * 1e3, "warm_step": warm_ms},
+        "breakdown_ms": dict({k: sum(ph[k] for ph in phases) / len(phases) for k in phases[0]}, warm_step=warm_ms),
         "lanczos": {"n_opinv": stats["n_opinv"], "restarts": stats["restarts"], "nconv": stats["nconv"],
                     "true_residual": stats.get("true_residual"), "refined": stats.get("refined")},
         "raw_eigenpairs_per_s": world * args.steps * stats["n_req"] / elapsed,
@@ -472,7 +493,7 @@ def _host_picture(solve, wall):
     tl = list(solve.timeline)
     if not tl:
         return None
-    lanes_seen = sorted({t[0] for t in tl})
+    lanes_seen = sorted({t[0] for t in tl})        # lane INDICES (0 .. lanes - 1), the same over all steps of the run
     host = {"lanes": len(lanes_seen),
             "busy_fraction_per_lane": [round(sum(t[4] - t[2] for t in tl if t[0] == ln) / wall, 3) for ln in lanes_seen],
             "analysis_wait_ms_total": round(1e3 * sum(t[3] - t[2] for t in tl), 2),

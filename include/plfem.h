@@ -39,6 +39,7 @@ extern "C" {
 #define PLFEM_ENOCONV (-4)  /* Lanczos did not converge within maxiter      -> scipy ArpackNoConvergence */
 #define PLFEM_ESTATE (-5)   /* call order violated (e.g. solve before factor) -> RuntimeError */
 #define PLFEM_ESINGULAR (-6)/* factorisation broke down (sigma is an eigenvalue) -> RuntimeError */
+#define PLFEM_ERESIDUAL (-7)/* plfem_solve_modes: eigenpairs fail the a-posteriori check even after the refined pass -> RuntimeError */
 
 typedef struct plfem_symbolic plfem_symbolic; /* host-only, mesh-only analysis               */
 typedef struct plfem_ctx plfem_ctx;           /* device + stream + workspaces for one symbolic */
@@ -229,6 +230,38 @@ int plfem_postprocess(plfem_ctx* ctx, int32_t k, double* evecs_dev, const double
  * ------------------------------------------------------------------------------------------- */
 int plfem_residuals(plfem_ctx* ctx, int32_t k, const double* evals_host, const double* evecs_dev, double* out_host);
 
+/* ---------------------------------------------------------------------------------------------
+ * The whole numeric solve in ONE call.
+ * Replaces: everything TrueVectorialMaxwellSolver.solve_vectorial_modes does between the mesh analysis and its mode
+ *           list -- assemble_hfield_system, the Dirichlet restriction, eigsh(..., sigma=...), the per-mode loop
+ *           (reference solver_fem.py:176-225); on a scalar context ScalarHelmholtzSolver.solve (solver_fem.py:251-271).
+ * = plfem_assemble_hfield (plfem_assemble_scalar on a context with one unknown per node) + plfem_factor(sigma) +
+ *   plfem_lanczos_shift_invert(k, ncv, tol, maxiter) + plfem_postprocess + plfem_residuals, enqueued back to back on the
+ *   context's stream, with the policy of the a-posteriori guard inside: if the largest residual exceeds residual_tol, or a
+ *   vanishing pivot was perturbed, the eigen-solve is repeated with one more refinement pass inside the operator and the
+ *   Ritz tolerance min(tol, tol_refined); if the check fails again: PLFEM_ERESIDUAL (message: plfem_last_error).
+ * Behind the Lanczos iteration (which waits on its own step events) the host waits for the device ONCE; the copy of the
+ * mode vectors to the host runs on a side stream beside the residual check.  Six C-ABI calls with four synchronisations
+ * and the host work between them become one call: 0.3-0.5 ms of a 23-ms solve at C1.
+ * Outputs (all caller-owned): evals_host[k] ascending; post_host[k][PLFEM_POST_COUNT] and *frac_core_host as
+ * plfem_postprocess; resid_host[k] as plfem_residuals; modes_int_host (may be NULL): [k][dofs_per_node nsolve] interior
+ * parts of the normalised vectors in the reference's 'Ex_dofs' / 'Ey_dofs' layout -- HOST memory, pinned for an
+ * asynchronous copy (pageable memory works, synchronously); stats_host[PLFEM_SOLVE_STATS] (may be NULL), see the enum.
+ * The full-length normalised vectors stay on the device in the context's own workspace: plfem_modes_dev.
+ * PLFEM_ENOCONV: as plfem_lanczos_shift_invert (evals_host and plfem_modes_dev hold the current Ritz pairs).
+ * ------------------------------------------------------------------------------------------- */
+enum { PLFEM_SOLVE_NCONV = 0, PLFEM_SOLVE_NOPINV, PLFEM_SOLVE_RESTARTS, PLFEM_SOLVE_MAX_REL_RES, PLFEM_SOLVE_BLOCK_SOLVES,
+       PLFEM_SOLVE_RESIDUAL_FIRST, PLFEM_SOLVE_RESIDUAL, PLFEM_SOLVE_REFINED, PLFEM_SOLVE_PERTURBED,
+       PLFEM_SOLVE_T_ASSEMBLE_US, PLFEM_SOLVE_T_FACTOR_US, PLFEM_SOLVE_T_LANCZOS_US, PLFEM_SOLVE_T_POST_US,
+       PLFEM_SOLVE_T_UPLOAD_US, PLFEM_SOLVE_T_RESIDUAL_US, PLFEM_SOLVE_T_CALL_US, PLFEM_SOLVE_STATS };
+int plfem_solve_modes(plfem_ctx* ctx, const double* cores_host, int32_t ncore, double eps_core, double eps_clad,
+                      double k0, double alpha_p, double sigma, int32_t k, int32_t ncv, double tol, int32_t maxiter,
+                      double residual_tol, double tol_refined, double* evals_host, double* post_host,
+                      double* frac_core_host, double* resid_host, double* modes_int_host, double* stats_host);
+/* device pointer of the k full-length vectors ([k][dofs_per_node N], row c = vector c) the last plfem_solve_modes (or
+ * plfem_lanczos_shift_invert) of the context produced; valid until the next plfem_factor / eigen-solve on the context */
+int plfem_modes_dev(plfem_ctx* ctx, const double** evecs_dev, int32_t* k);
+
 /* Options by name: "refine_steps" (iterative-refinement passes inside every OP application of
  * plfem_lanczos_shift_invert, default 0).  PLFEM_EINVAL for unknown names.  (No option alters a result in any other
  * way: the fault-injection hook of the test-suite is not in this library, see PLFEM_TEST_HOOKS below.) */
@@ -236,7 +269,7 @@ int plfem_set_option(plfem_ctx* ctx, const char* name, double value);
 
 /* timings of the last calls in microseconds (HIP events on the context's stream):
  * [0] assemble, [1] factor, [2] lanczos, [3] postprocess, [4] upload; plus counters
- * [5] pivot perturbations in the last factorisation. */
+ * [5] pivot perturbations in the last factorisation; [6] residual check of the last plfem_solve_modes. */
 int plfem_timings(plfem_ctx* ctx, double* out_host /* [8] */);
 
 /* ---------------------------------------------------------------------------------------------

@@ -19,7 +19,7 @@ LIB_PATH = os.path.join(_HERE, "libplfem_hip.so")
 HOOKS_PATH = os.path.join(_HERE, "libplfem_testhooks.so")
 
 PLFEM_OK = 0
-PLFEM_EINVAL, PLFEM_EMESH, PLFEM_EHIP, PLFEM_ENOCONV, PLFEM_ESTATE, PLFEM_ESINGULAR = -1, -2, -3, -4, -5, -6
+PLFEM_EINVAL, PLFEM_EMESH, PLFEM_EHIP, PLFEM_ENOCONV, PLFEM_ESTATE, PLFEM_ESINGULAR, PLFEM_ERESIDUAL = -1, -2, -3, -4, -5, -6, -7
 BLOCKS = ("Axx", "Axy", "Ayx", "Ayy", "Minv", "Dxx", "Dxy", "Dyy")
 INFO_NAMES = ("nv", "ne", "nedges", "N", "nsolve", "nnz", "levels", "nfronts", "front_doubles", "max_front",
               "solve_entries", "factor_flops", "t_numbering_us", "t_pattern_us", "t_tree_us", "t_fronts_us", "dofs_per_node",
@@ -35,7 +35,10 @@ EXPORTS = (
     "plfem_profile_begin", "plfem_profile_end",
     "plfem_mesh_edge_count", "plfem_mesh_refine",
     "plfem_residuals", "plfem_set_option", "plfem_symbolic_create_ex", "plfem_assemble_scalar", "plfem_cmt_coupling",
+    "plfem_solve_modes", "plfem_modes_dev",
 )
+SOLVE_STATS = ("nconv", "n_opinv", "restarts", "max_rel_res", "n_block_solves", "true_residual_first", "true_residual", "refined",
+               "pivot_perturbations", "assemble_us", "factor_us", "lanczos_us", "post_us", "upload_us", "residual_us", "call_us")
 # the test hooks (include/plfem.h under PLFEM_TEST_HOOKS): exported by the add-on libplfem_testhooks.so ONLY
 TEST_HOOK_EXPORTS = ("plfem_debug_factor_until", "plfem_debug_copy", "plfem_debug_solve_block", "plfem_debug_symeig",
                      "plfem_debug_symeig_band", "plfem_debug_set_perturb")
@@ -150,6 +153,10 @@ def load_library() -> ctypes.CDLL:
     lib.plfem_profile_end.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
     lib.plfem_residuals.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
     lib.plfem_set_option.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_double]
+    lib.plfem_solve_modes.argtypes = ([ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32] + [ctypes.c_double] * 5 +
+                                      [ctypes.c_int32, ctypes.c_int32, ctypes.c_double, ctypes.c_int32, ctypes.c_double,
+                                       ctypes.c_double] + [ctypes.c_void_p] * 6)
+    lib.plfem_modes_dev.argtypes = [ctypes.c_void_p, c_void_pp, ctypes.POINTER(ctypes.c_int32)]
     _lib = lib
     return lib
 
@@ -413,6 +420,44 @@ class Context:
             raise ArpackLikeNoConvergence(self._lib.plfem_last_error(self._h).decode(), evals, evecs)
         self._check(rc, "plfem_lanczos_shift_invert")
         return evals, evecs, st
+
+    def solve_modes(self, cores, eps_core, eps_clad, k0, alpha_p, sigma, k, ncv, tol, maxiter, residual_tol, tol_refined,
+                    modes_host=None):
+        """``plfem_solve_modes``: assembly, factorisation, eigen-solve, post-processing, a-posteriori check (with its
+        refined second pass) and the copy of the interior mode vectors into ``modes_host`` (a pinned torch tensor of
+        shape (k, dofs_per_node * nsolve), or None) in ONE call.  Returns ``(evals, post, frac_core, resid, stats)``."""
+        c, n = self._cores(cores)
+        evals = np.empty(k, dtype=np.float64)
+        post = np.zeros((k, len(POST_NAMES)), dtype=np.float64)
+        resid = np.zeros(k, dtype=np.float64)
+        stats = np.zeros(len(SOLVE_STATS), dtype=np.float64)
+        frac = ctypes.c_double(0.0)
+        if modes_host is not None and (tuple(modes_host.shape) != (k, self.dpn * self.sym.nsolve) or not modes_host.is_contiguous()
+                                       or modes_host.dtype != self.torch.float64 or modes_host.device.type != "cpu"):
+            raise ValueError("modes_host must be a contiguous float64 CPU tensor of shape (k, dofs_per_node * nsolve)")
+        rc = self._lib.plfem_solve_modes(self._h, _ptr(c), n, float(eps_core), float(eps_clad), float(k0), float(alpha_p),
+                                         float(sigma), int(k), int(ncv), float(tol), int(maxiter), float(residual_tol),
+                                         float(tol_refined), _ptr(evals), _ptr(post), ctypes.cast(ctypes.byref(frac), ctypes.c_void_p),
+                                         _ptr(resid), ctypes.c_void_p(modes_host.data_ptr()) if modes_host is not None else None,
+                                         _ptr(stats))
+        st = {name: (float(stats[i]) if name.endswith("_us") or "res" in name else int(stats[i])) for i, name in enumerate(SOLVE_STATS)}
+        st["refined"] = bool(st["refined"])
+        if rc == PLFEM_ENOCONV:
+            raise ArpackLikeNoConvergence(self._lib.plfem_last_error(self._h).decode(), evals, self.modes_dev())
+        self._check(rc, "plfem_solve_modes")
+        return evals, post, float(frac.value), resid, st
+
+    def modes_dev(self):
+        """The full-length vectors of the last eigen-solve as a torch tensor (a COPY of the context's own buffer, which
+        the next factorisation reuses)."""
+        ptr = ctypes.c_void_p()
+        k = ctypes.c_int32(0)
+        self._check(self._lib.plfem_modes_dev(self._h, ctypes.byref(ptr), ctypes.byref(k)), "plfem_modes_dev")
+
+        class _View:
+            __cuda_array_interface__ = {"shape": (int(k.value), int(self.n2)), "typestr": "<f8", "data": (int(ptr.value), True),
+                                        "version": 2, "strides": None}
+        return self.torch.as_tensor(_View(), device=self.tdev).clone()
 
     def postprocess(self, evecs, cores, want_interior: bool = True):
         k = evecs.shape[0]

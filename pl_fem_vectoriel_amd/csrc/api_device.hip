@@ -86,6 +86,32 @@ void events_give(int device, std::vector<hipEvent_t>& mine) {
 }  // namespace
 
 namespace {
+// Side streams for the device-to-host copy of the mode vectors (plfem_solve_modes), one pool per device ordinal: a
+// stream costs ~50 us to create and cold solves create a context each.
+std::mutex& stream_mutex() { static std::mutex* m = new std::mutex(); return *m; }
+std::vector<std::vector<hipStream_t>>& stream_pools() { static auto* v = new std::vector<std::vector<hipStream_t>>(); return *v; }
+hipError_t copy_stream_acquire(int device, hipStream_t* out) {
+  {
+    std::lock_guard<std::mutex> lk(stream_mutex());
+    auto& pools = stream_pools();
+    if ((int)pools.size() <= device) pools.resize(device + 1);
+    if (!pools[device].empty()) {
+      *out = pools[device].back();
+      pools[device].pop_back();
+      return hipSuccess;
+    }
+  }
+  return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
+}
+void copy_stream_release(int device, hipStream_t s) {
+  std::lock_guard<std::mutex> lk(stream_mutex());
+  auto& pools = stream_pools();
+  if ((int)pools.size() <= device) pools.resize(device + 1);
+  pools[device].push_back(s);
+}
+}  // namespace
+
+namespace {
 
 // Every device buffer of a context is carved out of ONE slab (caller-provided, e.g. a torch tensor
 // recycled by its caching allocator, or hipMalloc'ed once here).  Pass 0 (c->slab == nullptr) only
@@ -161,6 +187,12 @@ void free_all(plfem_ctx* c) {
   for (auto& e : c->ev_step)
     if (e) (void)hipEventDestroy(e);
   if (!c->prof_ev.empty()) events_give(c->device, c->prof_ev);
+  if (c->copy_stream) {
+    (void)hipStreamSynchronize(c->copy_stream);
+    copy_stream_release(c->device, c->copy_stream);
+    c->copy_stream = nullptr;
+  }
+  if (c->ev_copy) (void)hipEventDestroy(c->ev_copy);
 }
 
 static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
@@ -173,31 +205,24 @@ int create_impl(plfem_ctx* c, const plfem_symbolic* sym, int device, void* strea
   c->stream = (hipStream_t)stream;   // NULL = the device's default (null) stream
   if (!size_only) {
     HIP_TRY(c, hipSetDevice(device));
-    for (int q = 0; q < 5; ++q)
+    for (int q = 0; q < 6; ++q)
       for (int r = 0; r < 2; ++r) HIP_TRY(c, hipEventCreate(&c->ev[q][r]));
     for (int r = 0; r < 2; ++r) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_step[r], hipEventDisableTiming));
     HIP_TRY(c, hipEventRecord(c->ev[4][0], c->stream));
   }
   c->nv = S.nv; c->ne = S.ne; c->N = S.N; c->nnz = S.rowptr.empty() ? 0 : (int)S.rowptr[S.N]; c->nsolve = S.nsolve;
   c->L = S.L; c->nfronts = S.nfronts; c->dpn = S.dpn; c->sh = S.dpn - 1; c->n2 = S.dpn * (int64_t)S.N; c->max_ncv = max_ncv;
-  // per-front DOF counts + level table
-  std::vector<int32_t> fs2(S.nfronts), fm(S.nfronts);
-  for (int f = 0; f < S.nfronts; ++f) { fs2[f] = S.dpn * S.fs[f]; fm[f] = S.dpn * (S.fs[f] + S.fb[f]); }
-  c->levels.assign(S.L + 1, LevelInfo());
-  for (int lev = 0; lev <= S.L; ++lev) {
-    LevelInfo& li = c->levels[lev];
-    li.first = (1 << lev) - 1;
-    li.count = 1 << lev;
-    for (int f = li.first; f < li.first + li.count; ++f) {
-      li.max_m = std::max(li.max_m, fm[f]);
-      li.max_s2 = std::max(li.max_s2, fs2[f]);
-      li.max_b2 = std::max(li.max_b2, fm[f] - fs2[f]);
-      // one sweep over a front reads the s2 (s2 + 1) / 2 + s2 b2 entries of [L11^-1 ; Z] once, stages s2 (forward)
-      // or m (backward) vector entries and writes m (forward) or s2 (backward)
-      li.sweep_bytes += 8.0 * ((double)fs2[f] * fm[f] - 0.5 * (double)fs2[f] * fs2[f] + fm[f] + fs2[f]);
-      li.sweep_vec_doubles += fm[f] + fs2[f];
-    }
-  }
+  // The launch plan (kernel forms by level, launch order, workgroup lists) depends on the mesh only: it is part of the
+  // analysis (plan.cpp, built at the end of build_symbolic) and every context on that analysis uploads the same one.
+  const plfem::LaunchPlan& P = S.plan;
+  if (!P.built) { c->err = "plfem_create: the analysis carries no launch plan"; return PLFEM_ESTATE; }
+  c->levels = P.levels;
+  c->forder_s2 = P.forder_s2;
+  c->forder_maxm = P.forder_maxm;
+  c->upd_off = P.upd_off;
+  c->upd_n.assign(P.upd_n.begin(), P.upd_n.end());
+  c->formz_all_off = P.formz_all_off; c->formz_all_n = P.formz_all_n;
+  c->mirrorx_all_off = P.mirrorx_all_off; c->mirrorx_all_n = P.mirrorx_all_n;
   // The solve sweeps stage one front's right-hand sides in LDS: 8 P (max_m + 1) bytes dynamic + the static
   // partial-sum buffer of the tile kernels (P x 4 KB backward, 8 waves).  Beyond the device limit the launch would
   // fail as an opaque "invalid argument" much later, so decide here: P = BLOCK_P, else P = 1, else a clear error.
@@ -205,9 +230,8 @@ int create_impl(plfem_ctx* c, const plfem_symbolic* sym, int device, void* strea
     int lim = 0;
     HIP_TRY(c, hipDeviceGetAttribute(&lim, hipDeviceAttributeMaxSharedMemoryPerBlock, device));
     c->lds_limit = lim;
-    int worst = 0;
-    for (const LevelInfo& li : c->levels) worst = std::max(worst, li.max_m);
-    auto need = [&](int P) { return (int64_t)sizeof(double) * P * (worst + 1) + (int64_t)sizeof(double) * 8 * P * 64; };
+    const int worst = P.worst_m;
+    auto need = [&](int Pn) { return (int64_t)sizeof(double) * Pn * (worst + 1) + (int64_t)sizeof(double) * 8 * Pn * 64; };
     if (need(plfem::BLOCK_P) <= lim) c->max_block_p = plfem::BLOCK_P;
     else if (need(1) <= lim) c->max_block_p = 1;
     else {
@@ -218,154 +242,6 @@ int create_impl(plfem_ctx* c, const plfem_symbolic* sym, int device, void* strea
   }
   const bool ctx_trace = getenv("PLFEM_CTX_TRACE") != nullptr;
   const double tt0 = now_ms();
-  // Launch order of the fronts of a level: decreasing s2 (counting sort on s2 / 16, stable).  The fronts still
-  // active at a block step of the factorisation are then a prefix, and in every batched launch the long fronts
-  // start first.  blk: compact launch lists of the sweep kernels, (front, row block) per useful workgroup.
-  std::vector<int32_t> forder(S.nfronts);
-  c->forder_s2.assign(S.nfronts, 0);
-  c->forder_maxm.assign(S.nfronts, 0);
-  std::vector<int2> blk;
-  const int mix_big_s2 = getenv("PLFEM_MIX_BIG_S2") ? atoi(getenv("PLFEM_MIX_BIG_S2")) : plfem::MIX_BIG_S2;   // (tuning aid)
-  {
-    std::vector<int32_t> bucket;
-    for (int lev = 0; lev <= S.L; ++lev) {
-      LevelInfo& li = c->levels[lev];
-      int32_t* o = forder.data() + li.first;
-      const int nb = li.max_s2 / 16 + 2;
-      bucket.assign(nb, 0);
-      for (int f = li.first; f < li.first + li.count; ++f) bucket[nb - 2 - fs2[f] / 16 + 1]++;
-      for (int b = 1; b < nb; ++b) bucket[b] += bucket[b - 1];
-      for (int f = li.first; f < li.first + li.count; ++f) o[bucket[nb - 2 - fs2[f] / 16]++] = f;
-      int mx = 0;
-      for (int q = 0; q < li.count; ++q) {
-        mx = std::max(mx, fm[o[q]]);
-        c->forder_s2[li.first + q] = fs2[o[q]];
-        c->forder_maxm[li.first + q] = mx;
-      }
-      li.fwd_rows = plfem::fwd_block_rows(li.count);
-      li.bwd_rows = plfem::bwd_block_rows(li.count, lev == S.L);
-      li.fwd_off = (int64_t)blk.size();
-      for (int q = 0; q < li.count; ++q) {
-        const int f = o[q];
-        if (li.fwd_rows == 64 && fs2[f] > mix_big_s2) {      // long front of a tile-form level: row-form workgroups
-          li.fwd_mixed = true;
-          for (int t = 0; t * 16 < fm[f]; ++t) blk.push_back(make_int2(f, t | plfem::SWEEP_ROW_JOB_FLAG));
-        }
-        else
-          for (int t = 0; t * li.fwd_rows < fm[f]; ++t) blk.push_back(make_int2(f, t));
-      }
-      li.fwd_n = (int)(blk.size() - li.fwd_off);
-      li.bwd_off = (int64_t)blk.size();
-      // (a non-leaf front without owned DOFs still gets one workgroup: it republishes its boundary values for its children)
-      for (int q = 0; q < li.count; ++q) {
-        const int f = o[q];
-        const int rows = std::max(fs2[f], lev < S.L ? 1 : 0);
-        for (int t = 0; t * li.bwd_rows < rows; ++t) blk.push_back(make_int2(f, t));
-      }
-      li.bwd_n = (int)(blk.size() - li.bwd_off);
-    }
-  }
-  std::vector<plfem::SweepJob> jobs(size_only ? 0 : blk.size());
-  for (size_t q = 0; q < jobs.size(); ++q) {
-    const int f = blk[q].x;
-    jobs[q] = plfem::SweepJob{f, blk[q].y, fm[f], fs2[f], S.fnode_ptr[f], f > 0 ? S.fnode_ptr[(f - 1) >> 1] : 0, S.foff[f], 0};
-  }
-  if (size_only) jobs.resize(blk.size());                // (only the size matters)
-  std::vector<plfem::FrontRec> frec(S.nfronts);          // the fronts in launch order, with their parameters
-  if (!size_only)
-    for (int q = 0; q < S.nfronts; ++q) {
-      const int f = forder[q];
-      frec[q] = plfem::FrontRec{f, fm[f], fs2[f], 0, S.foff[f], S.fnode_ptr[f]};
-    }
-  // 64 x 64 tile lists of the factorisation kernels: only workgroups with work are launched (a dense
-  // (tiles of the largest front)^2 x fronts grid is 85-90 % empty workgroups, which cost ~3 ns each)
-  std::vector<int2> tiles;
-  c->upd_off.clear();
-  c->upd_n.clear();
-  {
-    auto cdiv = [](int a, int b) { return (a + b - 1) / b; };
-    // pass 0 counts (also all the size-only call needs), pass 1 fills
-    int64_t ntiles = 0;
-    for (int pass = 0; pass < (size_only ? 1 : 2); ++pass) {
-      int2* out = nullptr;
-      if (pass == 1) {
-        tiles.resize((size_t)ntiles);
-        out = tiles.data();
-        c->upd_off.clear();
-        c->upd_n.clear();
-      }
-      int64_t pos = 0;
-      auto rect = [&](int f, int ntx, int nty) {         // ntx x nty blocks of front f, x fastest
-        if (out)
-          for (int ty = 0; ty < nty; ++ty)
-            for (int tx = 0; tx < ntx; ++tx) out[pos++] = make_int2(f, tx | (ty << 16));
-        else
-          pos += (int64_t)ntx * nty;
-      };
-      auto lower = [&](int f, int nt) {                  // blocks tx >= ty of an nt x nt square (symmetric trailing matrix)
-        if (out)
-          for (int ty = 0; ty < nt; ++ty)
-            for (int tx = ty; tx < nt; ++tx) out[pos++] = make_int2(f, tx | (ty << 16));
-        else
-          pos += (int64_t)nt * (nt + 1) / 2;
-      };
-      auto block_rows = [&](int f) {                     // (f, kb) for the block rows kb >= 1 of F11, last (longest) first
-        for (int kb = cdiv(fs2[f], plfem::NB) - 1; kb >= 1; --kb) {
-          if (out) out[pos] = make_int2(f, kb);
-          ++pos;
-        }
-      };
-      for (int lev = 0; lev <= S.L; ++lev) {
-        LevelInfo& li = c->levels[lev];
-        const int32_t* o = forder.data() + li.first;
-        li.gather_off = pos;
-        if (lev < S.L)
-          for (int q = 0; q < li.count; ++q) lower(o[q], cdiv(fm[o[q]], 64));   // nothing reads the blocks above the diagonal
-        li.gather_n = (int)(pos - li.gather_off);
-        li.step0 = (int)c->upd_n.size();
-        const int steps = (li.max_s2 + plfem::NB - 1) / plfem::NB;
-        for (int kb = 0; kb < steps; ++kb) {
-          const int k0 = kb * plfem::NB;
-          c->upd_off.push_back(pos);
-          for (int q = 0; q < li.count && fs2[o[q]] > k0; ++q) {     // active fronts: a prefix of the order
-            const int f = o[q];
-            const int t0 = k0 + std::min(plfem::NB, fs2[f] - k0);
-            const int nt = cdiv(fm[f] - t0, 64);
-            // even step of a front that has a next one: nothing (the columns of its next pivot block are the column
-            // workgroups' job, the rest waits for the rank-64 pass of the odd step: k_ldl_update)
-            if (!((kb & 1) == 0 && t0 < fs2[f])) lower(f, nt);
-          }
-          c->upd_n.push_back((int)(pos - c->upd_off.back()));
-        }
-        li.formz_off = pos;
-        for (int q = 0; q < li.count; ++q) rect(o[q], cdiv(fm[o[q]] - fs2[o[q]], 64), cdiv(fs2[o[q]], 64));
-        li.formz_n = (int)(pos - li.formz_off);
-        li.mirrorx_off = pos;
-        for (int q = 0; q < li.count; ++q) block_rows(o[q]);
-        li.mirrorx_n = (int)(pos - li.mirrorx_off);
-      }
-      // the same Z blocks once more as ONE list over all levels, root first: nothing in the factorisation reads Z, so
-      // a complete run forms it for every front in a single launch at the end (the per-level lists above serve
-      // plfem_debug_factor_until, which stops after a given level)
-      c->formz_all_off = pos;
-      for (int lev = 0; lev <= S.L; ++lev) {
-        const LevelInfo& li = c->levels[lev];
-        const int32_t* o = forder.data() + li.first;
-        for (int q = 0; q < li.count; ++q) rect(o[q], cdiv(fm[o[q]] - fs2[o[q]], 64), cdiv(fs2[o[q]], 64));
-      }
-      c->formz_all_n = (int)(pos - c->formz_all_off);
-      // block rows >= 1 of every F11 (k_mirror_x), largest first within a level
-      c->mirrorx_all_off = pos;
-      for (int lev = 0; lev <= S.L; ++lev) {
-        const LevelInfo& li = c->levels[lev];
-        const int32_t* o = forder.data() + li.first;
-        for (int q = 0; q < li.count; ++q) block_rows(o[q]);
-      }
-      c->mirrorx_all_n = (int)(pos - c->mirrorx_all_off);
-      ntiles = pos;
-    }
-    if (size_only) tiles.resize((size_t)ntiles);          // only its size matters to the placement pass
-  }
   const double tt1 = now_ms();
   std::vector<UploadItem> items;
   size_t upload_span = 0;
@@ -373,10 +249,10 @@ int create_impl(plfem_ctx* c, const plfem_symbolic* sym, int device, void* strea
   c->slab_off = 0;
   items.clear();
   TRY(upload(c, items, &c->d_tsorted, S.tsorted));
-  TRY(upload(c, items, &c->d_blk, jobs));
-  TRY(upload(c, items, &c->d_tiles, tiles));
-  TRY(upload(c, items, &c->d_forder, forder));
-  TRY(upload(c, items, &c->d_frec, frec));
+  TRY(upload(c, items, &c->d_blk, P.jobs));
+  TRY(upload(c, items, reinterpret_cast<plfem::Tile**>(&c->d_tiles), P.tiles));   // (Tile has int2's layout)
+  TRY(upload(c, items, &c->d_forder, P.forder));
+  TRY(upload(c, items, &c->d_frec, P.frec));
   TRY(upload(c, items, &c->d_edof, S.edof));
   TRY(upload(c, items, &c->d_rowptr, S.rowptr));
   TRY(upload(c, items, &c->d_nptr, S.nptr));
@@ -385,8 +261,8 @@ int create_impl(plfem_ctx* c, const plfem_symbolic* sym, int device, void* strea
   TRY(upload(c, items, &c->d_interior, S.interior));
   TRY(upload(c, items, &c->d_bmask, S.bmask));
   TRY(upload(c, items, &c->d_doflocs, S.doflocs));
-  TRY(upload(c, items, &c->d_fs2, fs2));
-  TRY(upload(c, items, &c->d_fm, fm));
+  TRY(upload(c, items, &c->d_fs2, P.fs2));
+  TRY(upload(c, items, &c->d_fm, P.fm));
   TRY(upload(c, items, &c->d_fnode_ptr, S.fnode_ptr));
   TRY(upload(c, items, &c->d_foff, S.foff));
   TRY(upload(c, items, &c->d_soff, S.soff));
@@ -409,13 +285,7 @@ int create_impl(plfem_ctx* c, const plfem_symbolic* sym, int device, void* strea
   c->arena_doubles = (S.arena_doubles + 31) & ~(int64_t)31;
   TRY(dalloc(c, &c->d_fvec, (size_t)2 * fnodes_total * plfem::BLOCK_P));
   c->fnodes_total = fnodes_total;
-  // panel / block-row scratch of the factorisation: one tree level is in flight at a time, so these are sized by the
-  // level with the most (padded) nodes and addressed relative to the level's first front (launch_factor)
-  int64_t level_nodes = 0;
-  for (int lev = 0; lev <= S.L; ++lev) {
-    const int first = (1 << lev) - 1, last = std::min(S.nfronts, (1 << (lev + 1)) - 1);
-    level_nodes = std::max(level_nodes, S.fnode_ptr[last] - S.fnode_ptr[first]);
-  }
+  const int64_t level_nodes = P.level_nodes_max;   // (largest tree level: the panel scratch holds one level at a time)
   c->level_nodes_max = level_nodes;
   // What only the factorisation needs (Schur arenas, panels) and what only the Lanczos drivers need (the bases V, B V and
   // their restart copies) are never alive at the same time -- a context factorises, then iterates, on one stream -- and
@@ -455,7 +325,8 @@ int create_impl(plfem_ctx* c, const plfem_symbolic* sym, int device, void* strea
   TRY(dalloc(c, &c->d_Hcols, (nc1 + 1) * (nc1 + 1)));
   TRY(dalloc(c, &c->d_coremask, (size_t)S.N));
   const size_t post_blocks = (size_t)(S.N + 255) / 256;
-  TRY(dalloc(c, &c->d_post, nc1 * post_blocks * 5 + nc1 * 5 + 16));
+  c->post_doubles = nc1 * post_blocks * 5 + nc1 * 5 + 16;
+  TRY(dalloc(c, &c->d_post, 2 * c->post_doubles));   // (second half: the residual check, in flight beside the post-processing)
   return PLFEM_OK;
   };
   TRY(place());                      // pass 0: measure
@@ -957,11 +828,14 @@ static int lanczos_block(plfem_ctx* c, int k, int ncv, double tol, int maxiter, 
     std::memcpy(hH + (size_t)q * mm, &Svec[(size_t)want[q] * mm], sizeof(double) * mm);
   }
   HIP_TRY(c, hipMemcpyAsync(c->d_S, hH, sizeof(double) * mm * k, hipMemcpyHostToDevice, st));
+  if (!evecs_dev) evecs_dev = c->d_V2;            // (idle since the last restart, if any)
+  c->modes_dev = evecs_dev;
+  c->modes_k = k;
   plfem::launch_rotate(c, c->d_V, mm, c->d_S, mm, k, evecs_dev);
   HIP_TRY(c, hipEventRecord(c->ev[2][1], st));
   c->ev_used[2] = true;
   TRY(check_launch(c, "ritz rotation"));
-  HIP_TRY(c, hipStreamSynchronize(st));
+  if (!c->defer_sync) HIP_TRY(c, hipStreamSynchronize(st));   // (plfem_solve_modes: its one synchronisation comes later)
   if (stats_host) {
     stats_host[0] = nconv;
     stats_host[1] = nop;
@@ -979,9 +853,20 @@ static int lanczos_block(plfem_ctx* c, int k, int ncv, double tol, int maxiter, 
 // ------------------------------------------------------------------------------------------------
 // thick-restart Lanczos, shift-invert, B inner product
 // ------------------------------------------------------------------------------------------------
+// evecs_dev == nullptr: the vectors go into the context's own buffer (the idle restart double buffer d_V2; see
+// plfem_solve_modes / plfem_modes_dev)
+static int lanczos_run(plfem_ctx* c, int32_t k, int32_t ncv, double tol, int32_t maxiter,
+                       double sigma, double* evals_host, double* evecs_dev, double* stats_host);
+
 extern "C" int plfem_lanczos_shift_invert(plfem_ctx* c, int32_t k, int32_t ncv, double tol, int32_t maxiter,
                                           double sigma, double* evals_host, double* evecs_dev, double* stats_host) {
   if (!c || !evals_host || !evecs_dev) return PLFEM_EINVAL;
+  return lanczos_run(c, k, ncv, tol, maxiter, sigma, evals_host, evecs_dev, stats_host);
+}
+
+static int lanczos_run(plfem_ctx* c, int32_t k, int32_t ncv, double tol, int32_t maxiter,
+                       double sigma, double* evals_host, double* evecs_dev, double* stats_host) {
+  if (!c || !evals_host) return PLFEM_EINVAL;
   if (!c->factored || c->sigma != sigma) { c->err = "plfem_lanczos_shift_invert: call plfem_factor(sigma) first"; return PLFEM_ESTATE; }
   const int64_t n = c->n2;
   if (k < 1 || ncv <= k || ncv > c->max_ncv || ncv > c->dpn * c->nsolve) { c->err = "need 1 <= k < ncv <= max_ncv"; return PLFEM_EINVAL; }
@@ -1103,16 +988,20 @@ extern "C" int plfem_lanczos_shift_invert(plfem_ctx* c, int32_t k, int32_t ncv, 
     std::memcpy(hH + (size_t)q * m, &Svec[(size_t)want[q] * m], sizeof(double) * m);
   }
   HIP_TRY(c, hipMemcpyAsync(c->d_S, hH, sizeof(double) * m * k, hipMemcpyHostToDevice, st));
+  if (!evecs_dev) evecs_dev = c->d_V2;
+  c->modes_dev = evecs_dev;
+  c->modes_k = k;
   plfem::launch_rotate(c, c->d_V, m, c->d_S, m, k, evecs_dev);
   HIP_TRY(c, hipEventRecord(c->ev[2][1], st));
   c->ev_used[2] = true;
   TRY(check_launch(c, "ritz rotation"));
-  HIP_TRY(c, hipStreamSynchronize(st));
+  if (!c->defer_sync) HIP_TRY(c, hipStreamSynchronize(st));
   if (stats_host) {
     stats_host[0] = nconv;
     stats_host[1] = nop;
     stats_host[2] = restarts;
     stats_host[3] = max_rel_res;
+    stats_host[4] = 0;
   }
   if (!done) {
     c->err = "Lanczos: no convergence within maxiter restarts";
@@ -1136,6 +1025,108 @@ extern "C" int plfem_postprocess(plfem_ctx* c, int32_t k, double* evecs_dev, con
   return PLFEM_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// One call for the whole numeric solve (include/plfem.h): assembly, factorisation, eigen-solve, post-processing, the
+// a-posteriori check (with its refined second pass) and the copy of the interior mode vectors to the host, enqueued back
+// to back.  Behind the Lanczos run (which synchronises with its own step events) the host waits ONCE.
+// ------------------------------------------------------------------------------------------------
+extern "C" int plfem_solve_modes(plfem_ctx* c, const double* cores_host, int32_t ncore, double eps_core, double eps_clad,
+                                 double k0, double alpha_p, double sigma, int32_t k, int32_t ncv, double tol,
+                                 int32_t maxiter, double residual_tol, double tol_refined, double* evals_host,
+                                 double* post_host, double* frac_core_host, double* resid_host, double* modes_int_host,
+                                 double* stats_host) {
+  if (!c || !evals_host || !post_host || !resid_host) return PLFEM_EINVAL;
+  if (k < 1 || k > c->max_ncv) { c->err = "plfem_solve_modes: need 1 <= k <= max_ncv"; return PLFEM_EINVAL; }
+  const double th0 = now_ms();
+  HIP_TRY(c, hipSetDevice(c->device));
+  if (!c->copy_stream) HIP_TRY(c, copy_stream_acquire(c->device, &c->copy_stream));
+  if (!c->ev_copy) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_copy, hipEventDisableTiming));
+  struct Defer {                                   // the Lanczos drivers leave their final synchronisation to this call
+    plfem_ctx* c;
+    int saved_refine;
+    ~Defer() { c->defer_sync = false; c->refine_steps = saved_refine; }
+  } defer{c, c->refine_steps};
+  c->defer_sync = true;
+  if (c->dpn == 2) TRY(plfem_assemble_hfield(c, cores_host, ncore, eps_core, eps_clad, k0, alpha_p));
+  else TRY(plfem_assemble_scalar(c, cores_host, ncore, eps_core, eps_clad, k0));
+  TRY(plfem_factor(c, sigma));
+  double st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  double first_res = 0.0, res = 0.0;
+  int perturbed = 0, refined = 0;
+  double n_opinv = 0, n_block = 0, restarts = 0;
+  const size_t modes_bytes = sizeof(double) * (size_t)k * c->dpn * c->nsolve;
+  for (int pass = 0; pass < 2; ++pass) {
+    // second pass: refinement inside the operator (repairs an inaccurate factor) AND a tighter Ritz tolerance (repairs a
+    // first pass that merely stopped too early: a residual above the bound with no perturbed pivot)
+    c->refine_steps = pass == 0 ? defer.saved_refine : std::max(1, defer.saved_refine + 1);
+    const double tol_p = pass == 0 ? tol : std::min(tol, tol_refined);
+    const int rc = lanczos_run(c, k, ncv, tol_p, maxiter, sigma, evals_host, nullptr, st);
+    n_opinv += st[1]; n_block += st[4]; restarts += st[2];
+    if (rc != PLFEM_OK) {
+      (void)hipStreamSynchronize(c->stream);       // (PLFEM_ENOCONV: evals_host / plfem_modes_dev hold the current Ritz pairs)
+      if (stats_host) { stats_host[0] = st[0]; stats_host[1] = n_opinv; stats_host[2] = restarts; stats_host[3] = st[3]; stats_host[4] = n_block; }
+      return rc;
+    }
+    double* modes = c->modes_dev;
+    double* modes_int = c->d_BV2 != modes ? c->d_BV2 : c->d_BV;   // (a restart swaps the double buffers: take the idle one)
+    HIP_TRY(c, hipEventRecord(c->ev[3][0], c->stream));
+    plfem::post_enqueue(c, k, modes, ncore, modes_int_host ? modes_int : nullptr);
+    HIP_TRY(c, hipEventRecord(c->ev[3][1], c->stream));
+    c->ev_used[3] = true;
+    if (modes_int_host) {
+      // the copy of the mode vectors (~30 MB at C1) leaves on its own stream while the check below occupies this one
+      HIP_TRY(c, hipEventRecord(c->ev_copy, c->stream));
+      HIP_TRY(c, hipStreamWaitEvent(c->copy_stream, c->ev_copy, 0));
+      HIP_TRY(c, hipMemcpyAsync(modes_int_host, modes_int, modes_bytes, hipMemcpyDeviceToHost, c->copy_stream));
+    }
+    HIP_TRY(c, hipEventRecord(c->ev[5][0], c->stream));
+    plfem::resid_enqueue(c, k, evals_host, modes);
+    HIP_TRY(c, hipEventRecord(c->ev[5][1], c->stream));
+    c->ev_used[5] = true;
+    TRY(check_launch(c, "post-processing + residual check"));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));   // THE synchronisation of the call
+    plfem::post_finish(c, k, post_host, frac_core_host);
+    plfem::resid_finish(c, k, resid_host);
+    perturbed = reinterpret_cast<const int32_t*>(c->h_pinned + 4096)[0];
+    res = 0.0;
+    for (int i = 0; i < k; ++i) res = (resid_host[i] > res || !(resid_host[i] == resid_host[i])) ? resid_host[i] : res;
+    if (pass == 0) first_res = res;
+    if (res <= residual_tol && perturbed == 0) break;
+    if (modes_int_host) HIP_TRY(c, hipStreamSynchronize(c->copy_stream));   // (the vectors on their way: let them land, then redo)
+    if (pass == 1) {
+      if (res <= residual_tol) break;              // (perturbed pivots, repaired by the refinement)
+      char msg[512];
+      std::snprintf(msg, sizeof(msg), "eigen-residual %.2e after the refined re-run (first pass %.2e, bound %.0e); %s", res, first_res,
+                    residual_tol, perturbed > 0 ? "vanishing pivots were perturbed: the shift-invert factorisation is inaccurate on this mesh"
+                                                : "no pivot was perturbed: the eigenpairs did not converge tightly enough");
+      c->err = msg;
+      if (stats_host) { stats_host[5] = first_res; stats_host[6] = res; stats_host[7] = 1; stats_host[8] = perturbed; }
+      return PLFEM_ERESIDUAL;
+    }
+    refined = 1;
+  }
+  if (modes_int_host) HIP_TRY(c, hipStreamSynchronize(c->copy_stream));
+  if (stats_host) {
+    stats_host[0] = st[0]; stats_host[1] = n_opinv; stats_host[2] = restarts; stats_host[3] = st[3]; stats_host[4] = n_block;
+    stats_host[5] = first_res; stats_host[6] = res; stats_host[7] = refined; stats_host[8] = perturbed;
+    const int slot[6] = {0, 1, 2, 3, 4, 5};         // assemble, factor, lanczos, post, upload, residual check
+    for (int q = 0; q < 6; ++q) {
+      float ms = 0;
+      stats_host[9 + q] = (c->ev_used[slot[q]] && hipEventElapsedTime(&ms, c->ev[slot[q]][0], c->ev[slot[q]][1]) == hipSuccess) ? ms * 1e3 : 0.0;
+    }
+    stats_host[15] = (now_ms() - th0) * 1e3;
+  }
+  return PLFEM_OK;
+}
+
+extern "C" int plfem_modes_dev(plfem_ctx* c, const double** evecs_dev, int32_t* k) {
+  if (!c || !evecs_dev) return PLFEM_EINVAL;
+  if (!c->modes_dev) { c->err = "plfem_modes_dev: no eigen-solve has run on this context"; return PLFEM_ESTATE; }
+  *evecs_dev = c->modes_dev;
+  if (k) *k = c->modes_k;
+  return PLFEM_OK;
+}
+
 extern "C" int plfem_timings(plfem_ctx* c, double* out_host) {
   if (!c || !out_host) return PLFEM_EINVAL;
   HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -1147,6 +1138,10 @@ extern "C" int plfem_timings(plfem_ctx* c, double* out_host) {
   }
   for (int i = 0; i < 8; ++i) out_host[i] = c->timings[i];
   out_host[5] = cnt[0];
+  {
+    float ms = 0;
+    if (c->ev_used[5] && hipEventElapsedTime(&ms, c->ev[5][0], c->ev[5][1]) == hipSuccess) out_host[6] = ms * 1e3;
+  }
   return PLFEM_OK;
 }
 

@@ -8,61 +8,7 @@
 
 #include "../../include/plfem.h"
 #include "internal.h"
-
-namespace plfem {
-
-constexpr int NB = 32;          // pivot-block width of the block LDL^T
-constexpr int PANEL_CHUNK = 1024; // rows per partial sum of the tall-skinny panel products
-// sweep kernel forms by level (launch_solve_p and the launch lists must agree)
-constexpr int ROW_FORM_MAX_FRONTS = 32;   // levels with at most this many fronts use the row-form kernels in both sweeps
-// 8 / 16: pure row form with that many rows per workgroup; 64: tile form (backward: leaf level only; forward: mixed
-// launch -- tiles of 64 rows, row-form workgroups of 16 rows for the fronts with more than MIX_BIG_S2 owned DOFs)
-constexpr int MIX_BIG_S2 = 192;
-constexpr int SWEEP_ROW_JOB_FLAG = 1 << 30;
-// One workgroup of a sweep kernel: the front, its row block and everything the workgroup would otherwise look up by
-// front number (one dependent memory round trip less in front of every launch of a latency-bound level)
-struct alignas(16) SweepJob {
-  int32_t f, rb;          // front, row block (| SWEEP_ROW_JOB_FLAG in the mixed forward kernel)
-  int32_t m, s2;          // order of the front, owned DOFs
-  int64_t np, npp;        // fnode_ptr of the front and of its parent
-  int64_t foff;           // offset of the front in d_front
-  int64_t reserved;
-};
-static_assert(sizeof(SweepJob) == 48, "SweepJob layout");
-// A front as the factorisation's chain workgroups (first panel, column workgroups) see it, in launch order (d_forder)
-struct alignas(16) FrontRec {
-  int32_t f, m, s2, reserved;
-  int64_t foff, np;       // offset in d_front, fnode_ptr
-};
-static_assert(sizeof(FrontRec) == 32, "FrontRec layout");
-inline int fwd_block_rows(int count) { return count <= 8 ? 8 : count <= ROW_FORM_MAX_FRONTS ? 16 : 64; }
-// (round 3 re-measured the tile form at the two levels above the leaves: 28.1 / 25.5 us against 22.3 / 21.5 us in row form)
-inline int bwd_block_rows(int count, bool leaf) { return leaf ? 64 : count <= ROW_FORM_MAX_FRONTS ? 8 : 16; }
-constexpr int BLOCK_P = 4;      // right-hand sides per block solve / block Lanczos step
-constexpr int ELEM_FORMS = 8;   // Axx Axy Ayx Ayy Minv Dxx Dxy Dyy
-constexpr int ELEM_STRIDE = ELEM_FORMS * 36;
-
-struct LevelInfo {
-  int first = 0;    // first front id of the level (heap order)
-  int count = 0;
-  int max_m = 0;    // DOFs
-  int max_s2 = 0;
-  int max_b2 = 0;
-  // compact launch lists of the sweep kernels (d_blk): one entry per useful workgroup = (front, row block),
-  // fronts in order of decreasing work so that the long ones start first
-  // factorisation: 64 x 64 tile lists (d_tiles) of the extend-add, of Z, and (per block step: upd_off / upd_n of
-  // the context, index step0 + kb) of the trailing updates
-  int64_t gather_off = 0, formz_off = 0, mirrorx_off = 0;
-  int gather_n = 0, formz_n = 0, mirrorx_n = 0, step0 = 0;
-  int fwd_rows = 0, bwd_rows = 0;      // rows per workgroup of the forward / backward kernel of this level
-  bool fwd_mixed = false;              // tile-form level with at least one long front (row-form workgroups in the same launch)
-  int64_t fwd_off = 0, bwd_off = 0;    // first entry in d_blk
-  int fwd_n = 0, bwd_n = 0;            // entries = workgroups
-  double sweep_bytes = 0;   // algorithmic bytes one forward (or backward) sweep launch of this level moves (1 rhs)
-  double sweep_vec_doubles = 0;   // vector doubles (staged + written) per rhs of that launch
-};
-
-}  // namespace plfem
+#include "plan.h"
 
 struct plfem_ctx {
   const plfem::Symbolic* S = nullptr;
@@ -125,7 +71,8 @@ struct plfem_ctx {
   double *d_h = nullptr, *d_hacc = nullptr, *d_partial = nullptr, *d_scal = nullptr, *d_S = nullptr;
   double* d_Hcols = nullptr;      // (max_ncv+1) x (max_ncv+1) projected matrix columns
   uint8_t* d_coremask = nullptr;  // [N]
-  double* d_post = nullptr;       // post-processing partial sums
+  double* d_post = nullptr;       // partial sums: post-processing in [0, post_doubles), residual check behind it
+  size_t post_doubles = 0;
   int npartial = 0;
   double* h_pinned = nullptr;     // pinned staging
   size_t h_pinned_bytes = 0;      // size of that block (it returns to a process-wide cache)
@@ -139,6 +86,9 @@ struct plfem_ctx {
   // state
   bool assembled = false, factored = false;
   hipEvent_t ev_step[2] = {nullptr, nullptr};   // block Lanczos: completion of the two block steps in flight
+  bool defer_sync = false;        // plfem_solve_modes: the Lanczos drivers leave their final stream synchronisation to it
+  hipStream_t copy_stream = nullptr;   // plfem_solve_modes: side stream of the device-to-host copy of the mode vectors
+  hipEvent_t ev_copy = nullptr;        // "mode vectors ready" (main stream -> copy stream)
   // live kernel timing (plfem_profile_*): event pairs around every tile-form forward-sweep launch
   bool prof_on = false;
   unsigned prof_toggle = 0;       // block solves alternate between timing whole sweeps and timing single launches
@@ -157,8 +107,10 @@ struct plfem_ctx {
   int max_block_p = plfem::BLOCK_P;   // right-hand sides per sweep the LDS budget allows (BLOCK_P or 1)
   int lds_limit = 0;              // bytes of LDS one workgroup may use on this device
   double sigma = 0.0, k0 = 0.0;
-  hipEvent_t ev[5][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
-  bool ev_used[5] = {false, false, false, false, false};
+  hipEvent_t ev[6][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
+  bool ev_used[6] = {false, false, false, false, false, false};   // assemble, factor, lanczos, post, upload, residual check
+  double* modes_dev = nullptr;    // where the last eigen-solve left its vectors (caller's buffer or the context's own)
+  int modes_k = 0;
   double timings[8] = {0};
 };
 
@@ -223,5 +175,10 @@ void launch_block_scale(plfem_ctx* c, const double* W, const double* BW, int64_t
                         int32_t* cnt_dst = nullptr, double* bv_front = nullptr);
 void launch_start_field(plfem_ctx* c, int nvec, double* out);
 void launch_post(plfem_ctx* c, int k, double* evecs, int ncore, double* out_host, double* frac_core, double* modes_int);
+// the same in two halves (plfem_solve_modes: one stream synchronisation for everything behind the Lanczos run)
+void post_enqueue(plfem_ctx* c, int k, double* evecs, int ncore, double* modes_int);
+void post_finish(plfem_ctx* c, int k, double* out_host, double* frac_core);
+void resid_enqueue(plfem_ctx* c, int k, const double* lam_host, const double* evecs);
+void resid_finish(plfem_ctx* c, int k, double* out_host);
 
 }  // namespace plfem

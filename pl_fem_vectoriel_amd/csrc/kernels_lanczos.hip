@@ -556,15 +556,20 @@ __global__ __launch_bounds__(64) void k_resid_finish(int nblocks, const double* 
 
 }  // namespace
 
-void launch_residuals(plfem_ctx* c, int k, const double* lam_host, const double* evecs, double* out_host) {
+// pinned scratch of the two result read-backs (doubles from h_pinned): post-processing sums [0, 5 k), residual check
+// lambda up [2048, 2048 + k) and sums down [2048 + k, 2048 + 3 k) -- disjoint, so that both can be in flight together
+constexpr int RESID_HS = 2048;
+
+// enqueue only: the k residual sums end up in pinned memory once the stream has drained (resid_finish)
+void resid_enqueue(plfem_ctx* c, int k, const double* lam_host, const double* evecs) {
   hipStream_t st = c->stream;
   const int N = c->N;
   const int nblocks = (N + POST_ROWS - 1) / POST_ROWS;
-  double* hs = c->h_pinned;                          // [0, k): lambda up, [k, 3k): sums down
+  double* hs = c->h_pinned + RESID_HS;
   for (int i = 0; i < k; ++i) hs[i] = lam_host[i];
   (void)hipMemcpyAsync(c->d_hacc, hs, sizeof(double) * k, hipMemcpyHostToDevice, st);
-  double* partial = c->d_post;                       // [k][nblocks][2]
-  double* sums = c->d_post + (int64_t)k * nblocks * 2;
+  double* partial = c->d_post + c->post_doubles;     // second half of d_post: [k][nblocks][2], then the sums
+  double* sums = partial + (int64_t)k * nblocks * 2;
   if (c->dpn == 1)
     hipLaunchKernelGGL(k_resid_sums<1>, dim3(nblocks, (k + POST_MB - 1) / POST_MB), dim3(256), 0, st, N, k, nblocks, c->d_rowptr, c->d_colind, c->d_bmask,
                        c->d_vals[PLFEM_BLK_AXX], c->d_vals[PLFEM_BLK_AXY], c->d_vals[PLFEM_BLK_AYX], c->d_vals[PLFEM_BLK_AYY],
@@ -575,11 +580,21 @@ void launch_residuals(plfem_ctx* c, int k, const double* lam_host, const double*
                        c->d_vals[PLFEM_BLK_MINV], c->d_hacc, evecs, partial);
   hipLaunchKernelGGL(k_resid_finish, dim3(2 * k), dim3(64), 0, st, nblocks, partial, sums);
   (void)hipMemcpyAsync(hs + k, sums, sizeof(double) * 2 * k, hipMemcpyDeviceToHost, st);
-  (void)hipStreamSynchronize(st);
+}
+
+// after the stream has been synchronised
+void resid_finish(plfem_ctx* c, int k, double* out_host) {
+  const double* hs = c->h_pinned + RESID_HS;
   for (int i = 0; i < k; ++i) {
     const double r2 = hs[k + 2 * i], a2 = hs[k + 2 * i + 1];
     out_host[i] = a2 > 0.0 ? std::sqrt(r2 / a2) : (r2 > 0.0 ? INFINITY : 0.0);
   }
+}
+
+void launch_residuals(plfem_ctx* c, int k, const double* lam_host, const double* evecs, double* out_host) {
+  resid_enqueue(c, k, lam_host, evecs);
+  (void)hipStreamSynchronize(c->stream);
+  resid_finish(c, k, out_host);
 }
 
 void launch_axpby_n(plfem_ctx* c, int64_t n, double a, const double* x, double b, const double* y, double* z) {
@@ -704,8 +719,7 @@ void launch_rotate(plfem_ctx* c, const double* V, int m, const double* Smat, int
   }
 }
 
-void launch_post(plfem_ctx* c, int k, double* evecs, int ncore, double* out_host, double* frac_core,
-                 double* modes_int) {
+void post_enqueue(plfem_ctx* c, int k, double* evecs, int ncore, double* modes_int) {
   hipStream_t st = c->stream;
   const int N = c->N;
   (void)hipMemsetAsync(c->d_counters + 1, 0, sizeof(int32_t), st);
@@ -732,7 +746,12 @@ void launch_post(plfem_ctx* c, int k, double* evecs, int ncore, double* out_host
   (void)hipMemcpyAsync(hs, sums, sizeof(double) * k * 5, hipMemcpyDeviceToHost, st);
   int32_t* hc = reinterpret_cast<int32_t*>(c->h_pinned + 4096);
   (void)hipMemcpyAsync(hc, c->d_counters, sizeof(int32_t) * 4, hipMemcpyDeviceToHost, st);
-  (void)hipStreamSynchronize(st);
+}
+
+// after the stream has been synchronised
+void post_finish(plfem_ctx* c, int k, double* out_host, double* frac_core) {
+  const double* hs = c->h_pinned;
+  const int32_t* hc = reinterpret_cast<const int32_t*>(c->h_pinned + 4096);
   for (int mode = 0; mode < k; ++mode) {
     const double* s = hs + mode * 5;
     double nrm2 = c->dpn == 2 ? s[0] + s[1] : s[4];      // scalar solver: M-norm (solver_fem.py:268)
@@ -747,6 +766,13 @@ void launch_post(plfem_ctx* c, int k, double* evecs, int ncore, double* out_host
     o[PLFEM_POST_ALL_Y] = s[1] * inv2;
   }
   if (frac_core) *frac_core = (double)hc[1] / (double)c->nsolve;
+}
+
+void launch_post(plfem_ctx* c, int k, double* evecs, int ncore, double* out_host, double* frac_core,
+                 double* modes_int) {
+  post_enqueue(c, k, evecs, ncore, modes_int);
+  (void)hipStreamSynchronize(c->stream);
+  post_finish(c, k, out_host, frac_core);
 }
 
 }  // namespace plfem

@@ -9,7 +9,10 @@
 #include <memory>
 #include <numeric>
 #include <atomic>
+#include <condition_variable>
+#include <mutex>
 #include <thread>
+#include <pthread.h>
 
 namespace plfem {
 namespace {
@@ -27,69 +30,239 @@ inline void cpu_relax(int spins) {
   else std::this_thread::yield();
 }
 
-// Small spin-waiting worker pool, alive for the duration of one build_symbolic() call: the parallel
-// regions of the analysis are ~0.1-3 ms each, far too short to pay a thread creation per region.
+// Type-erased reference to a callable void(int rank) that outlives the call (fork-join: the caller waits).
+struct FnRef {
+  void (*call)(void*, int) = nullptr;
+  void* obj = nullptr;
+};
+template <class F>
+FnRef fn_ref(F& f) {
+  return FnRef{[](void* o, int r) { (*static_cast<F*>(o))(r); }, &f};
+}
+
+// Worker pool of one analysis.  The parallel regions of the analysis are 0.05-1 ms each, so
+//   * the workers live across analyses (a process-wide cache of idle pools: creating and joining 15 threads cost
+//     0.3-0.5 ms per analysis), parked on a condition variable between analyses and spin-waiting inside one;
+//   * every worker has its own mailbox, so DISJOINT thread ranges ("teams") work independently: a team's leader
+//     (its first thread) hands a job to the members [first + 1, first + count) and joins them, or splits the team in
+//     two (fork2: the second half's first thread becomes a leader of its own).  That is what lets the numbering chain
+//     run on a few threads beside the bisection tree, and sibling subdomains of the top tree levels be bisected at
+//     the same time, each by its share of the threads, instead of one after the other by all of them.
+// Thread 0 of a pool is the caller of build_symbolic.
 struct Pool {
-  int nt;
+  struct alignas(128) Slot {
+    std::atomic<uint32_t> seq{0};       // bumped by the dispatcher when a job is posted
+    std::atomic<uint32_t> ack{0};       // = seq once the job is done
+    FnRef fn;
+    int rank = 0, team_first = 0, team_count = 1;
+  };
+  const int nt;
+  std::unique_ptr<Slot[]> slots;
   std::vector<std::thread> th;
-  std::atomic<int> gen{0}, done{0};
-  std::atomic<bool> stop{false};
-  std::function<void(int)> job;
-  explicit Pool(int n) : nt(n) {
-    for (int t = 1; t < nt; ++t)
-      th.emplace_back([this, t] {
-        int seen = 0;
-        while (true) {
-          for (int spins = 0; gen.load(std::memory_order_acquire) == seen; ++spins) {
-            if (stop.load(std::memory_order_acquire)) return;
-            cpu_relax(spins);
-          }
-          seen = gen.load(std::memory_order_acquire);
-          job(t);
-          done.fetch_add(1, std::memory_order_release);
-        }
-      });
-  }
-  void run(const std::function<void(int)>& f) {
-    job = f;
-    done.store(0, std::memory_order_release);
-    gen.fetch_add(1, std::memory_order_release);
-    f(0);
-    for (int spins = 0; done.load(std::memory_order_acquire) < nt - 1; ++spins) cpu_relax(spins);
-  }
+  std::mutex mu;
+  std::condition_variable cv;
+  std::atomic<bool> active{false}, stop{false}, failed{false};
+  std::exception_ptr error;              // first exception thrown inside a worker's job (rethrown by the leader's join)
+  explicit Pool(int n);
   ~Pool() {
-    stop.store(true, std::memory_order_release);
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      stop.store(true, std::memory_order_release);
+    }
+    cv.notify_all();
     for (auto& x : th) x.join();
   }
+  void begin() {                         // wake the workers (they spin from here on)
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      active.store(true, std::memory_order_release);
+    }
+    cv.notify_all();
+  }
+  void end() { active.store(false, std::memory_order_release); }   // the workers park after a few hundred idle spins
+  void rethrow() {                       // leader side, after a join
+    if (!failed.load(std::memory_order_acquire)) return;
+    std::exception_ptr e;
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      e = error;
+      error = nullptr;
+      failed.store(false, std::memory_order_release);
+    }
+    if (e) std::rethrow_exception(e);
+  }
+  void post(int thread, FnRef fn, int rank, int team_first, int team_count) {
+    Slot& s = slots[thread];
+    s.fn = fn; s.rank = rank; s.team_first = team_first; s.team_count = team_count;
+    s.seq.store(s.seq.load(std::memory_order_relaxed) + 1, std::memory_order_release);
+  }
+  void join(int thread) {
+    Slot& s = slots[thread];
+    const uint32_t want = s.seq.load(std::memory_order_relaxed);
+    for (int spins = 0; s.ack.load(std::memory_order_acquire) != want; ++spins) cpu_relax(spins);
+  }
 };
-thread_local Pool* g_pool = nullptr;
 
-// run f(begin, end, tid) over [0, n) in static chunks on the pool of the current build (if any)
+// the team the current thread leads (count = 1: no members, everything it starts runs serially)
+struct TeamCtx {
+  Pool* pool = nullptr;
+  int first = 0, count = 1;
+};
+thread_local TeamCtx g_team;
+inline int team_size() { return g_team.pool ? g_team.count : 1; }
+struct TeamScope {                       // sets the calling thread's team for a scope
+  TeamCtx saved;
+  TeamScope(Pool* p, int first, int count) : saved(g_team) { g_team = TeamCtx{p, first, count}; }
+  ~TeamScope() { g_team = saved; }
+};
+
+Pool::Pool(int n) : nt(n), slots(new Slot[n]) {
+  for (int t = 1; t < nt; ++t)
+    th.emplace_back([this, t] {
+      Slot& s = slots[t];
+      uint32_t seen = 0;
+      while (true) {
+        for (int spins = 0; s.seq.load(std::memory_order_acquire) == seen; ++spins) {
+          if (!active.load(std::memory_order_acquire) && spins > 256) {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return active.load(std::memory_order_acquire) || stop.load(std::memory_order_acquire); });
+            if (stop.load(std::memory_order_acquire)) return;
+            spins = 0;
+            continue;
+          }
+          if (stop.load(std::memory_order_acquire)) return;
+          cpu_relax(spins);
+        }
+        seen = s.seq.load(std::memory_order_acquire);
+        try {
+          TeamScope scope(this, s.team_first, s.team_count);
+          s.fn.call(s.fn.obj, s.rank);
+        } catch (...) {                  // (an exception must not leave a thread body)
+          std::lock_guard<std::mutex> lk(mu);
+          if (!error) error = std::current_exception();
+          failed.store(true, std::memory_order_release);
+        }
+        s.ack.store(seen, std::memory_order_release);
+      }
+    });
+}
+
+// Process-wide cache of idle pools (a sweep prepares several analyses at once, each on its own pool).  The pools are
+// destroyed by an atexit handler; a forked child starts with an empty cache (its parent's worker threads do not exist
+// in it).
+struct PoolCache {
+  std::mutex mu;
+  std::vector<Pool*> idle;
+  bool registered = false;
+};
+PoolCache& pool_cache() { static PoolCache* c = new PoolCache(); return *c; }
+void pool_cache_shutdown() {
+  PoolCache& c = pool_cache();
+  std::vector<Pool*> all;
+  {
+    std::lock_guard<std::mutex> lk(c.mu);
+    all.swap(c.idle);
+  }
+  for (Pool* p : all) delete p;
+}
+void pool_cache_forked() {                // (child side of fork: no locks held by design: only forget the pools)
+  PoolCache& c = pool_cache();
+  new (&c.mu) std::mutex();
+  for (Pool*& p : c.idle) p = nullptr;    // leaked on purpose: their threads are gone
+  c.idle.clear();
+}
+Pool* pool_acquire(int nthreads) {
+  PoolCache& c = pool_cache();
+  {
+    std::lock_guard<std::mutex> lk(c.mu);
+    if (!c.registered) {
+      c.registered = true;
+      std::atexit(pool_cache_shutdown);
+      pthread_atfork(nullptr, nullptr, pool_cache_forked);
+    }
+    for (size_t q = 0; q < c.idle.size(); ++q)
+      if (c.idle[q]->nt == nthreads) {
+        Pool* p = c.idle[q];
+        c.idle.erase(c.idle.begin() + q);
+        return p;
+      }
+  }
+  return new Pool(nthreads);
+}
+void pool_release(Pool* p) {
+  PoolCache& c = pool_cache();
+  {
+    std::lock_guard<std::mutex> lk(c.mu);
+    if (c.idle.size() < 8) { c.idle.push_back(p); return; }
+  }
+  delete p;
+}
+
+// f(rank) on every thread of the current team, the caller as rank 0.  Inside the job a thread leads a team of one.
+template <class F>
+void team_run(F&& f) {
+  const TeamCtx T = g_team;
+  if (!T.pool || T.count <= 1) { f(0); return; }
+  auto body = [&](int rank) { f(rank); };
+  FnRef ref = fn_ref(body);
+  for (int r = 1; r < T.count; ++r) T.pool->post(T.first + r, ref, r, T.first + r, 1);
+  struct Join {                          // the members reference this frame: join them on every way out
+    const TeamCtx& T;
+    ~Join() { for (int r = 1; r < T.count; ++r) T.pool->join(T.first + r); }
+  };
+  {
+    Join join{T};
+    TeamScope alone(T.pool, T.first, 1);
+    f(0);
+  }
+  T.pool->rethrow();
+}
+
+// fa() on the first count_a threads of the current team, fb() on the rest, side by side; each half is a team of its own
+template <class FA, class FB>
+void team_fork2(int count_a, FA&& fa, FB&& fb) {
+  const TeamCtx T = g_team;
+  if (!T.pool || T.count <= 1 || count_a <= 0 || count_a >= T.count) { fa(); fb(); return; }
+  auto body = [&](int) { fb(); };
+  FnRef ref = fn_ref(body);
+  const int mid = T.first + count_a;
+  T.pool->post(mid, ref, 0, mid, T.count - count_a);
+  struct Join {
+    Pool* pool; int mid;
+    ~Join() { pool->join(mid); }
+  };
+  {
+    Join join{T.pool, mid};
+    TeamScope half(T.pool, T.first, count_a);
+    fa();
+  }
+  T.pool->rethrow();
+}
+
+// run f(begin, end, rank) over [0, n) in static chunks on the current team
 template <class F>
 void parallel_for(int64_t n, int nthreads, F f, int64_t min_parallel = 4096) {
-  Pool* pool = g_pool;
-  if (nthreads <= 1 || n < min_parallel || !pool) {
+  const int nt = team_size();
+  if (nthreads <= 1 || n < min_parallel || nt <= 1) {
     f((int64_t)0, n, 0);
     return;
   }
-  const int nt = pool->nt;
   const int64_t chunk = (n + nt - 1) / nt;
-  pool->run([&](int tdx) {
-    int64_t b = tdx * chunk, e = std::min(n, b + chunk);
-    if (b < e) f(b, e, tdx);
+  team_run([&](int rank) {
+    int64_t b = rank * chunk, e = std::min(n, b + chunk);
+    if (b < e) f(b, e, rank);
   });
 }
 
 // run f(task) for task in [0, ntasks), tasks handed out one at a time (uneven task sizes)
 template <class F>
 void parallel_tasks(int ntasks, int nthreads, F f) {
-  Pool* pool = g_pool;
-  if (nthreads <= 1 || ntasks <= 1 || !pool) {
+  if (nthreads <= 1 || ntasks <= 1 || team_size() <= 1) {
     for (int q = 0; q < ntasks; ++q) f(q);
     return;
   }
   std::atomic<int> next{0};
-  pool->run([&](int) {
+  team_run([&](int) {
     for (int q = next.fetch_add(1, std::memory_order_relaxed); q < ntasks; q = next.fetch_add(1, std::memory_order_relaxed)) f(q);
   });
 }
@@ -122,7 +295,7 @@ std::string p2_sort_columns(int nv, int ne, const int32_t* t, Symbolic& S) {
   int32_t* t1 = t0 + ne;
   int32_t* t2 = t1 + ne;
   std::atomic<int> bad_t{0};
-  parallel_for(ne, g_pool ? g_pool->nt : 1, [&](int64_t eb_, int64_t ee_, int) {
+  parallel_for(ne, team_size(), [&](int64_t eb_, int64_t ee_, int) {
     for (int64_t e = eb_; e < ee_; ++e) {
       int32_t a = t[e], b = t[ne + e], c = t[2 * (size_t)ne + e];
       if (a < 0 || b < 0 || c < 0 || a >= nv || b >= nv || c >= nv) { bad_t.store(1); continue; }
@@ -163,7 +336,7 @@ std::string p2_edges_and_dofs(int nv, int ne, const double* p, Symbolic& S) {
   // (two passes so that the per-vertex work runs on the worker pool: sort + count, prefix, write)
   std::vector<int32_t> eoff((size_t)nv + 1, 0);
   std::atomic<int> bad{0};
-  const int nth = g_pool ? g_pool->nt : 1;
+  const int nth = team_size();
   parallel_for(nv, nth, [&](int64_t vb, int64_t ve, int) {
     for (int64_t v = vb; v < ve; ++v) {
       int32_t* b = nb.data() + cnt[v];
@@ -251,7 +424,7 @@ std::string p2_edges_and_dofs(int nv, int ne, const double* p, Symbolic& S) {
   // interior list / inverse map: per-chunk counts, prefix, fill
   S.int_index.resize(N);
   {
-    const int nt = nth > 1 && N >= 4096 && g_pool ? g_pool->nt : 1;
+    const int nt = nth > 1 && N >= 4096 ? team_size() : 1;
     const int64_t chunk = ((int64_t)N + nt - 1) / nt;
     std::vector<int32_t> cnt((size_t)nt + 1, 0);
     parallel_for(N, nt, [&](int64_t b, int64_t e_, int tid) {
@@ -275,8 +448,12 @@ std::string p2_edges_and_dofs(int nv, int ne, const double* p, Symbolic& S) {
   return "";
 }
 
-// node -> adjacent elements (CSR), elements ascending within each node.  Every thread scans the whole
-// element table but only files the nodes of its own range: sequential reads, no shared counters.
+// node -> adjacent elements (CSR), elements ascending within each node.  Counting sort by node on the team: degrees by
+// relaxed atomic increments, a serial prefix sum, the (element, local index) pairs dropped through atomic cursors in
+// whatever order the threads arrive, then every node's short list (a vertex of the lantern meshes has ~6 elements, an
+// edge node 1 or 2) sorted by element id -- so the result does not depend on the thread count.  (Round 3: every thread
+// scanned the whole element table and filed the nodes of its own range -- no atomics, but O(6 ne) per THREAD: 0.8 ms at
+// C1 however many threads.)
 void node_to_elem(Symbolic& S, int nthreads) {
   const int N = S.N, ne = S.ne;
   std::vector<int32_t>& ptr = S.nptr;
@@ -286,25 +463,35 @@ void node_to_elem(Symbolic& S, int nthreads) {
   adj.resize((size_t)6 * ne);
   loc.resize((size_t)6 * ne);
   const int32_t* d = S.edof.data();
-  parallel_for(N, nthreads, [&](int64_t b, int64_t e_, int) {
-    for (size_t q = 0; q < (size_t)6 * ne; ++q) {
-      const int32_t i = d[q];
-      if (i >= b && i < e_) ptr[i + 1]++;
-    }
-  }, 8192);
+  int32_t* deg = ptr.data() + 1;
+  parallel_for((int64_t)6 * ne, nthreads, [&](int64_t b, int64_t e_, int) {
+    for (int64_t q = b; q < e_; ++q) __atomic_fetch_add(&deg[d[q]], 1, __ATOMIC_RELAXED);
+  }, 16384);
   for (int i = 0; i < N; ++i) ptr[i + 1] += ptr[i];
-  parallel_for(N, nthreads, [&](int64_t b, int64_t e_, int) {
-    std::vector<int32_t> fill(ptr.begin() + b, ptr.begin() + e_);
-    for (int e = 0; e < ne; ++e)
+  std::vector<int32_t> cursor(ptr.begin(), ptr.end() - 1);
+  rawvec_i32 packed((size_t)6 * ne);                 // element << 3 | local index (ne < 2^28: checked by the caller)
+  parallel_for(ne, nthreads, [&](int64_t b, int64_t e_, int) {
+    for (int64_t e = b; e < e_; ++e)
       for (int a = 0; a < 6; ++a) {
         const int32_t i = d[(size_t)a * ne + e];
-        if (i >= b && i < e_) {
-          int32_t& f = fill[i - b];
-          adj[f] = e;
-          loc[f] = (uint8_t)a;
-          ++f;
-        }
+        packed[__atomic_fetch_add(&cursor[i], 1, __ATOMIC_RELAXED)] = (int32_t)(e << 3) | a;
       }
+  }, 4096);
+  parallel_for(N, nthreads, [&](int64_t b, int64_t e_, int) {
+    for (int64_t i = b; i < e_; ++i) {
+      int32_t* lo = packed.data() + ptr[i];
+      const int n = ptr[i + 1] - ptr[i];
+      for (int q = 1; q < n; ++q) {                  // insertion sort: the lists are short and nearly sorted
+        const int32_t v = lo[q];
+        int r = q;
+        for (; r > 0 && lo[r - 1] > v; --r) lo[r] = lo[r - 1];
+        lo[r] = v;
+      }
+      for (int q = 0; q < n; ++q) {
+        adj[ptr[i] + q] = lo[q] >> 3;
+        loc[ptr[i] + q] = (uint8_t)(lo[q] & 7);
+      }
+    }
   }, 8192);
 }
 
@@ -321,12 +508,9 @@ void csr_rowptr(Symbolic& S, int nthreads) {
   const int N = S.N, nv = S.nv, nedges = S.nedges;
   std::vector<int32_t> inc((size_t)nv, 0);                  // edges incident to each vertex
   const int32_t* ea = S.edges.data();
-  parallel_for(nv, nthreads, [&](int64_t b, int64_t e_, int) {
-    for (size_t q = 0; q < (size_t)2 * nedges; ++q) {
-      const int32_t v = ea[q];
-      if (v >= b && v < e_) inc[v]++;
-    }
-  }, 8192);
+  parallel_for((int64_t)2 * nedges, nthreads, [&](int64_t b, int64_t e_, int) {
+    for (int64_t q = b; q < e_; ++q) __atomic_fetch_add(&inc[ea[q]], 1, __ATOMIC_RELAXED);
+  }, 16384);
   S.rowptr.assign((size_t)N + 1, 0);
   for (int i = 0; i < N; ++i) {
     const int d = S.nptr[i + 1] - S.nptr[i];
@@ -404,7 +588,7 @@ void nd_tree(Symbolic& S, const double* p, int leaf_elems, int nthreads) {
   const double* Y = p + S.nv;
   Box root_box;
   {
-    const int nt0 = (nthreads > 1 && g_pool) ? g_pool->nt : 1;
+    const int nt0 = nthreads > 1 ? team_size() : 1;
     std::vector<Box> tb(nt0);
     parallel_for(ne, nthreads, [&](int64_t b_, int64_t e_, int tid) {
       Box bx;
@@ -445,7 +629,7 @@ void nd_tree(Symbolic& S, const double* p, int leaf_elems, int nthreads) {
   // where there are fewer nodes than threads).  The result does not depend on par or on the thread count.
   auto bisect = [&](const ElemGeo* src, ElemGeo* dst, int lo, int hi, int level, bool par, const Box& box) -> Cut {
     const int n = hi - lo;
-    const int nt = (par && g_pool) ? g_pool->nt : 1;
+    const int nt = par ? team_size() : 1;
     std::vector<Hist> hs(nt);
     const ElemGeo* Gl = src + lo;
     ElemGeo* Dl = dst + lo;
@@ -613,27 +797,32 @@ void nd_tree(Symbolic& S, const double* p, int leaf_elems, int nthreads) {
     subtree(lo, c.mid, level + 1, 2 * idx, src ^ 1, c.left);
     subtree(c.mid, hi, level + 1, 2 * idx + 1, src ^ 1, c.right);
   };
-  // top of the tree breadth-first with pool-parallel passes, then one task per subtree
+  // Top of the tree: the passes over a subdomain run on the team that holds it, and after every bisection the team
+  // splits with it -- sibling subdomains are bisected SIDE BY SIDE, each by its share of the threads (one after the
+  // other by all threads, a top level of 2^l subdomains cost 2^l rounds of short synchronised passes: 1.2-1.5 ms of the
+  // analysis of C1 went into the four top levels).  Below `top` levels: one task per subtree, handed out dynamically
+  // over the whole team.  The result does not depend on the team sizes.
   struct Node { int lo, hi, idx; Box box; };
-  std::vector<Node> cur{{0, ne, 0, root_box}};
-  int level = 0;
-  if (nthreads > 1 && g_pool) {
-    int top = 0;
-    // ~2 subtrees per thread up to 8 threads, one per thread beyond (every extra top level is a round of short
-    // pool-parallel passes over small subdomains: synchronisation, not work); handed out dynamically
-    const int want = getenv("PLFEM_TREE_SUBTREES") ? atoi(getenv("PLFEM_TREE_SUBTREES")) : std::max(2 * std::min(nthreads, 8), nthreads);
+  int top = 0;
+  const int nteam = nthreads > 1 ? team_size() : 1;
+  if (nteam > 1) {
+    // ~2 subtrees per thread (uneven subtrees: dynamic hand-out evens them out)
+    const int want = getenv("PLFEM_TREE_SUBTREES") ? atoi(getenv("PLFEM_TREE_SUBTREES")) : 2 * nteam;
     while ((1 << top) < want) ++top;
-    for (; level < std::min(top, L); ++level) {
-      std::vector<Node> next;
-      next.reserve(2 * cur.size());
-      for (const Node& nd : cur) {
-        const Cut c = bisect(buf[level & 1], buf[(level & 1) ^ 1], nd.lo, nd.hi, level, nd.hi - nd.lo >= 4096, nd.box);
-        next.push_back({nd.lo, c.mid, 2 * nd.idx, c.left});
-        next.push_back({c.mid, nd.hi, 2 * nd.idx + 1, c.right});
-      }
-      cur.swap(next);
-    }
+    top = std::min(top, L);
   }
+  std::vector<Node> cur((size_t)1 << top);
+  std::function<void(const Node&, int)> descend = [&](const Node& nd, int lev) {
+    if (lev == top) { cur[nd.idx] = nd; return; }
+    const Cut c = bisect(buf[lev & 1], buf[(lev & 1) ^ 1], nd.lo, nd.hi, lev, team_size() > 1 && nd.hi - nd.lo >= 4096, nd.box);
+    const Node l{nd.lo, c.mid, 2 * nd.idx, c.left}, r{c.mid, nd.hi, 2 * nd.idx + 1, c.right};
+    const int nt = team_size();
+    // threads in proportion to the halves' sizes (at least one each)
+    const int na = nt > 1 ? std::min(nt - 1, std::max(1, (int)(((int64_t)nt * (c.mid - nd.lo) + (nd.hi - nd.lo) / 2) / std::max(1, nd.hi - nd.lo)))) : 0;
+    team_fork2(na, [&] { descend(l, lev + 1); }, [&] { descend(r, lev + 1); });
+  };
+  descend(Node{0, ne, 0, root_box}, 0);
+  const int level = top;
   tr.lap("tree: top levels");
   const int src0 = level & 1;
   parallel_tasks((int)cur.size(), nthreads, [&](int q) { subtree(cur[q].lo, cur[q].hi, level, cur[q].idx, src0, cur[q].box); });
@@ -693,7 +882,7 @@ std::string build_fronts(Symbolic& S, int nthreads) {
     for (int lf = 0; lf < nleaf; ++lf) lb.off[lf + 1] = lb.off[lf] + 6 * (int64_t)(S.leaf_elem_ptr[lf + 1] - S.leaf_elem_ptr[lf]);
     lb.own.resize(lb.off[nleaf]);
     lb.bnd.resize(lb.off[nleaf]);
-    const int nt = (nthreads > 1 && g_pool && N >= 8192) ? g_pool->nt : 1;
+    const int nt = (nthreads > 1 && N >= 8192) ? team_size() : 1;
     // cnt[(t * nleaf + lf) * 2 + {0: own, 1: boundary}]: first counts, then start cursors of chunk t in leaf lf
     std::vector<int32_t> cnt((size_t)nt * nleaf * 2, 0);
     auto leaves_of = [&](int64_t i, int32_t* lfs) {      // distinct leaves of node i, in order of first appearance
@@ -838,6 +1027,9 @@ std::string build_fronts(Symbolic& S, int nthreads) {
     std::fill(dst + count, dst + padded, -1);
   };
   constexpr int FB = 32;                 // fronts per task
+  // beside the flattening, on one thread of the team: the launch plan of the device kernels (plan.cpp) -- it needs the
+  // front sizes and offsets computed above, not the lists being written here
+  auto flatten = [&] {
   parallel_tasks((nf + FB - 1) / FB, nthreads, [&](int task) {
     for (int f = task * FB; f < std::min(nf, (task + 1) * FB); ++f) {
       const int level = bitlen((uint32_t)f + 1) - 1;
@@ -874,7 +1066,9 @@ std::string build_fronts(Symbolic& S, int nthreads) {
       }
     }
   });
-  tr.lap("fronts: flatten");
+  };
+  team_fork2(team_size() - 1, flatten, [&] { build_launch_plan(S, S.plan); });
+  tr.lap("fronts: flatten + plan");
   return "";
 }
 
@@ -890,23 +1084,28 @@ std::string numbering_only(int nv, int ne, const double* p, const int32_t* t, Sy
 std::string build_symbolic(int nv, int ne, const double* p, const int32_t* t, int leaf_elems,
                            int nthreads, Symbolic& S, int dofs_per_node, bool dirichlet) {
   if (nv < 3 || ne < 1) return "empty mesh";
+  if ((int64_t)ne >= ((int64_t)1 << 28)) return "mesh too large: at most 2^28 - 1 elements (32-bit index structures)";
   if (dofs_per_node != 1 && dofs_per_node != 2) return "dofs_per_node must be 1 or 2";
   S.dpn = dofs_per_node;
   S.dirichlet = dirichlet;
   if (leaf_elems < 1) leaf_elems = 16;
   if (nthreads < 1) nthreads = 1;
-  std::unique_ptr<Pool> pool;
-  if (nthreads > 1) pool.reset(new Pool(nthreads));
-  g_pool = pool.get();
-  struct Reset { ~Reset() { g_pool = nullptr; } } reset_guard;
+  // the worker pool of this analysis (from the process-wide cache of idle pools) and the caller as leader of all of it
+  struct PoolLease {
+    Pool* pool = nullptr;
+    explicit PoolLease(int n) { if (n > 1) { pool = pool_acquire(n); pool->begin(); } }
+    ~PoolLease() { if (pool) { pool->end(); pool_release(pool); } }
+  } lease(nthreads);
+  TeamScope whole(lease.pool, 0, lease.pool ? nthreads : 1);
   auto t0 = clk::now();
   std::string err = p2_sort_columns(nv, ne, t, S);
   if (!err.empty()) return err;
   auto t1 = clk::now();
-  // Two chains that touch disjoint data run side by side: the bisection tree (reads the sorted element table and the
-  // caller's vertex coordinates) on the pool, and -- on one side thread, serially: these loops are short and gain
-  // little from the pool -- the P2 numbering (edges, element DOFs, DOF locations, boundary) followed by the node ->
-  // element adjacency and the CSR row pointers.  The fronts need both.
+  // Two chains that touch disjoint data run side by side, each on its own team of the pool: the bisection tree (reads the
+  // sorted element table and the caller's vertex coordinates) on three quarters of the threads, and the P2 numbering
+  // (edges, element DOFs, DOF locations, boundary) followed by the node -> element adjacency and the CSR row pointers
+  // on the rest.  (Round 3 ran the second chain serially on one extra thread: 3.3 ms beside a 2.1-ms tree on the MI355X
+  // host -- it was the critical path.)  The fronts need both.
   double t_num = 0.0, t_side = 0.0;
   std::string err_side;
   auto side = [&] {
@@ -916,20 +1115,18 @@ std::string build_symbolic(int nv, int ne, const double* p, const int32_t* t, in
       auto b = clk::now();
       t_num = secs(a, b);
       if (!err_side.empty()) return;
-      node_to_elem(S, 1);
-      csr_rowptr(S, 1);
+      node_to_elem(S, team_size());
+      csr_rowptr(S, team_size());
       t_side = secs(b, clk::now());
     } catch (const std::exception& e) {
       err_side = std::string("exception in the numbering chain: ") + e.what();
     }
   };
   static const bool chains_in_sequence = getenv("PLFEM_SYM_SEQUENTIAL") != nullptr;   // (A/B timing aid)
+  static const int side_share = getenv("PLFEM_SIDE_THREADS") ? atoi(getenv("PLFEM_SIDE_THREADS")) : 0;
   if (nthreads > 1 && !chains_in_sequence) {
-    struct Joined {                              // joins on every way out of the scope (an exception in the tree included)
-      std::thread th;
-      ~Joined() { if (th.joinable()) th.join(); }
-    } guard{std::thread(side)};
-    nd_tree(S, p, leaf_elems, nthreads);
+    const int n_side = std::min(nthreads - 1, std::max(1, side_share > 0 ? side_share : (nthreads + 1) / 3));
+    team_fork2(nthreads - n_side, [&] { nd_tree(S, p, leaf_elems, nthreads); }, side);
   } else {
     side();
     if (err_side.empty()) nd_tree(S, p, leaf_elems, nthreads);

@@ -14,6 +14,8 @@
 #include <string>
 #include <vector>
 
+#include "plan.h"
+
 namespace plfem {
 
 // std::vector whose resize() leaves the new elements uninitialised: the big index arrays of the front
@@ -82,6 +84,8 @@ struct Symbolic {
   int64_t solve_entries = 0;           // sum over fronts of s2 * (m + (m - s2)) matrix entries read per solve
   int max_m = 0;
   double t_numbering = 0, t_pattern = 0, t_tree = 0, t_fronts = 0;  // seconds
+  // ---- launch plan of the device kernels (plan.h): mesh-only, shared by every context on this analysis
+  LaunchPlan plan;
 };
 
 // p: [2][nv] (x row then y row), t: [3][ne].  leaf_elems: target elements per leaf front.

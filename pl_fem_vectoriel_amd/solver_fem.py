@@ -30,8 +30,6 @@ from .mesh import TriMesh, generate_mesh
 logger = logging.getLogger("pl_v18.solver_fem")   # same logger name as the reference (solver_fem.py:40)
 
 
-_COPY_STREAMS: Dict[int, "object"] = {}
-
 try:                                   # 64-bit content hash of the mesh arrays: 40 us for C1 with xxh3
     from xxhash import xxh3_64_intdigest as _digest
 except ImportError:                    # pragma: no cover  (zlib is ~10 x slower, still far below one analysis)
@@ -249,63 +247,34 @@ class TrueVectorialMaxwellSolver:
             raise ValueError("mesh too small for the requested number of modes")
         ncv = min(self._basis_size(n_req, 2 * sym.N), 2 * N_solve, ctx.max_ncv)
         cores = _core_table(g)
-        t0 = time.perf_counter()
-        self._assemble_device(ctx)
         sigma = shift_estimate(g)
-        ctx.factor(sigma)
+        import torch
+        # (k, 2 N_solve) on the host: the caller owns NumPy arrays, as in the reference.  They live in pinned memory
+        # from torch's caching host allocator, so a released mode list hands its 32 MB block to the next solve
+        # (no first-touch page faults, no munmap) and the copy runs at full PCIe rate.
+        t0 = time.perf_counter()
+        host = torch.empty((n_req, 2 * N_solve), dtype=torch.float64, pin_memory=True)
+        t_pinned = time.perf_counter() - t0
         if self.profile_kernel:
             ctx.profile_begin(4096)
         ctx.set_option("refine_steps", self.refine_steps)
-        evals, evecs, st = ctx.lanczos(n_req, ncv, self.eig_tol, self.MAXITER, sigma)
+        # ONE call into the library (plfem_solve_modes): assembly, factorisation, eigen-solve, post-processing, the
+        # a-posteriori guard and the copy of the mode vectors.  The guard: the LDL^T pivots statically and the Lanczos
+        # convergence test trusts K^-1, so every solve is checked against the ASSEMBLED pencil; a failed check (or a
+        # perturbed pivot) re-runs the eigen-solve with iterative refinement inside the operator and a tighter Ritz
+        # tolerance, and a second failure is an error (RuntimeError), never a silent result.
+        t0 = time.perf_counter()
+        evals, post, frac_core, resid, st = ctx.solve_modes(cores, g.n_core ** 2, g.n_clad ** 2, self.k0, self.ALPHA_P, sigma,
+                                                            n_req, ncv, self.eig_tol, self.MAXITER, self.RESIDUAL_TOL, 1e-10,
+                                                            modes_host=host)
+        t1 = time.perf_counter()
+        if st["refined"]:
+            logger.warning(f"eigenpairs failed the a-posteriori check (residual {st['true_residual_first']:.2e}, "
+                           f"{st['pivot_perturbations']} perturbed pivots): re-ran with refinement -> {st['true_residual']:.2e}")
         if self.profile_kernel:
             st = dict(st, kernel_profile=ctx.profile_end())
-        # Post-processing first, so that the copy of the mode vectors to the host (a DMA of ~30 MB on its own stream)
-        # runs WHILE the a-posteriori check below occupies the compute queue.
-        import torch
-        t_p0 = time.perf_counter()
-        post, frac_core, modes_int = ctx.postprocess(evecs, cores, want_interior=True)    # (synchronous)
-        # (k, 2 N_solve) to the host: the caller owns NumPy arrays, as in the reference.  They live in pinned memory
-        # from torch's caching host allocator, so a released mode list hands its 32 MB block to the next solve
-        # (no first-touch page faults, no munmap) and the copy runs at full PCIe rate.
-        host = torch.empty(modes_int.shape, dtype=torch.float64, pin_memory=True)
-        copy_stream = _copy_stream(ctx.device)
-        with torch.cuda.stream(copy_stream):
-            host.copy_(modes_int, non_blocking=True)
-        # A-posteriori guard: the LDL^T pivots statically and the Lanczos convergence test trusts K^-1, so every
-        # solve is checked against the ASSEMBLED pencil (the check is scale-invariant: the normalisation above does
-        # not matter); a failed check (or a perturbed pivot) re-runs the eigen-solve with iterative refinement inside
-        # the operator, and a second failure is an error, never a silent result.
-        t_r0 = time.perf_counter()
-        true_res = float(ctx.residuals(evals, evecs).max())
-        perturbed = ctx.timings()["pivot_perturbations"]
-        st = dict(st, true_residual=true_res, true_residual_first=true_res, refined=False,
-                  t_residual_check=time.perf_counter() - t_r0, t_eigen=t_p0 - t0)
-        if not (true_res <= self.RESIDUAL_TOL) or perturbed > 0:
-            logger.warning(f"eigenpairs failed the a-posteriori check (residual {true_res:.2e}, "
-                           f"{perturbed} perturbed pivots): re-running with refinement")
-            copy_stream.synchronize()                 # the first pass's vectors are on their way: let them land, then redo
-            # second pass: refinement inside the operator (repairs an inaccurate factor) AND a tighter Ritz tolerance
-            # (repairs a first pass that merely stopped too early: a residual above the bound with no perturbed pivot)
-            ctx.set_option("refine_steps", max(1, self.refine_steps + 1))
-            try:
-                evals, evecs, st2 = ctx.lanczos(n_req, ncv, min(self.eig_tol, 1e-10), self.MAXITER, sigma)
-            finally:
-                ctx.set_option("refine_steps", self.refine_steps)
-            res2 = float(ctx.residuals(evals, evecs).max())
-            st = dict(st, **st2, true_residual=res2, refined=True)
-            if not (res2 <= self.RESIDUAL_TOL):
-                why = (f"{perturbed} vanishing pivots were perturbed: the shift-invert factorisation is inaccurate on this mesh"
-                       if perturbed > 0 else "no pivot was perturbed: the eigenpairs did not converge tightly enough")
-                raise RuntimeError(f"eigen-residual {res2:.2e} after the refined re-run (first pass {true_res:.2e}, bound "
-                                   f"{self.RESIDUAL_TOL:.0e}); {why}")
-            post, frac_core, modes_int = ctx.postprocess(evecs, cores, want_interior=True)
-            with torch.cuda.stream(copy_stream):
-                host.copy_(modes_int, non_blocking=True)
-        t1 = time.perf_counter()
-        copy_stream.synchronize()
         vecs = host.numpy()
-        t2 = time.perf_counter()
-        timings = ctx.timings()
+        st = dict(st, t_pinned=t_pinned, t_call=t1 - t0)
         if not self.reuse_symbolic:
             # nothing will reuse the analysis or the context: release them now, so the device workspace goes back
             # to the allocator before the next solve asks for one
@@ -341,8 +310,7 @@ class TrueVectorialMaxwellSolver:
         self.last_stats = dict(st, sigma=sigma, n_req=n_req, ncv=ncv, N=sym.N, N_solve=N_solve, n=2 * N_solve,
                                beta_sq=np.array(evals, dtype=np.float64),
                                t_symbolic=ent.get("t_symbolic", 0.0), t_context=ent.get("t_context", 0.0),
-                               t_workspace=ent.get("t_workspace", 0.0),
-                               t_device=t1 - t0, t_copy_out=t2 - t1, frac_core=frac_core, **timings)
+                               t_workspace=ent.get("t_workspace", 0.0), frac_core=frac_core)
         if not modes_raw:
             self.last_stats["t_total"] = time.perf_counter() - t_start
             return []       # the reference would raise on np.median([]) (solver_fem.py:229); SURVEY.md §5
@@ -425,28 +393,17 @@ class ScalarHelmholtzSolver:
             ent["ctx"] = _native.Context(sym, self.device, max_ncv=max(ncv, 65))
         ctx = ent["ctx"]
         cores = _core_table(g)
-        ctx.assemble_scalar(cores, g.n_core ** 2, g.n_clad ** 2, self.k0)
         sigma = float(-(self.k0 * (g.n_core - 0.008)) ** 2)                  # solver_fem.py:260
-        ctx.factor(sigma)
-        evals, evecs, st = ctx.lanczos(n_req, ncv, self.eig_tol, self.MAXITER, sigma)
-        true_res = float(ctx.residuals(evals, evecs).max())
-        st = dict(st, true_residual=true_res, true_residual_first=true_res, refined=False)
-        if not (true_res <= self.RESIDUAL_TOL) or ctx.timings()["pivot_perturbations"] > 0:
-            logger.warning(f"scalar eigenpairs failed the a-posteriori check (residual {true_res:.2e}): re-running with refinement")
-            perturbed = ctx.timings()["pivot_perturbations"]
-            ctx.set_option("refine_steps", 1)
-            try:
-                evals, evecs, st2 = ctx.lanczos(n_req, ncv, min(self.eig_tol, 1e-12), self.MAXITER, sigma)
-            finally:
-                ctx.set_option("refine_steps", 0)
-            res2 = float(ctx.residuals(evals, evecs).max())
-            st = dict(st, **st2, true_residual=res2, refined=True)
-            if not (res2 <= self.RESIDUAL_TOL):
-                why = (f"{perturbed} vanishing pivots were perturbed: the shift-invert factorisation is inaccurate on this mesh"
-                       if perturbed > 0 else "no pivot was perturbed: the eigenpairs did not converge tightly enough")
-                raise RuntimeError(f"eigen-residual {res2:.2e} after the refined re-run (first pass {true_res:.2e}); {why}")
-        post, _frac, fields = ctx.postprocess(evecs, cores, want_interior=True)   # M-normalised in place (solver_fem.py:268)
-        vecs = fields.cpu().numpy()
+        import torch
+        host = torch.empty((n_req, N), dtype=torch.float64, pin_memory=True)
+        # one call (plfem_solve_modes on a scalar context): K - k0^2 M_eps and M, factorisation, eigen-solve, the
+        # M-normalisation of solver_fem.py:268, the a-posteriori guard (second pass at 1e-12) and the copy of the fields
+        evals, post, _frac, resid, st = ctx.solve_modes(cores, g.n_core ** 2, g.n_clad ** 2, self.k0, 0.0, sigma, n_req, ncv,
+                                                        self.eig_tol, self.MAXITER, self.RESIDUAL_TOL, 1e-12, modes_host=host)
+        if st["refined"]:
+            logger.warning(f"scalar eigenpairs failed the a-posteriori check (residual {st['true_residual_first']:.2e}): "
+                           f"re-ran with refinement -> {st['true_residual']:.2e}")
+        vecs = host.numpy()
         modes = []
         for i in range(len(evals)):
             lam = float(evals[i])
@@ -461,7 +418,7 @@ class ScalarHelmholtzSolver:
                                    "is_vectorial": False}))
         modes.sort(key=lambda x: x["n_eff"], reverse=True)
         self.last_stats = dict(st, sigma=sigma, n_req=n_req, ncv=ncv, N=N, t_symbolic=ent.get("t_symbolic", 0.0),
-                               t_total=time.perf_counter() - t_start, **ctx.timings())
+                               t_total=time.perf_counter() - t_start)
         return modes
 
 

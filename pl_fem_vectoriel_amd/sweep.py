@@ -82,22 +82,38 @@ def multiband_sweep_items(n_modes: int = 10, mesh_levels: int = 1, mesh_refineme
 
 
 def partition(items: Sequence[SweepItem], world_size: int) -> List[List[SweepItem]]:
-    """Static partition: groups sharing a mesh stay together; groups dealt heaviest-first to the least
-    loaded rank that still has room (longest-processing-time rule under an equal-count cap).
-    Deterministic — every rank computes the same table."""
+    """Static partition with equal item counts per rank (C4: 8 solves per GPU).  Items sharing a mesh form a group and
+    stay together on one rank (the host analysis is built once per mesh and rank) -- except that a group heavier than
+    three quarters of a rank's fair share is split in two halves first: the 19-core cross-section alone is 1.34 fair
+    shares at 8 ranks, so whole groups leave one rank with 1.5 x the mean load and the sweep waits for it, while two
+    wavelengths of it per rank cost one more analysis (10-20 ms of host time) and bring max / mean to 1.14.  The units are
+    dealt heaviest-first to the least loaded rank with room (longest-processing-time rule under the count cap; a unit
+    that fits nowhere is halved again).  Deterministic -- every rank computes the same table."""
     groups: Dict[tuple, List[SweepItem]] = {}
     for it in items:
         groups.setdefault(it.mesh_key, []).append(it)
-    order = sorted(groups.values(), key=lambda g: (-sum(i.cost() for i in g), g[0].index))
-    cap = -(-len(order) // world_size)          # at most ceil(G / world_size) meshes per rank (8 solves per GPU in C4)
+    share = sum(i.cost() for i in items) / max(world_size, 1)
+    cap = -(-len(items) // world_size)          # items per rank
+    units: List[List[SweepItem]] = []
+    for g in groups.values():
+        if world_size > 1 and len(g) >= 2 and sum(i.cost() for i in g) > 0.75 * share:
+            units += [g[:len(g) // 2], g[len(g) // 2:]]
+        else:
+            units.append(g)
+    pending = sorted(units, key=lambda g: (-sum(i.cost() for i in g), g[0].index))
     loads = [0.0] * world_size
     counts = [0] * world_size
     out: List[List[SweepItem]] = [[] for _ in range(world_size)]
-    for g in order:
-        r = min((q for q in range(world_size) if counts[q] < cap), key=lambda q: (loads[q], q))
+    while pending:
+        g = pending.pop(0)
+        rooms = [q for q in range(world_size) if counts[q] + len(g) <= cap]
+        if not rooms:                           # (only units of several items can be stranded: halve and retry)
+            pending = [g[:len(g) // 2], g[len(g) // 2:]] + pending
+            continue
+        r = min(rooms, key=lambda q: (loads[q], q))
         out[r].extend(g)
         loads[r] += sum(i.cost() for i in g)
-        counts[r] += 1
+        counts[r] += len(g)
     return out
 
 
@@ -123,8 +139,10 @@ def default_solve(device: Optional[int] = None, meshes: Optional[dict] = None) -
 
     lock = threading.Lock()
     shared: Dict[tuple, dict] = {}          # mesh_key -> {"ready": Event, "mesh", "sym", "error"}
-    timeline: list = []                     # (lane thread id, item index, t_start, t_analysis_ready, t_end, new context?)
-    prepared: list = []                     # (mesh_key, t_start, t_mesh_ready, t_analysis_ready) of every mesh made here
+    import collections
+    # host-side picture of the last few thousand solves (bounded: a long-lived solve closure must not grow without limit)
+    timeline = collections.deque(maxlen=4096)   # (lane index, item index, t_start, t_analysis_ready, t_end, new context?)
+    prepared = collections.deque(maxlen=1024)   # (mesh_key, t_start, t_mesh_ready, t_analysis_ready) of every mesh made here
 
     def prepare(item: SweepItem) -> dict:
         with lock:
@@ -171,7 +189,7 @@ def default_solve(device: Optional[int] = None, meshes: Optional[dict] = None) -
         s = cur["solver"]
         s.geometry, s.k0 = g, g.k0
         modes = s.solve_vectorial_modes(cur["mesh"], item.n_modes)
-        timeline.append((threading.get_ident(), item.index, t_start, t_ready, _time.perf_counter(), fresh))
+        timeline.append((cache.get("lane", 0), item.index, t_start, t_ready, _time.perf_counter(), fresh))
         return np.array([[m[f] for m in modes] for f in FIELDS], dtype=np.float64).reshape(NF, len(modes))
 
     solve.prepare = prepare
@@ -190,7 +208,8 @@ def _close_lane(cache: dict) -> None:
             pass
 
 
-def _run_lane(queue, qlock, remaining, holders, solve, rank: int, rec: np.ndarray, device, own_stream: bool, errors: list) -> None:
+def _run_lane(queue, qlock, remaining, holders, solve, rank: int, rec: np.ndarray, device, own_stream: bool, errors: list,
+              lane: int = 0) -> None:
     """One lane = a host thread (with its own stream on a GPU, so that lanes overlap on the device) that takes the next
     entry (row in rec, item) off the rank's queue until it is empty.  A lane stays on the mesh it holds a device context
     for while that mesh has items left; then it takes the first mesh NO other lane is working on (a context per lane and
@@ -202,7 +221,7 @@ def _run_lane(queue, qlock, remaining, holders, solve, rank: int, rec: np.ndarra
     if own_stream:
         import torch
         ctx = torch.cuda.stream(torch.cuda.Stream(device))
-    cache: dict = {}
+    cache: dict = {"lane": lane}               # (the lane's index: what solve.timeline keys its entries by)
     held = None
     with ctx:
         while True:
@@ -323,10 +342,18 @@ def run_sweep(items: Sequence[SweepItem], rank: int = 0, world_size: int = 1,
                 solve.prepare(it0)
             except Exception:                  # noqa: BLE001 - the lane that needs it raises the same error
                 pass
+            # The check above and prepare() are not one atomic step: if the lanes finished this mesh (and released it)
+            # in between -- or a lane died and its items stay ST_SKIPPED -- prepare() has just rebuilt a mesh and an
+            # analysis nobody will ask for or release.  Drop them again.
+            with qlock:
+                orphan = remaining.get(it0.mesh_key, 0) == 0
+            if orphan and hasattr(solve, "release"):
+                solve.release(it0.mesh_key)
 
-    def work():
+    def work(lane: int = 0):
         try:
-            _run_lane(queue, qlock, remaining, holders, solve, rank, rec, device, own_stream=on_gpu and lanes > 1, errors=errors)
+            _run_lane(queue, qlock, remaining, holders, solve, rank, rec, device, own_stream=on_gpu and lanes > 1, errors=errors,
+                      lane=lane)
         except Exception as exc:               # noqa: BLE001 - the lane's remaining items stay ST_SKIPPED
             errors.append((-1, exc))
 
@@ -338,13 +365,16 @@ def run_sweep(items: Sequence[SweepItem], rank: int = 0, world_size: int = 1,
     if lanes == 1:
         work()
     else:
-        threads = [threading.Thread(target=work) for _ in range(min(lanes, max(len(queue), 1)))]
+        threads = [threading.Thread(target=work, args=(ln,)) for ln in range(min(lanes, max(len(queue), 1)))]
         for t in threads:
             t.start()
         for t in threads:
             t.join()
     for t in pres:
         t.join()
+    if hasattr(solve, "release"):              # whatever a dead lane or a late preparer left behind: nothing outlives the sweep
+        for key in groups:
+            solve.release(key)
     table: Dict[int, np.ndarray] = {}
     if world_size > 1 and gather:
         import torch.distributed as dist

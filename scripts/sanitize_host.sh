@@ -16,9 +16,9 @@ for lv in (0, 1):
     with open('$OUT/mesh%d.bin' % lv, 'wb') as f:
         np.array([p.shape[1], t.shape[1]], dtype=np.int32).tofile(f); p.tofile(f); t.tofile(f)
 PY
-SRC="pl_fem_vectoriel_amd/csrc/symbolic.cpp pl_fem_vectoriel_amd/csrc/host_eig.cpp pl_fem_vectoriel_amd/csrc/api_host.cpp scripts/micro/sanitize_host.cpp"
+SRC="pl_fem_vectoriel_amd/csrc/symbolic.cpp pl_fem_vectoriel_amd/csrc/plan.cpp pl_fem_vectoriel_amd/csrc/host_eig.cpp pl_fem_vectoriel_amd/csrc/api_host.cpp pl_fem_vectoriel_amd/csrc/api_debug_host.cpp scripts/micro/sanitize_host.cpp"
 for san in address,undefined thread; do
-  g++ -std=c++17 -O1 -g -fsanitize=$san -fno-omit-frame-pointer -pthread -Iinclude -Ipl_fem_vectoriel_amd/csrc $SRC -o $OUT/h_${san%%,*}
+  g++ -std=c++17 -O1 -g -fsanitize=$san -fno-omit-frame-pointer -pthread -DPLFEM_TEST_HOOKS=1 -Iinclude -Ipl_fem_vectoriel_amd/csrc $SRC -o $OUT/h_${san%%,*}
 done
 ASAN_OPTIONS=detect_leaks=1 $OUT/h_address $OUT/mesh0.bin $OUT/mesh1.bin
 TSAN_OPTIONS=halt_on_error=1 $OUT/h_thread $OUT/mesh0.bin $OUT/mesh1.bin

@@ -25,16 +25,20 @@ def test_partition_covers_everything_once_and_keeps_meshes_together():
         parts = partition(items, ws)
         flat = sorted(i.index for p in parts for i in p)
         assert flat == list(range(64))
-        for p in parts:
+        homes = {}
+        for r, p in enumerate(parts):
             keys = [i.mesh_key for i in p]
-            # the 4 wavelengths of a mesh are contiguous on one rank
+            # the wavelengths of a mesh a rank holds are contiguous; a mesh is whole on one rank or (heavy meshes at
+            # many ranks) in two halves on two
             for k in set(keys):
                 idx = [q for q, kk in enumerate(keys) if kk == k]
-                assert len(idx) == 4 and idx == list(range(idx[0], idx[0] + 4))
-        if ws == 8:
-            assert all(len(p) == 8 for p in parts)             # 8 solves per GPU
+                assert len(idx) in (2, 4) and idx == list(range(idx[0], idx[0] + len(idx)))
+                homes.setdefault(k, []).append(r)
+        assert all(len(v) <= 2 for v in homes.values())
+        assert all(len(p) == 64 // ws for p in parts)          # equal counts: 8 solves per GPU at 8 ranks
         loads = [sum(i.cost() for i in p) for p in parts]
-        assert max(loads) / (sum(loads) / ws) < 1.6          # the 19-core mesh alone is ~1.5x the mean share at 8 ranks
+        # (whole groups only: the 19-core mesh alone made one rank 1.5 x the mean share at 8 ranks)
+        assert max(loads) / (sum(loads) / ws) < 1.15 and max(loads) / min(loads) <= 1.3, loads
 
 
 def _worker(rank, world_size, port, out_dir):
@@ -176,9 +180,10 @@ def test_four_lanes_stay_busy_on_a_rank_with_two_meshes():
     import threading
     import time
     items = multiband_sweep_items()
-    for rank in range(8):
-        mine = partition(items, 8)[rank]
-        assert len(mine) == 8 and len({i.mesh_key for i in mine}) == 2
+    parts = partition(items, 8)
+    for mine in parts:
+        assert len(mine) == 8 and len({i.mesh_key for i in mine}) in (2, 3)     # (3: halves of the heaviest meshes)
+    rank = next(r for r, mine in enumerate(parts) if len({i.mesh_key for i in mine}) == 2)
     seen, prepared, lock = {}, [], threading.Lock()
 
     def solve(item, cache):
@@ -191,7 +196,7 @@ def test_four_lanes_stay_busy_on_a_rank_with_two_meshes():
         with lock:
             prepared.append(item.mesh_key)
     solve.prepare = prepare
-    table, n = run_sweep(items, 3, 8, solve=solve, gather=False, lanes=4)
+    table, n = run_sweep(items, rank, 8, solve=solve, gather=False, lanes=4)
     assert n == 8 and len(table) == 8
     assert len(seen) == 4 and sorted(len(v) for v in seen.values()) == [2, 2, 2, 2]     # four lanes, two solves each
     assert len(set(prepared)) == 2                                                       # one preparation per mesh
@@ -216,3 +221,37 @@ def test_lanes_keep_one_context_per_mesh_while_meshes_outnumber_them():
     assert n == 64 and len(table) == 64
     assert len({k for _t, k in pairs}) == 16 and len({t for t, _k in pairs}) == 4
     assert len(pairs) <= 16 + 3                      # (only the tail, when fewer meshes than lanes remain, is shared)
+
+
+def test_a_late_preparer_leaves_nothing_behind():
+    """the preparer checks `remaining` and calls prepare() in two steps.  When the lanes finish (and release) a
+    mesh in between, prepare() rebuilds a mesh + analysis nobody asks for: they must be released again, and nothing may
+    outlive run_sweep in the solve closure's `shared` table.  Also: eight ranks get eight solves each (two or three
+    meshes: the heaviest cross-sections are split in halves) with a cost spread within 1.3."""
+    import threading
+    import time
+    items = multiband_sweep_items()
+    shared, lock, log = set(), threading.Lock(), []
+
+    def solve(item, cache):                     # instant: the lanes are done long before a preparer returns
+        return fake_solve(item, cache)
+
+    def prepare(item):
+        time.sleep(0.05)
+        with lock:
+            shared.add(item.mesh_key)
+            log.append(("prepare", item.mesh_key))
+
+    def release(key):
+        with lock:
+            shared.discard(key)
+            log.append(("release", key))
+    solve.prepare, solve.release = prepare, release
+    table, n = run_sweep(items, 0, 4, solve=solve, gather=False, lanes=4)
+    assert n == 16 and len(table) == 16
+    assert not shared, shared                   # every prepared mesh was released again
+    assert any(kind == "prepare" for kind, _ in log)
+    parts = partition(items, 8)
+    assert all(len(p) == 8 and len({i.mesh_key for i in p}) in (2, 3) for p in parts)
+    loads = [sum(i.cost() for i in p) for p in parts]
+    assert max(loads) / min(loads) <= 1.3, loads
