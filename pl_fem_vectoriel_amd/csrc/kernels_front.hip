@@ -203,9 +203,15 @@ __device__ __forceinline__ double lane_xor16(double v, bool odd_row) {
 // the pivot block costs what its waves issue (one wave per SIMD: ~5 clocks per instruction, 16 for v_rcp_f64) and a
 // compare -> select pair on the path costs 56 clocks against 7 for a dependent v_fma_f64 (scripts/micro/f64_latency.hip).
 // Vanishing pivots -- below thr = 1e-13 of the largest entry the pair's two rows had in the pivot block when the block
-// step began -- are perturbed statically (+-thr) and counted.
+// step began -- are replaced statically by +-rep = 1e-8 of that entry and counted (plfem_solve_modes then repeats the
+// eigen-solve with refinement inside the operator).  rep is the sqrt(eps)-sized replacement of static pivoting (Li &
+// Demmel): the factor is that of a matrix 1e-8 away, the multipliers stay below 1e8, and ONE refinement pass brings K^-1 b
+// back to full accuracy -- emulated on a pair made singular on purpose (scripts/singular_pair_emulation.py: 1.7e-10 before,
+// 2.6e-13 after one pass; with rep = thr, as in round 3, 3.9e-6 and 1.9e-9).  The 2 x 2 form is guarded the same way:
+// a = 0, |b| << thr, c ~ rmax passes the pivot rule (det = -b^2, p |det| > a^2 s^2) and used to be inverted with entries
+// ~1 / b^2, up to inf, uncounted.
 //   d0, d1, od: this pair's D^-1 (diagonal entries of rows 2q and 2q+1, off-diagonal entry), for the panel and the sweeps.
-__device__ __forceinline__ void pair_step(double a, double b, double c, double thr, bool past_first, bool past_second,
+__device__ __forceinline__ void pair_step(double a, double b, double c, double thr, double rep, bool past_first, bool past_second,
                                           double y0, double y1, const double (&ra)[4], const double (&rb)[4],
                                           double (&v)[4], double& d0, double& d1, double& od, int& nper) {
   const double p = b * b;
@@ -215,14 +221,14 @@ __device__ __forceinline__ void pair_step(double a, double b, double c, double t
     // scalar pivots a, then d2 = c - g b with g = b / a: two eliminations in the arithmetic of the sequential LDL^T
     // (row 2q+1 itself takes part in the first one: its x part becomes row 2q+1 of L^-1, entry 2q = -g)
     if (__builtin_expect(!(fabs(a) >= thr), 0)) {
-      a = (a < 0.0) ? -thr : thr;
+      a = (a < 0.0) ? -rep : rep;
       nper += 1;
     }
     const double r1 = fast_rcp(a);
     const double g = b * r1;
     double d2 = fma(-g, b, c);
     if (__builtin_expect(!(fabs(d2) >= thr), 0)) {
-      d2 = (d2 < 0.0) ? -thr : thr;
+      d2 = (d2 < 0.0) ? -rep : rep;
       nper += 1;
     }
     const double r2 = fast_rcp(d2);
@@ -235,8 +241,14 @@ __device__ __forceinline__ void pair_step(double a, double b, double c, double t
     od = 0.0;
     asm volatile("" ::: "memory");                          // (keeps the arms apart: no if-conversion into selects)
   } else {
-    // 2 x 2 pivot: |det| is a sizeable part of max|E|^2 here, the explicit inverse is benign
-    const double rd = fast_rcp(det);
+    // 2 x 2 pivot: |det| is a sizeable part of max|E|^2 here, the explicit inverse is benign -- unless the whole pair
+    // vanishes against its rows (|det| < thr s: entries of the inverse beyond 1 / thr)
+    double dt = det;
+    if (__builtin_expect(!(fabs(dt) >= thr * s), 0)) {
+      dt = (dt < 0.0) ? -rep * s : rep * s;
+      nper += 1;
+    }
+    const double rd = fast_rcp(dt);
     const double x11 = c * rd, x12 = -b * rd, x22 = a * rd;
     const double l0 = past_second ? fma(y0, x11, y1 * x12) : 0.0;
     const double l1 = past_second ? fma(y0, x12, y1 * x22) : 0.0;
@@ -311,7 +323,7 @@ __device__ __forceinline__ void ldl_pivot_block(const double* src, int64_t ld, i
     }
     __syncthreads();
     const double a = S.col[buf][0][k], b = S.col[buf][0][k + 1], c = S.col[buf][1][k + 1];
-    const double thr = fmax(1e-13 * S.rmax[k], 1e-300);
+    const double thr = fmax(1e-13 * S.rmax[k], 1e-300), rep = fmax(1e-8 * S.rmax[k], 1e-300);
     // this row's entries in the pair's columns (rows up to 2q are done; row 2q+1 still takes part in a scalar step)
     const double y0 = (i > k) ? S.col[buf][0][i] : 0.0, y1 = (i > k + 1) ? S.col[buf][1][i] : 0.0;
     double ra[4], rb[4];
@@ -323,7 +335,7 @@ __device__ __forceinline__ void ldl_pivot_block(const double* src, int64_t ld, i
       rb[cc] = behind ? S.col[buf][1][cidx] : S.row[buf][1][cidx];
     }
     double d0, d1, o01;
-    pair_step(a, b, c, thr, i > k, i > k + 1, y0, y1, ra, rb, v, d0, d1, o01, nper);
+    pair_step(a, b, c, thr, rep, i > k, i > k + 1, y0, y1, ra, rb, v, d0, d1, o01, nper);
     if ((i | 1) == k + 1) {
       dd = (i == k) ? d0 : d1;
       od = o01;

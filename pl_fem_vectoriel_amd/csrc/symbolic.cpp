@@ -448,51 +448,62 @@ std::string p2_edges_and_dofs(int nv, int ne, const double* p, Symbolic& S) {
   return "";
 }
 
-// node -> adjacent elements (CSR), elements ascending within each node.  Counting sort by node on the team: degrees by
-// relaxed atomic increments, a serial prefix sum, the (element, local index) pairs dropped through atomic cursors in
-// whatever order the threads arrive, then every node's short list (a vertex of the lantern meshes has ~6 elements, an
-// edge node 1 or 2) sorted by element id -- so the result does not depend on the thread count.  (Round 3: every thread
-// scanned the whole element table and filed the nodes of its own range -- no atomics, but O(6 ne) per THREAD: 0.8 ms at
-// C1 however many threads.)
+// node -> adjacent elements (CSR), elements ascending within each node: a parallel counting sort by node.  Thread t of
+// the team takes a contiguous range of ELEMENTS and counts, in a private array, how many of their nodes are node i; a
+// pass over the nodes turns the counts into each thread's first slot inside every node's list (thread 0's elements first:
+// ascending element ids without any sorting, the same result for every team size); then every thread files its elements.
+// Plain loads and stores only.  (Round 3: every thread scanned the WHOLE element table and filed the nodes of its own range
+// -- O(6 ne) per thread, 0.8 ms at C1 however many threads; relaxed atomic increments instead of the private counts were
+// tried and are far slower on the x86 host: a locked read-modify-write costs ~20 cycles uncontended, 1.8-4.8 ms.)
 void node_to_elem(Symbolic& S, int nthreads) {
   const int N = S.N, ne = S.ne;
   std::vector<int32_t>& ptr = S.nptr;
   std::vector<int32_t>& adj = S.nadj;
   std::vector<uint8_t>& loc = S.nloc;
-  ptr.assign((size_t)N + 1, 0);
+  ptr.resize((size_t)N + 1);
   adj.resize((size_t)6 * ne);
   loc.resize((size_t)6 * ne);
   const int32_t* d = S.edof.data();
-  int32_t* deg = ptr.data() + 1;
-  parallel_for((int64_t)6 * ne, nthreads, [&](int64_t b, int64_t e_, int) {
-    for (int64_t q = b; q < e_; ++q) __atomic_fetch_add(&deg[d[q]], 1, __ATOMIC_RELAXED);
-  }, 16384);
-  for (int i = 0; i < N; ++i) ptr[i + 1] += ptr[i];
-  std::vector<int32_t> cursor(ptr.begin(), ptr.end() - 1);
-  rawvec_i32 packed((size_t)6 * ne);                 // element << 3 | local index (ne < 2^28: checked by the caller)
-  parallel_for(ne, nthreads, [&](int64_t b, int64_t e_, int) {
-    for (int64_t e = b; e < e_; ++e)
-      for (int a = 0; a < 6; ++a) {
-        const int32_t i = d[(size_t)a * ne + e];
-        packed[__atomic_fetch_add(&cursor[i], 1, __ATOMIC_RELAXED)] = (int32_t)(e << 3) | a;
-      }
-  }, 4096);
+  const int nt = (nthreads > 1 && ne >= 4096) ? std::min(team_size(), 8) : 1;     // (nt private arrays of N counters)
+  const int64_t chunk = ((int64_t)ne + nt - 1) / nt;
+  rawvec_i32 cnt((size_t)nt * N);
+  team_run([&](int rank) {
+    if (rank >= nt) return;
+    int32_t* c = cnt.data() + (size_t)rank * N;
+    std::memset(c, 0, sizeof(int32_t) * (size_t)N);
+    const int64_t e0 = rank * chunk, e1 = std::min<int64_t>(ne, e0 + chunk);
+    for (int a = 0; a < 6; ++a) {
+      const int32_t* row = d + (size_t)a * ne;
+      for (int64_t e = e0; e < e1; ++e) c[row[e]]++;
+    }
+  });
+  // degree of every node and, in place of the counts, thread t's offset inside the node's list
   parallel_for(N, nthreads, [&](int64_t b, int64_t e_, int) {
     for (int64_t i = b; i < e_; ++i) {
-      int32_t* lo = packed.data() + ptr[i];
-      const int n = ptr[i + 1] - ptr[i];
-      for (int q = 1; q < n; ++q) {                  // insertion sort: the lists are short and nearly sorted
-        const int32_t v = lo[q];
-        int r = q;
-        for (; r > 0 && lo[r - 1] > v; --r) lo[r] = lo[r - 1];
-        lo[r] = v;
+      int32_t run = 0;
+      for (int t = 0; t < nt; ++t) {
+        int32_t& c = cnt[(size_t)t * N + i];
+        const int32_t k = c;
+        c = run;
+        run += k;
       }
-      for (int q = 0; q < n; ++q) {
-        adj[ptr[i] + q] = lo[q] >> 3;
-        loc[ptr[i] + q] = (uint8_t)(lo[q] & 7);
-      }
+      ptr[i + 1] = run;
     }
   }, 8192);
+  ptr[0] = 0;
+  for (int i = 0; i < N; ++i) ptr[i + 1] += ptr[i];
+  team_run([&](int rank) {
+    if (rank >= nt) return;
+    int32_t* c = cnt.data() + (size_t)rank * N;
+    const int64_t e0 = rank * chunk, e1 = std::min<int64_t>(ne, e0 + chunk);
+    for (int64_t e = e0; e < e1; ++e)
+      for (int a = 0; a < 6; ++a) {
+        const int32_t i = d[(size_t)a * ne + e];
+        const int32_t slot = ptr[i] + c[i]++;
+        adj[slot] = (int32_t)e;
+        loc[slot] = (uint8_t)a;
+      }
+  });
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -506,15 +517,24 @@ void node_to_elem(Symbolic& S, int nthreads) {
 // ------------------------------------------------------------------------------------------------
 void csr_rowptr(Symbolic& S, int nthreads) {
   const int N = S.N, nv = S.nv, nedges = S.nedges;
-  std::vector<int32_t> inc((size_t)nv, 0);                  // edges incident to each vertex
+  // edges incident to each vertex, by the same private-count scheme (the counters are only nv ints per thread)
+  const int nt = (nthreads > 1 && nedges >= 8192) ? std::min(team_size(), 8) : 1;
+  std::vector<int32_t> part((size_t)nt * nv, 0);
   const int32_t* ea = S.edges.data();
-  parallel_for((int64_t)2 * nedges, nthreads, [&](int64_t b, int64_t e_, int) {
-    for (int64_t q = b; q < e_; ++q) __atomic_fetch_add(&inc[ea[q]], 1, __ATOMIC_RELAXED);
-  }, 16384);
+  const int64_t chunk = ((int64_t)2 * nedges + nt - 1) / nt;
+  team_run([&](int rank) {
+    if (rank >= nt) return;
+    int32_t* c = part.data() + (size_t)rank * nv;
+    const int64_t q0 = rank * chunk, q1 = std::min<int64_t>((int64_t)2 * nedges, q0 + chunk);
+    for (int64_t q = q0; q < q1; ++q) c[ea[q]]++;
+  });
   S.rowptr.assign((size_t)N + 1, 0);
   for (int i = 0; i < N; ++i) {
     const int d = S.nptr[i + 1] - S.nptr[i];
-    S.rowptr[i + 1] = S.rowptr[i] + (i < nv ? 1 + 2 * inc[i] + d : 3 + 3 * d);
+    int inc = 0;
+    if (i < nv)
+      for (int t = 0; t < nt; ++t) inc += part[(size_t)t * nv + i];
+    S.rowptr[i + 1] = S.rowptr[i] + (i < nv ? 1 + 2 * inc + d : 3 + 3 * d);
   }
   S.colind.clear();
   S.slot_row.clear();

@@ -48,6 +48,13 @@ def totals(per, name, pattern, counter):
     return sum(per[d].get(counter, 0.0) for d in ids), len(ids)
 
 
+def matched_names(name, pattern):
+    """Distinct kernel names a family's regex matched (argument lists cut off): bench.py refuses the file when one of them
+    is no longer in the built library (the counters were then collected on other code)."""
+    pat = re.compile(pattern)
+    return sorted({re.sub(r"^void ", "", n).split("(")[0].replace("plfem::(anonymous namespace)::", "") for n in name.values() if pat.search(n)})
+
+
 def main():
     fetch_csv, write_csv, mfma_csv, out = sys.argv[1:5]
     fper, fname = load(fetch_csv, {"FETCH_SIZE"})
@@ -64,7 +71,8 @@ def main():
         res["families"][fam] = {"regex": pat, "unit": unit, "dispatches_fetch_pass": nf, "dispatches_write_pass": nw,
                                 "units_fetch_pass": uf, "units_write_pass": uw,
                                 "fetch_bytes_raw": f * 1024 / uf, "write_bytes": w * 1024 / uw,
-                                "hbm_bytes": 2 * f * 1024 / uf + w * 1024 / uw}
+                                "hbm_bytes": 2 * f * 1024 / uf + w * 1024 / uw,
+                                "kernel_names": matched_names(fname, pat)}
     if mfma_csv != "-":
         names = {"SQ_INSTS_VALU_MFMA_MOPS_F64", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_INSTS_MFMA"}
         mper, mname = load(mfma_csv, names)

@@ -51,3 +51,42 @@ def test_world_size_mismatch_and_failing_rank_are_errors():
     if not torch.cuda.is_available():
         res = _run("--gpus", "2", "--steps", "1", "--warmup", "0", env=env)
         assert res.returncode != 0 and "exited with code" in res.stderr
+
+
+def test_eight_ranks_rehearsal_of_the_sweep():
+    """the 8-rank layout of BASELINE configs[3] without hardware -- one line, 8 solves per rank, the
+    same table as one rank, every rank analysing with its share of the host's cores.  (A rehearsal of the launcher, the
+    partition and the gather under gloo: it says nothing about scaling, and no scaling curve is derived from it.)"""
+    one = _run("--gpus", "1", "--steps", "1", "--warmup", "0", "--sweep")
+    eight = _run("--gpus", "8", "--steps", "1", "--warmup", "0", "--sweep", timeout=600)
+    assert one.returncode == 0 and eight.returncode == 0, one.stderr[-2000:] + eight.stderr[-3000:]
+    lines = [l for l in eight.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
+    d8 = json.loads(lines[0])
+    assert d8["n_gpus"] == 8 and d8["scaling"] == "strong" and d8["sweep"]["solves"] == 64
+    assert d8["sweep"]["solves_rank0"] == 8
+    assert d8["sweep"]["n_eff_checksum"] == d1["sweep"]["n_eff_checksum"]
+    ncpu = os.cpu_count() or 64
+    assert d8["config"]["host_threads_per_rank"] == max(4, min(16, ncpu // 8))     # Dist: the ranks share the host's cores
+    assert d1["config"]["host_threads_per_rank"] is None                            # one rank: the library's default
+
+
+def test_only_a_rendezvous_failure_is_retried():
+    """an import error, an out-of-memory kill or a HIP fault during start-up must not be launched a second
+    time; an address-in-use / c10d store error before rank 0 printed anything may."""
+    sys.path.insert(0, ROOT)
+    import bench
+    assert bench.is_rendezvous_failure(1, "", "RuntimeError: The server socket has failed to listen on any local network address. "
+                                              "port: 29500, useIpv6: false, code: -98, name: EADDRINUSE, message: address already in use")
+    assert bench.is_rendezvous_failure(1, "", "torch.distributed.DistNetworkError: The client socket has failed to connect")
+    assert not bench.is_rendezvous_failure(1, "", "ModuleNotFoundError: No module named 'scipy'")
+    assert not bench.is_rendezvous_failure(-9, "", "EADDRINUSE")                   # killed by a signal: never retried
+    assert not bench.is_rendezvous_failure(1, '{"metric": "x"}', "EADDRINUSE")      # rank 0 had already printed its line
+    assert not bench.is_rendezvous_failure(1, "", "HIP error: an illegal memory access was encountered")
+    # and the failing-rank path of the launcher reports the rank's own stderr, without a second launch
+    env = {k: v for k, v in ENV.items() if k != "PLFEM_BENCH_FAKE"}
+    import torch
+    if not torch.cuda.is_available():
+        res = _run("--gpus", "2", "--steps", "1", "--warmup", "0", env=env)
+        assert res.returncode != 0 and "retrying" not in res.stderr and "bench.py needs a GPU" in res.stderr

@@ -97,8 +97,7 @@ def test_ladder_rung_l2_full_size(c1_geometry, gpu_device, built_library):
 
 
 def test_ladder_rung_l2_matches_the_oracle(c1_geometry, gpu_device, built_library):
-    """The finest rung against the oracle itself (40-80 s of SuperLU + ARPACK on the host; C5 the same way takes 100-200 s
-    and is recorded by scripts/fullsize_parity.py -> profiles/r03_fullsize_parity.txt instead of run here)."""
+    """The finest rung against the oracle itself (40-80 s of SuperLU + ARPACK on the host)."""
     from oracle import hfield
     from oracle.compare import mode_field_errors
     from oracle.p2 import MeshTriLite
@@ -122,6 +121,35 @@ def test_c5_nineteen_cores_full_size(gpu_device, built_library):
     evals, st, sym = _eigen_properties(g, mesh, 20, gpu_device, expect_N=744037, max_front_bound=3400, mem_bound_gb=26)
     assert st["n_block_solves"] > 0                     # the P = 4 block path fits the LDS budget at this size
     assert 8 * 4 * (sym.info["max_front"] + 1) > 64 * 1024      # ... and is the > 64 KB case the guard is about
+
+
+def test_c5_nineteen_cores_matches_the_oracle(gpu_device, built_library):
+    """BASELINE configs[4] at FULL size against the oracle itself, under the driver's eyes (round 3 kept
+    this in scripts/fullsize_parity.py -> profiles/r03_fullsize_parity.txt): 19 cores, N = 744 037, k = 32, one
+    ``solve_vectorial_modes`` vs ``oracle.hfield.solve_vectorial_modes`` on the same (p, t): 100-200 s of SuperLU + ARPACK on
+    the host.  Bars: north_star's |dn_eff| < 5e-5 and field L2 < 1e-6 (sign-invariant; subspace distance inside clusters)."""
+    import time
+    from oracle import hfield
+    from oracle.compare import mode_field_errors
+    from oracle.p2 import MeshTriLite
+    g = MCFGeometry(19, 8.0, 1.5, 1.535, 1.0, wavelength_um=1.55)
+    mesh = generate_mesh(g, 1.0, 2)
+    solver = TrueVectorialMaxwellSolver(g, device=gpu_device)
+    t0 = time.perf_counter()
+    modes = solver.solve_vectorial_modes(mesh, n_modes_target=20)
+    t1 = time.perf_counter()
+    st = solver.last_stats
+    assert st["N"] == 744037 and st["n_req"] == 32 and st["nconv"] == 32
+    assert st["pivot_perturbations"] == 0 and st["refined"] is False and st["true_residual"] < 1e-8
+    solver.clear_cache()                                   # (24 GB of device workspace back before the host leg)
+    tm = {}
+    ref = hfield.solve_vectorial_modes(g, MeshTriLite(mesh.p, mesh.t), n_modes_target=20, fused=True, timings=tm)
+    assert len(modes) == len(ref) == 32
+    dn = max(abs(a["n_eff"] - b["n_eff"]) for a, b in zip(modes, ref))
+    fe = float(mode_field_errors(modes, ref, rel_gap=1e-6).max())
+    print(f"C5 full size: max |dn_eff| = {dn:.2e}, max field L2 = {fe:.2e}; GPU cold solve {t1 - t0:.2f} s, oracle {tm['total']:.0f} s")
+    assert dn < 5e-5 and dn < 1e-10                        # (the bar, and what is actually reached)
+    assert fe < 1e-6
 
 
 def test_c4_full_multiband_sweep_on_one_gpu(gpu_device, built_library):
@@ -153,14 +181,19 @@ def test_c4_full_multiband_sweep_on_one_gpu(gpu_device, built_library):
         solver.clear_cache()
 
 
-def test_sweep_items_that_needed_the_guard_in_round_2_factor_cleanly(gpu_device, built_library):
+def test_sweep_items_that_needed_the_guard_in_round_2_factor_cleanly_and_match_the_oracle(gpu_device, built_library):
     """Three cross-sections of the 64-item sweep met a "vanishing" pivot pair in round 2 (perturbed pivots, first-pass
     eigen-residual 2e-7 .. 2e-6, a second eigen-solve with refinement): a healthy pivot of 2e-4 that shared its 32 x 32
     block with the 1e9-sized entries of a sliver element and was judged against the block's largest entry.  With the
     node-pair pivots and the row-relative threshold they factor like every other item."""
+    from oracle import hfield
+    from oracle.compare import mode_field_errors
+    from oracle.p2 import MeshTriLite
     from pl_fem_vectoriel_amd.sweep import multiband_sweep_items
     items = multiband_sweep_items()
-    for idx in (13, 31, 41):
+    nineteen = next(i.index for i in items if i.arrangement == "hex_1plus6plus12_19" and abs(i.wavelength_um - 1.55) < 1e-9)
+    worst_dn = worst_fe = 0.0
+    for idx in (13, 31, 41, nineteen):
         it = items[idx]
         g = it.geometry()
         mesh = generate_mesh(g, it.mesh_refinement, it.mesh_levels)
@@ -171,3 +204,12 @@ def test_sweep_items_that_needed_the_guard_in_round_2_factor_cleanly(gpu_device,
         assert st["pivot_perturbations"] == 0 and st["refined"] is False, (idx, st["pivot_perturbations"], st["true_residual_first"])
         assert st["true_residual"] < 1e-8, (idx, st["true_residual"])
         solver.clear_cache()
+        # ... and, at the full size of the sweep's items, against the ORACLE (round 3 compared the
+        # sampled sweep items with a second HIP solve only): 8-30 s of SuperLU + ARPACK per item on the host
+        ref = hfield.solve_vectorial_modes(g, MeshTriLite(mesh.p, mesh.t), n_modes_target=it.n_modes, fused=True)
+        assert len(modes) == len(ref), (idx, len(modes), len(ref))
+        dn = max(abs(a["n_eff"] - b["n_eff"]) for a, b in zip(modes, ref))
+        fe = float(mode_field_errors(modes, ref, rel_gap=1e-6).max())
+        assert dn < 5e-5 and fe < 1e-6, (idx, it.arrangement, it.wavelength_um, dn, fe)
+        worst_dn, worst_fe = max(worst_dn, dn), max(worst_fe, fe)
+    print(f"C4 items 13, 31, 41, {nineteen} at full size vs the oracle: max |dn_eff| = {worst_dn:.2e}, max field L2 = {worst_fe:.2e}")

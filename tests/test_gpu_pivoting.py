@@ -37,10 +37,18 @@ def random_cross_sections(n=N_ALL, seed=20261004):
         yield t, arr, float(rng.uniform(6.0, 10.0)), float(rng.uniform(1.45, 1.65)), float(rng.uniform(0.3, 0.6))
 
 
-@pytest.mark.parametrize("chunk", range(4))          # (26 cases each: a test that stays silent for minutes looks hung)
+# Cases whose eigenvalues differ from eigsh run with the REFERENCE's own arguments (k = 18, tol 1e-7) and agree with a wider,
+# tighter eigsh instead -- i.e. where this path returns a different set than the reference's call would.  The list is
+# asserted, so that a new divergence from the reference-argument run shows up as a failure, not as a silent switch of
+# oracles.  Case 38: an exactly degenerate pair at the far edge of the wanted set (see below).
+KNOWN_WIDE_ORACLE_CASES = {38}
+
+
+@pytest.mark.parametrize("chunk", range(4))          # (a quarter of the cases each -- 12 by default, 26 of the full list: a test that stays silent for minutes looks hung)
 def test_random_coarse_cross_sections_factor_cleanly_and_match_the_oracle(chunk, gpu_device, built_library):
     from scipy.sparse.linalg import eigsh
     worst_dn, worst_res = 0.0, 0.0
+    took_wide_oracle = set()
     for t, arr, pitch, lam, refinement in list(random_cross_sections())[:N_CASES][chunk::4]:
         n, variant = ARRANGEMENTS[arr]
         g = MCFGeometry(n, pitch, 1.5, 1.535, 1.0, wavelength_um=lam, variant=variant)
@@ -74,13 +82,15 @@ def test_random_coarse_cross_sections_factor_cleanly_and_match_the_oracle(chunk,
                          return_eigenvectors=False)
             wide = wide[np.argsort(np.abs(wide - raw["sigma"]))][:18]
             want = np.sort(np.sqrt(wide)) / g.k0
+            took_wide_oracle.add(t)
         assert len(got) == len(want) == 18
         dn = float(np.abs(got - want).max())
         assert dn < 1e-9, (case, dn)                      # (north_star's bar is 5e-5)
         assert 0 < len(modes) <= 18, (case, len(modes))
         worst_dn, worst_res = max(worst_dn, dn), max(worst_res, st["true_residual"])
         solver.clear_cache()
-    print(f"chunk {chunk}: max |dn_eff| {worst_dn:.2e}, max first-pass residual {worst_res:.2e}")
+    print(f"chunk {chunk}: max |dn_eff| {worst_dn:.2e}, max first-pass residual {worst_res:.2e}, wide oracle for {sorted(took_wide_oracle)}")
+    assert took_wide_oracle <= KNOWN_WIDE_ORACLE_CASES, sorted(took_wide_oracle - KNOWN_WIDE_ORACLE_CASES)
 
 
 def test_random_cross_sections_of_the_scalar_pencil(gpu_device, built_library):
@@ -115,3 +125,58 @@ def test_random_cross_sections_of_the_scalar_pencil(gpu_device, built_library):
         solver.clear_cache()
     print(f"scalar pencil, {N_CASES_SCALAR} cross-sections: max |dn_eff| {worst:.2e}")
 
+
+
+def _first_pair_singular_sigma(sym, A, B, which=0):
+    """sigma at which the FIRST node pair a leaf front eliminates is singular as a whole: an eigenvalue of the 2 x 2 pencil
+    (A_pp, B_pp) of that node's (Hx, Hy) DOFs (nothing is eliminated before it, so its Schur complement is K_pp itself)."""
+    N = sym.N
+    fs_true, fptr, fnodes = sym.array("fs_true"), sym.array("fnode_ptr"), sym.array("fnodes")
+    nf = len(fs_true)
+    leaf0 = (nf + 1) // 2 - 1
+    f = next(q for q in range(leaf0, nf) if fs_true[q] > 0)
+    node = int(fnodes[fptr[f]])
+    idx = [node, N + node]
+    w = np.sort(np.linalg.eigvals(np.linalg.solve(B[idx][:, idx].toarray(), A[idx][:, idx].toarray())).real)
+    return float(w[which]), node, f
+
+
+@pytest.mark.parametrize("which", [0, 1])
+def test_a_pair_singular_as_a_whole_yields_the_oracles_modes(which, gpu_device, built_library):
+    """The one situation where this path and the reference differ in KIND.  The reference factorises with
+    SuperLU's partial pivoting (solver_fem.py:197 -> scipy arpack.py:915) and returns modes for any regular A - sigma B; the
+    block LDL^T here pivots inside node pairs in a static order.  sigma is chosen so that the first pair a leaf front
+    eliminates is singular as a whole -- A - sigma B itself is perfectly regular, eigsh does not even notice -- which no
+    choice inside the pair can repair.  Required: the vanishing pivot is replaced and COUNTED, the a-posteriori policy of
+    plfem_solve_modes repeats the eigen-solve with refinement inside the operator, and the modes are the oracle's -- not
+    an exception.  (Emulated on the CPU first: scripts/singular_pair_emulation.py.)"""
+    from scipy.sparse.linalg import eigsh
+    from pl_fem_vectoriel_amd import _native
+    from pl_fem_vectoriel_amd.solver_fem import _core_table
+    g = MCFGeometry(7, 8.0, 1.5, 1.535, 1.0, wavelength_um=1.55)
+    mesh = generate_mesh(g, 0.3, 0)
+    A, B, basis, *_ = hfield.assemble_hfield_system_fused(g, MeshTriLite(mesh.p, mesh.t))
+    A_int, B_int, interior = hfield.restrict_interior(A, B, basis)
+    sym = _native.Symbolic(mesh.p, mesh.t)
+    sigma, node, front = _first_pair_singular_sigma(sym, A.tocsr(), B.tocsr(), which)
+    k, ncv = 8, 64
+    want = eigsh(A_int, k=k, M=B_int, sigma=sigma, which="LM", tol=1e-12, maxiter=12000, return_eigenvectors=False)
+    want = np.sort(want)
+    ctx = _native.Context(sym, gpu_device, max_ncv=ncv + 8)
+    import torch
+    host = torch.empty((k, 2 * sym.nsolve), dtype=torch.float64, pin_memory=True)
+    evals, post, frac, resid, st = ctx.solve_modes(_core_table(g), g.n_core ** 2, g.n_clad ** 2, g.k0, 1.0, sigma, k, ncv, 1e-8,
+                                                   12000, 1e-7, 1e-10, modes_host=host)
+    print(f"sigma* = {sigma!r} (node {node}, front {front}): perturbed {st['pivot_perturbations']}, refined {st['refined']}, "
+          f"residual first {st['true_residual_first']:.2e} final {st['true_residual']:.2e}, OP applications {st['n_opinv']}")
+    assert st["pivot_perturbations"] >= 1                      # the pair was seen to vanish, and said so
+    assert st["refined"] is True                               # ... which alone sends the solve through the refined pass
+    assert st["true_residual"] <= 1e-7 and float(resid.max()) <= 1e-7
+    assert np.abs(np.sort(evals) - want).max() <= 1e-9 * np.abs(want).max(), (np.sort(evals), want)
+    # the vectors: eigen-residual against the ORACLE's pencil, interior parts as delivered to the host
+    V = host.numpy()
+    for i in range(k):
+        v = V[i]
+        r = A_int @ v - evals[i] * (B_int @ v)
+        assert np.linalg.norm(r) <= 1e-6 * np.linalg.norm(A_int @ v), (i, np.linalg.norm(r) / np.linalg.norm(A_int @ v))
+    ctx.close()
