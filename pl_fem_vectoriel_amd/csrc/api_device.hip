@@ -259,7 +259,7 @@ int create_impl(plfem_ctx* c, const plfem_symbolic* sym, int device, void* strea
     HIP_TRY(c, hipDeviceGetAttribute(&lim, hipDeviceAttributeMaxSharedMemoryPerBlock, device));
     c->lds_limit = lim;
     const int worst = P.worst_m;
-    auto need = [&](int Pn) { return (int64_t)sizeof(double) * Pn * (worst + 1) + (int64_t)sizeof(double) * 8 * Pn * 64; };
+    auto need = [&](int Pn) { return (int64_t)sizeof(double) * Pn * (worst + 2) + (int64_t)sizeof(double) * 8 * Pn * 64; };
     if (need(plfem::BLOCK_P) <= lim) c->max_block_p = plfem::BLOCK_P;
     else if (need(1) <= lim) c->max_block_p = 1;
     else {

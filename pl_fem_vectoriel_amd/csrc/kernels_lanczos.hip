@@ -196,153 +196,10 @@ __global__ __launch_bounds__(256) void k_panel_axpy_p(int64_t n, int ncols, cons
   }
 }
 
-// ---- the same two panel products with 16-byte accesses (n even: every column starts 16-byte aligned) -------------
-// An 8-byte access per lane streams at 0.54-0.70 of the rate of a 16-byte one on this chip (MI355X_MICROARCH.md, cache
-// policy table) -- the round-3 kernels above sat at 3.1 TB/s for exactly that reason -- so a lane takes TWO consecutive
-// rows per load.
-// Sums V (a power of two <= 64) per-lane values over the 64 lanes with V - 1 + log2(64 / V) shuffles instead of 6 V (the
-// butterfly of the solve sweeps); on return a[0] of lane l is the complete sum of value multi_reduce_index<V>(l).
-template <int V>
-__device__ __forceinline__ int multi_reduce_index(int lane) {
-  int idx = 0;
-#pragma unroll
-  for (int h = V / 2, s = 0; h >= 1; h >>= 1, ++s) idx += ((lane >> s) & 1) ? h : 0;
-  return idx;
-}
-template <int V>
-__device__ __forceinline__ void multi_reduce(double (&a)[V], int lane) {
-#pragma unroll
-  for (int h = V / 2, bit = 1; h >= 1; h >>= 1, bit <<= 1) {
-    const bool up = (lane & bit) != 0;
-#pragma unroll
-    for (int k = 0; k < h; ++k) {
-      const double send = up ? a[k] : a[k + h];
-      const double keep = up ? a[k + h] : a[k];
-      a[k] = keep + __shfl_xor(send, bit);
-    }
-  }
-#pragma unroll
-  for (int off = V; off < 64; off <<= 1) a[0] += __shfl_xor(a[0], off);
-}
-
-// partial[(c P + q) nseg + seg] = sum over the rows of segment seg of Pm[i, c] W[i, q].  One WAVE per (row segment of
-// DOT_SEG rows, group of 4 columns), the waves of a workgroup on consecutive column groups of one segment (they share
-// the segment's rows of W in L1 / L2).  Two trips of (4 + P) 16-byte loads per lane in flight = 16 KB per wave.
-constexpr int DOT_SEG = 1024;          // rows per partial sum (8 trips of 128 rows)
-template <int P>
-__global__ __launch_bounds__(256) void k_panel_dot_p16(int64_t n, int ncols, int ncg, int nseg, const double* __restrict__ Pm,
-                                                       const double* __restrict__ W, int64_t ldw, double* __restrict__ partial) {
-  constexpr int CW = 4;
-  static_assert(CW * P == 16, "epilogue reduces 16 values per wave");
-  const int job = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (job >= nseg * ncg) return;
-  const int seg = job / ncg, c0 = (job - seg * ncg) * CW;
-  const int lane = threadIdx.x & 63;
-  const int64_t i0 = (int64_t)seg * DOT_SEG, i1 = min(n, i0 + DOT_SEG);
-  const double2* col[CW];
-#pragma unroll
-  for (int t = 0; t < CW; ++t) col[t] = reinterpret_cast<const double2*>(Pm + (int64_t)min(c0 + t, ncols - 1) * n);   // clamped: result discarded
-  const double2* wq[P];
-#pragma unroll
-  for (int q = 0; q < P; ++q) wq[q] = reinterpret_cast<const double2*>(W + (int64_t)q * ldw);
-  double acc[CW * P];
-#pragma unroll
-  for (int v = 0; v < CW * P; ++v) acc[v] = 0.0;
-  // pair index p covers rows 2p, 2p + 1 (n even: no pair straddles the end)
-  const int64_t p1 = i1 >> 1;
-  int64_t p = (i0 >> 1) + lane;
-  for (; p + 64 < p1; p += 128) {
-    double2 a[2][CW], w[2][P];
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-#pragma unroll
-      for (int t = 0; t < CW; ++t) a[h][t] = col[t][p + 64 * h];
-#pragma unroll
-      for (int q = 0; q < P; ++q) w[h][q] = wq[q][p + 64 * h];
-    }
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-      for (int t = 0; t < CW; ++t)
-#pragma unroll
-        for (int q = 0; q < P; ++q) acc[t * P + q] = fma(a[h][t].y, w[h][q].y, fma(a[h][t].x, w[h][q].x, acc[t * P + q]));
-  }
-  for (; p < p1; p += 64) {
-    double2 w[P];
-#pragma unroll
-    for (int q = 0; q < P; ++q) w[q] = wq[q][p];
-#pragma unroll
-    for (int t = 0; t < CW; ++t) {
-      const double2 a = col[t][p];
-#pragma unroll
-      for (int q = 0; q < P; ++q) acc[t * P + q] = fma(a.y, w[q].y, fma(a.x, w[q].x, acc[t * P + q]));
-    }
-  }
-  multi_reduce<CW * P>(acc, lane);
-  if (lane < CW * P) {
-    const int v = multi_reduce_index<CW * P>(lane), t = v / P, q = v % P;
-    if (c0 + t < ncols) partial[((int64_t)(c0 + t) * P + q) * nseg + seg] = acc[0];
-  }
-}
-
-// W[i, q] -= sum_c Pm[i, c] H[c + q ldh], two rows per lane, UNR columns (16-byte loads) in flight per lane
-template <int P, int UNR>
-__global__ __launch_bounds__(256) void k_panel_axpy_p16(int64_t n, int ncols, const double* __restrict__ Pm,
-                                                        const double* __restrict__ H, int ldh, double* __restrict__ W,
-                                                        int64_t ldw, double* __restrict__ wil, int N, int dpn) {
-  extern __shared__ double sh[];      // [c][P]
-  for (int k = threadIdx.x; k < ncols * P; k += 256) sh[k] = H[(k / P) + (int64_t)(k % P) * ldh];
-  __syncthreads();
-  const int64_t pr = (int64_t)blockIdx.x * 256 + threadIdx.x;       // row pair
-  if (2 * pr >= n) return;
-  const double2* base = reinterpret_cast<const double2*>(Pm) + pr;
-  const int64_t cs = n >> 1;                                          // column stride in pairs
-  double2 acc[P];
-#pragma unroll
-  for (int q = 0; q < P; ++q) acc[q] = make_double2(0.0, 0.0);
-  int c = 0;
-  for (; c + UNR <= ncols; c += UNR) {
-    double2 a[UNR];
-#pragma unroll
-    for (int u = 0; u < UNR; ++u) a[u] = base[(int64_t)(c + u) * cs];
-#pragma unroll
-    for (int u = 0; u < UNR; ++u)
-#pragma unroll
-      for (int q = 0; q < P; ++q) {
-        const double hq = sh[(c + u) * P + q];
-        acc[q].x = fma(a[u].x, hq, acc[q].x);
-        acc[q].y = fma(a[u].y, hq, acc[q].y);
-      }
-  }
-  for (; c < ncols; ++c) {
-    const double2 a = base[(int64_t)c * cs];
-#pragma unroll
-    for (int q = 0; q < P; ++q) {
-      const double hq = sh[c * P + q];
-      acc[q].x = fma(a.x, hq, acc[q].x);
-      acc[q].y = fma(a.y, hq, acc[q].y);
-    }
-  }
-  double2 w[P];
-#pragma unroll
-  for (int q = 0; q < P; ++q) {
-    double2* wp = reinterpret_cast<double2*>(W + (int64_t)q * ldw) + pr;
-    w[q] = *wp;
-    w[q].x -= acc[q].x;
-    w[q].y -= acc[q].y;
-    *wp = w[q];
-  }
-  if (wil) {
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int64_t i = 2 * pr + h;
-      const int comp = (int)(i / N), node = (int)(i - (int64_t)comp * N);
-      double* d = wil + ((int64_t)node * dpn + comp) * P;
-#pragma unroll
-      for (int q = 0; q < P; ++q) d[q] = h == 0 ? w[q].x : w[q].y;
-    }
-  }
-}
+// (Round 4 measured 16-byte variants of the two panel products -- two rows per lane, W staged in LDS, 8 columns per wave,
+// double-buffered column batches: scripts/micro/panel_bench.hip.  At 72-96 columns k_panel_axpy_p already streams at
+// 5.6-5.9 TB/s, what a plain streaming read of the same panel reaches on this chip (5.4-5.9), and k_panel_dot_p at 4.2;
+// every variant was equal or slower, so the kernels above stay.  Below ~24 columns both are at their launch-latency floor.)
 
 // acc[c + q*lda] += h[c + q*ldh]
 __global__ void k_mat_add(int ncols, int P, double* __restrict__ acc, int lda, const double* __restrict__ h, int ldh) {
@@ -445,55 +302,6 @@ __global__ __launch_bounds__(256) void k_block_scale(int64_t n, const double* __
     Vn[(int64_t)q * ldv + i] = a;
     BVn[(int64_t)q * ldv + i] = b;
     if (fo >= 0) bv_front[fo + q] = b;
-  }
-}
-
-// the same with two rows per lane (16-byte accesses; n even)
-template <int P>
-__global__ __launch_bounds__(256) void k_block_scale16(int64_t n, const double* __restrict__ W, const double* __restrict__ BW,
-                                                       int64_t ldw, const double* __restrict__ Rinv,
-                                                       double* __restrict__ Vn, double* __restrict__ BVn, int64_t ldv,
-                                                       const double* __restrict__ exp_src, int exp_n, double* __restrict__ exp_dst,
-                                                       const int32_t* __restrict__ cnt_src, int32_t* __restrict__ cnt_dst,
-                                                       double* __restrict__ bv_front, const int32_t* __restrict__ npos, int N) {
-  __shared__ double X[P * P];
-  if (threadIdx.x < P * P) X[threadIdx.x] = Rinv[threadIdx.x];
-  if (blockIdx.x == 0 && exp_dst) {
-    for (int t = threadIdx.x; t < exp_n; t += 256) exp_dst[t] = exp_src[t];
-    if (threadIdx.x < 4) cnt_dst[threadIdx.x] = cnt_src[threadIdx.x];
-  }
-  __syncthreads();
-  const int64_t pr = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (2 * pr >= n) return;
-  double2 w[P], bw[P];
-#pragma unroll
-  for (int q = 0; q < P; ++q) {
-    w[q] = reinterpret_cast<const double2*>(W + (int64_t)q * ldw)[pr];
-    bw[q] = reinterpret_cast<const double2*>(BW + (int64_t)q * ldw)[pr];
-  }
-  int64_t fo[2] = {-1, -1};
-  if (bv_front) {
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int64_t i = 2 * pr + h;
-      const int c = i >= N;
-      const int pos = npos[(int)(i - (int64_t)c * N)];
-      if (pos >= 0) fo[h] = ((int64_t)pos + c) * P;
-    }
-  }
-#pragma unroll
-  for (int q = 0; q < P; ++q) {
-    double2 a = make_double2(0.0, 0.0), b = make_double2(0.0, 0.0);
-#pragma unroll
-    for (int k = 0; k <= q; ++k) {
-      const double x = X[k + q * P];
-      a.x += w[k].x * x; a.y += w[k].y * x;
-      b.x += bw[k].x * x; b.y += bw[k].y * x;
-    }
-    reinterpret_cast<double2*>(Vn + (int64_t)q * ldv)[pr] = a;
-    reinterpret_cast<double2*>(BVn + (int64_t)q * ldv)[pr] = b;
-    if (fo[0] >= 0) bv_front[fo[0] + q] = b.x;
-    if (fo[1] >= 0) bv_front[fo[1] + q] = b.y;
   }
 }
 
@@ -788,9 +596,6 @@ void resid_finish(plfem_ctx* c, int k, double* out_host) {
   }
 }
 
-// 16-byte kernels: vectors of even length whose columns start 16-byte aligned (always true for the vectorial pencil: n = 2 N)
-static inline bool wide_ok(const plfem_ctx* c, int64_t ldw) { return (c->n2 & 1) == 0 && (ldw & 1) == 0; }
-
 void launch_residuals(plfem_ctx* c, int k, const double* lam_host, const double* evecs, double* out_host) {
   resid_enqueue(c, k, lam_host, evecs);
   (void)hipStreamSynchronize(c->stream);
@@ -836,13 +641,6 @@ void launch_axpby(plfem_ctx* c, double a, const double* x, double b, const doubl
 void launch_panel_dot_block(plfem_ctx* c, const double* Pm, int ncols, const double* W, int64_t ldw, double* h, int ldh,
                             double* hacc, int ldacc) {
   constexpr int P = BLOCK_P;
-  if (wide_ok(c, ldw) && (reinterpret_cast<uintptr_t>(Pm) & 15) == 0 && (reinterpret_cast<uintptr_t>(W) & 15) == 0) {
-    const int nseg = (int)((c->n2 + DOT_SEG - 1) / DOT_SEG), ncg = (ncols + 3) / 4;
-    hipLaunchKernelGGL(k_panel_dot_p16<P>, dim3((nseg * ncg + 3) / 4), dim3(256), 0, c->stream, c->n2, ncols, ncg, nseg, Pm, W, ldw,
-                       c->d_partial);
-    hipLaunchKernelGGL(k_panel_dot_finish_p, dim3(ncols * P), dim3(64), 0, c->stream, P, nseg, c->d_partial, h, ldh, hacc, ldacc);
-    return;
-  }
   const int nchunks = c->npartial;
   hipLaunchKernelGGL(k_panel_dot_p<P>, dim3(nchunks, (ncols + 15) / 16), dim3(256), 0, c->stream, c->n2, ncols, nchunks,
                      Pm, W, ldw, c->d_partial);
@@ -853,16 +651,6 @@ void launch_panel_dot_block(plfem_ctx* c, const double* Pm, int ncols, const dou
 void launch_panel_axpy_block(plfem_ctx* c, const double* Pm, int ncols, const double* H, int ldh, double* W, int64_t ldw,
                              double* w_interleaved) {
   constexpr int P = BLOCK_P;
-  if (wide_ok(c, ldw) && (reinterpret_cast<uintptr_t>(Pm) & 15) == 0 && (reinterpret_cast<uintptr_t>(W) & 15) == 0) {
-    const unsigned grid = (unsigned)((c->n2 / 2 + 255) / 256);
-    if (ncols >= 16)
-      hipLaunchKernelGGL((k_panel_axpy_p16<P, 16>), dim3(grid), dim3(256), sizeof(double) * ncols * P, c->stream, c->n2, ncols, Pm, H,
-                         ldh, W, ldw, w_interleaved, c->N, c->dpn);
-    else
-      hipLaunchKernelGGL((k_panel_axpy_p16<P, 8>), dim3(grid), dim3(256), sizeof(double) * ncols * P, c->stream, c->n2, ncols, Pm, H,
-                         ldh, W, ldw, w_interleaved, c->N, c->dpn);
-    return;
-  }
   hipLaunchKernelGGL(k_panel_axpy_p<P>, dim3((unsigned)((c->n2 + 255) / 256)), dim3(256), sizeof(double) * ncols * P,
                      c->stream, c->n2, ncols, Pm, H, ldh, W, ldw, w_interleaved, c->N, c->dpn);
 }
@@ -880,13 +668,8 @@ void launch_chol_block(plfem_ctx* c, const double* G, int ldg, double* Tblk, int
 // Gram matrix W^T BW (chunk partials only) + its Cholesky factor in two launches
 void launch_gram_chol_block(plfem_ctx* c, const double* W, const double* BW, int64_t ldw, double* Tblk, int ldT, double* Rinv) {
   constexpr int P = BLOCK_P;
-  int nchunks = c->npartial;
-  if (wide_ok(c, ldw) && (reinterpret_cast<uintptr_t>(W) & 15) == 0 && (reinterpret_cast<uintptr_t>(BW) & 15) == 0) {
-    nchunks = (int)((c->n2 + DOT_SEG - 1) / DOT_SEG);
-    hipLaunchKernelGGL(k_panel_dot_p16<P>, dim3((nchunks + 3) / 4), dim3(256), 0, c->stream, c->n2, P, 1, nchunks, W, BW, ldw, c->d_partial);
-  } else {
-    hipLaunchKernelGGL(k_panel_dot_p<P>, dim3(nchunks, 1), dim3(256), 0, c->stream, c->n2, P, nchunks, W, BW, ldw, c->d_partial);
-  }
+  const int nchunks = c->npartial;
+  hipLaunchKernelGGL(k_panel_dot_p<P>, dim3(nchunks, 1), dim3(256), 0, c->stream, c->n2, P, nchunks, W, BW, ldw, c->d_partial);
   hipLaunchKernelGGL(k_chol_small<P>, dim3(1), dim3(64 * P * P), 0, c->stream, (const double*)nullptr, 0, c->d_partial, nchunks,
                      Tblk, ldT, Rinv, c->d_counters);
 }
@@ -894,12 +677,6 @@ void launch_gram_chol_block(plfem_ctx* c, const double* W, const double* BW, int
 void launch_block_scale(plfem_ctx* c, const double* W, const double* BW, int64_t ldw, const double* Rinv, double* Vn,
                         double* BVn, int64_t ldv, const double* exp_src, int exp_n, double* exp_dst, int32_t* cnt_dst,
                         double* bv_front) {
-  if (wide_ok(c, ldw) && (ldv & 1) == 0 && ((reinterpret_cast<uintptr_t>(W) | reinterpret_cast<uintptr_t>(BW) | reinterpret_cast<uintptr_t>(Vn) |
-                                             reinterpret_cast<uintptr_t>(BVn)) & 15) == 0) {
-    hipLaunchKernelGGL(k_block_scale16<BLOCK_P>, dim3((unsigned)((c->n2 / 2 + 255) / 256)), dim3(256), 0, c->stream, c->n2, W,
-                       BW, ldw, Rinv, Vn, BVn, ldv, exp_src, exp_n, exp_dst, c->d_counters, cnt_dst, bv_front, c->d_npos, c->N);
-    return;
-  }
   hipLaunchKernelGGL(k_block_scale<BLOCK_P>, dim3((unsigned)((c->n2 + 255) / 256)), dim3(256), 0, c->stream, c->n2, W,
                      BW, ldw, Rinv, Vn, BVn, ldv, exp_src, exp_n, exp_dst, c->d_counters, cnt_dst, bv_front, c->d_npos, c->N);
 }

@@ -26,6 +26,7 @@
 // their columns in the mirrored upper storage.  Backward: row form (contiguous columns of the lower storage)
 // except at the leaf level.  The cross-lane sums of the row forms use multi_reduce.  Deterministic throughout.
 #include <algorithm>
+#include <cstdlib>
 
 #include "device.h"
 
@@ -40,6 +41,12 @@
 #endif
 #ifndef PLFEM_SWEEP_ROWLOADS
 #define PLFEM_SWEEP_ROWLOADS 8
+#endif
+#ifndef PLFEM_SWEEP_LD_TILE_DEFAULT
+#define PLFEM_SWEEP_LD_TILE_DEFAULT 4
+#endif
+#ifndef PLFEM_SWEEP_LD_ROWS_DEFAULT
+#define PLFEM_SWEEP_LD_ROWS_DEFAULT 4
 #endif
 
 namespace plfem {
@@ -156,6 +163,12 @@ struct FwdOut {
 
 // ---- forward, tile form ------------------------------------------------------------------------------------------
 // (SweepJob.rb carries SWEEP_ROW_JOB_FLAG in the mixed kernels: row-form workgroup (16 rows) instead of a tile (64 rows))
+// 16-BYTE LOADS (round 4): an 8-byte access per lane streams at 0.54-0.70 of the rate of a 16-byte one on this chip
+// (MI355X_MICROARCH.md, cache-policy table), and the leaf-level kernels sat right at that ceiling (4.5 TB/s forward, 3.2
+// backward).  A 16-byte access in the column-major factors is TWO CONSECUTIVE ROWS of one column, so a lane of the tile
+// forms now owns a row pair (2 rp, 2 rp + 1), rp = lane & 31, and the two halves of a wave take two different columns of
+// the same 64-row tile: one wave-level load = 2 columns x 64 rows = two 512-byte runs.  The halves' sums meet by one
+// v_permlane32-style shuffle (lane ^ 32) before the waves' sums meet in LDS as before.
 constexpr int TB = PLFEM_SWEEP_TB;      // matrix loads in flight per lane and trip (a long front is a chain of such trips)
 template <int P, int NW, int TBF = TB>
 __device__ __forceinline__ void fwd_tile_body(const SweepArgs& A, const SweepJob& J, double* __restrict__ sv, double* __restrict__ red) {
@@ -165,48 +178,78 @@ __device__ __forceinline__ void fwd_tile_body(const SweepArgs& A, const SweepJob
   const int64_t np = J.np;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int need = (r0 + 64 <= s2) ? r0 + 64 : s2;
-  const int r = r0 + lane;
+  const int r = r0 + lane;                                           // (epilogue: wave 0, lane = row)
   const bool valid = r < m;
-  const int ce = valid ? ((r < s2) ? r + 1 : s2) : 0;               // rows of L11^-1 are lower triangular
-  const double* p = A.front + J.foff + r;
+  // this lane's row pair and column slot: columns c = 2 (wave + NW t) + h
+  const int h = lane >> 5, ra = r0 + 2 * (lane & 31), rb = ra + 1;
+  const bool pvalid = ra < m;                                        // (m is even: both rows or none)
+  const int cea = pvalid ? ((ra < s2) ? ra + 1 : s2) : 0;           // rows of L11^-1 are lower triangular
+  const int ceb = pvalid ? ((rb < s2) ? rb + 1 : s2) : 0;           // (ceb >= cea)
+  const double* p = A.front + J.foff + ra;
   FwdOut<P> out;
   if (wave == 0) out.request(A, J.npp, np, s2, m, r);
   FwdStage<P> st;
   stage_fwd<P, false>(A, sv, np, need, NW * 64, tid, st);
-  // first batch of this wave's columns (c == wave mod NW), requested before the staged vector is complete
-  double a0[TBF];
+  // first batch of this half-wave's columns, requested before the staged vector is complete
+  double2 a0[TBF];
 #pragma unroll
-  for (int t = 0; t < TBF; ++t) a0[t] = (wave + NW * t < ce) ? p[(int64_t)(wave + NW * t) * m] : 0.0;
+  for (int t = 0; t < TBF; ++t) {
+    const int c = 2 * (wave + NW * t) + h;
+    a0[t] = (c < ceb) ? *reinterpret_cast<const double2*>(p + (int64_t)c * m) : make_double2(0.0, 0.0);
+  }
   if (tid < need) {
 #pragma unroll
     for (int u = 0; u < P; ++u) sv[tid * P + u] = st.value(u);
   }
   __syncthreads();
-  double acc[P];
+  double acc[2][P];
 #pragma unroll
-  for (int u = 0; u < P; ++u) acc[u] = 0.0;
+  for (int u = 0; u < P; ++u) { acc[0][u] = 0.0; acc[1][u] = 0.0; }
 #pragma unroll
   for (int t = 0; t < TBF; ++t) {
-    const int c = wave + NW * t;
-    if (c < ce) {
+    const int c = 2 * (wave + NW * t) + h;
+    if (c < ceb) {
+      const double ax = (c < cea) ? a0[t].x : 0.0;                   // (c == rb: the entry above the diagonal is L11^-T's)
 #pragma unroll
-      for (int u = 0; u < P; ++u) acc[u] += a0[t] * sv[c * P + u];
-    }
-  }
-  for (int c = wave + NW * TBF; c < ce; c += TBF * NW) {
-    double a[TBF];
-#pragma unroll
-    for (int t = 0; t < TBF; ++t) a[t] = (c + NW * t < ce) ? p[(int64_t)(c + NW * t) * m] : 0.0;
-#pragma unroll
-    for (int t = 0; t < TBF; ++t) {
-      if (c + NW * t < ce) {
-#pragma unroll
-        for (int u = 0; u < P; ++u) acc[u] += a[t] * sv[(c + NW * t) * P + u];
+      for (int u = 0; u < P; ++u) {
+        const double v = sv[c * P + u];
+        acc[0][u] += ax * v;
+        acc[1][u] += a0[t].y * v;
       }
     }
   }
+  for (int c0 = 2 * NW * TBF; c0 < ceb; c0 += 2 * NW * TBF) {         // (c0 + the lane's slot: uniform trip start)
+    double2 a[TBF];
 #pragma unroll
-  for (int u = 0; u < P; ++u) red[(wave * P + u) * 64 + lane] = acc[u];
+    for (int t = 0; t < TBF; ++t) {
+      const int c = c0 + 2 * (wave + NW * t) + h;
+      a[t] = (c < ceb) ? *reinterpret_cast<const double2*>(p + (int64_t)c * m) : make_double2(0.0, 0.0);
+    }
+#pragma unroll
+    for (int t = 0; t < TBF; ++t) {
+      const int c = c0 + 2 * (wave + NW * t) + h;
+      if (c < ceb) {
+        const double ax = (c < cea) ? a[t].x : 0.0;
+#pragma unroll
+        for (int u = 0; u < P; ++u) {
+          const double v = sv[c * P + u];
+          acc[0][u] += ax * v;
+          acc[1][u] += a[t].y * v;
+        }
+      }
+    }
+  }
+  // the two halves of the wave hold the same row pairs: add them, then the waves' sums meet in LDS in a fixed order
+#pragma unroll
+  for (int u = 0; u < P; ++u) {
+    acc[0][u] += __shfl_xor(acc[0][u], 32);
+    acc[1][u] += __shfl_xor(acc[1][u], 32);
+  }
+  if (h == 0) {
+#pragma unroll
+    for (int u = 0; u < P; ++u)
+      *reinterpret_cast<double2*>(&red[(wave * P + u) * 64 + 2 * lane]) = make_double2(acc[0][u], acc[1][u]);
+  }
   __syncthreads();
   if (wave == 0 && valid) {
     double tot[P];
@@ -229,9 +272,11 @@ __device__ __forceinline__ void fwd_tile_body(const SweepArgs& A, const SweepJob
 }
 
 // ---- forward, row form -------------------------------------------------------------------------------------------
-template <int P, int NW, int R>
+// (16-byte loads: the lane index runs along the row's contiguous run, two entries per lane; the staged vector is read as
+// double2 from its [u][i] planes, whose leading dimension ldv is even)
+template <int P, int NW, int R, int LOADS = PLFEM_SWEEP_ROWLOADS>
 __device__ __forceinline__ void fwd_rows_body(const SweepArgs& A, const SweepJob& J, double* __restrict__ sv) {
-  constexpr int RB = NW * R, UNR = PLFEM_SWEEP_ROWLOADS / R, V = R * P;
+  constexpr int RB = NW * R, UNR = LOADS / R, V = R * P;
   const int f = J.f, m = J.m, s2 = J.s2;
   if (A.dbg && ((A.dbg == 1) == (s2 > 128))) return;
   const int j0 = (J.rb & ~SWEEP_ROW_JOB_FLAG) * RB;
@@ -257,12 +302,12 @@ __device__ __forceinline__ void fwd_rows_body(const SweepArgs& A, const SweepJob
   out.request(A, J.npp, np, s2, m, lane < V ? orow : m);
   FwdStage<P> st;
   stage_fwd<P, true>(A, sv, np, need, NW * 64, tid, st);
-  double a0[UNR][R];
+  double2 a0[UNR][R];
 #pragma unroll
   for (int t = 0; t < UNR; ++t) {
-    const int i = 64 * t + lane;
+    const int i = 128 * t + 2 * lane;
 #pragma unroll
-    for (int q = 0; q < R; ++q) a0[t][q] = (i < ce[q]) ? rowp[q][i] : 0.0;
+    for (int q = 0; q < R; ++q) a0[t][q] = (i < ce[q]) ? *reinterpret_cast<const double2*>(rowp[q] + i) : make_double2(0.0, 0.0);
   }
   if (tid < need) {
 #pragma unroll
@@ -272,39 +317,33 @@ __device__ __forceinline__ void fwd_rows_body(const SweepArgs& A, const SweepJob
   double acc[V];
 #pragma unroll
   for (int v = 0; v < V; ++v) acc[v] = 0.0;
-#pragma unroll
-  for (int t = 0; t < UNR; ++t) {
-    const int i = 64 * t + lane;
-    if (i < cmax) {
-#pragma unroll
-      for (int u = 0; u < P; ++u) {
-        const double vi = sv[u * A.ldv + i];
-#pragma unroll
-        for (int q = 0; q < R; ++q) acc[q * P + u] += a0[t][q] * vi;
-      }
-    }
+  // (an entry past the end of its row -- i + 1 == ce for the odd end of a triangular row -- is masked: what lies there is
+  // the other triangle's; the staged vector is finite everywhere below ldv)
+#define PLFEM_FWD_ROWS_CONSUME(a, c)                                                                   \
+  _Pragma("unroll") for (int t = 0; t < UNR; ++t) {                                                    \
+    const int i = (c) + 128 * t + 2 * lane;                                                            \
+    if (i < cmax) {                                                                                    \
+      _Pragma("unroll") for (int u = 0; u < P; ++u) {                                                  \
+        const double2 vi = *reinterpret_cast<const double2*>(&sv[u * A.ldv + i]);                      \
+        _Pragma("unroll") for (int q = 0; q < R; ++q) {                                                \
+          const double ay = (i + 1 < ce[q]) ? a[t][q].y : 0.0;                                         \
+          acc[q * P + u] = fma(ay, vi.y, fma(a[t][q].x, vi.x, acc[q * P + u]));                        \
+        }                                                                                              \
+      }                                                                                                \
+    }                                                                                                  \
   }
-  for (int c = 64 * UNR; c < cmax; c += 64 * UNR) {
-    double a[UNR][R];
+  PLFEM_FWD_ROWS_CONSUME(a0, 0)
+  for (int c = 128 * UNR; c < cmax; c += 128 * UNR) {
+    double2 a[UNR][R];
 #pragma unroll
     for (int t = 0; t < UNR; ++t) {
-      const int i = c + 64 * t + lane;
+      const int i = c + 128 * t + 2 * lane;
 #pragma unroll
-      for (int q = 0; q < R; ++q) a[t][q] = (i < ce[q]) ? rowp[q][i] : 0.0;
+      for (int q = 0; q < R; ++q) a[t][q] = (i < ce[q]) ? *reinterpret_cast<const double2*>(rowp[q] + i) : make_double2(0.0, 0.0);
     }
-#pragma unroll
-    for (int t = 0; t < UNR; ++t) {
-      const int i = c + 64 * t + lane;
-      if (i < cmax) {
-#pragma unroll
-        for (int u = 0; u < P; ++u) {
-          const double vi = sv[u * A.ldv + i];
-#pragma unroll
-          for (int q = 0; q < R; ++q) acc[q * P + u] += a[t][q] * vi;
-        }
-      }
-    }
+    PLFEM_FWD_ROWS_CONSUME(a, c)
   }
+#undef PLFEM_FWD_ROWS_CONSUME
   multi_reduce<V>(acc, lane);
   if (lane < V && orow < m) {
     const int u = oidx % P;
@@ -369,59 +408,80 @@ __device__ __forceinline__ void stage_bwd_rest(const SweepArgs& A, double* sv, i
   }
 }
 
-template <int P, int NW>
+template <int P, int NW, int TBB = PLFEM_SWEEP_TB_BWD>
 __device__ __forceinline__ void bwd_tile_body(const SweepArgs& A, const SweepJob& J, double* __restrict__ sv, double* __restrict__ red) {
   const int rb = J.rb, m = J.m, s2 = J.s2;
   if (A.dbg && ((A.dbg == 1) == (s2 > 128))) return;
   const int r0 = rb * 64;
   const int64_t np = J.np;
   const int64_t npp = J.npp;
-  constexpr int TBB = PLFEM_SWEEP_TB_BWD;   // matrix loads in flight per lane and trip (leaf fronts: ~20 columns per wave)
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const bool publish = rb == 0 && !A.leaf_level;
   BwdStage<P> st;
   st.request_index(A, np, s2, r0 + tid, r0 + tid < m);
-  const int r = r0 + lane;
+  const int r = r0 + lane;                                           // (epilogue: wave 0, lane = row)
   const bool valid = r < s2;
-  // element (j = r, i) of [L11^-T | Z^T]: column i of [F11; F21] at row r for i < s2 (upper mirror), of Z^T (leading
-  // dimension s2, behind [F11; F21]) for i >= s2
-  const double* p = A.front + J.foff + r;
-  const double* pz = A.front + J.foff + (int64_t)m * s2 + r - (int64_t)s2 * s2;     // pz[i s2] for i >= s2
-  auto entry = [&](int i) { return i < s2 ? p[(int64_t)i * m] : pz[(int64_t)i * s2]; };
-  const int cb = valid ? r : m, ce = m;
-  const int cstart = cb + ((wave - cb) & (NW - 1));
-  double a0[TBB];
+  // 16-byte loads: this lane's row pair (ra, ra + 1) and column slot: columns i = slot (mod 2 NW), slot = 2 wave + h.
+  // Element (j, i) of [L11^-T | Z^T]: column i of [F11; F21] at row j for i < s2 (upper mirror), of Z^T (leading
+  // dimension s2, behind [F11; F21]) for i >= s2; row j takes the columns i >= j.
+  const int h = lane >> 5, ra = r0 + 2 * (lane & 31);
+  const bool pvalid = ra < s2;                                       // (s2 is even: both rows or none)
+  const double* p = A.front + J.foff + ra;
+  const double* pz = A.front + J.foff + (int64_t)m * s2 + ra - (int64_t)s2 * s2;     // pz[i s2] for i >= s2
+  auto entry = [&](int i) { return *reinterpret_cast<const double2*>(i < s2 ? p + (int64_t)i * m : pz + (int64_t)i * s2); };
+  const int cb = pvalid ? ra : m, ce = m;
+  const int slot = 2 * wave + h;
+  const int cstart = cb + ((slot - cb) & (2 * NW - 1));
+  double2 a0[TBB];
 #pragma unroll
-  for (int t = 0; t < TBB; ++t) a0[t] = (cstart + NW * t < ce) ? entry(cstart + NW * t) : 0.0;
+  for (int t = 0; t < TBB; ++t) a0[t] = (cstart + 2 * NW * t < ce) ? entry(cstart + 2 * NW * t) : make_double2(0.0, 0.0);
   st.request_value(A, npp);
   stage_bwd_rest<P, false>(A, sv, r0, m, s2, np, npp, NW * 64, tid, publish);
   st.template finish<false>(A, sv, np, publish);
   __syncthreads();
-  double acc[P];
+  double acc[2][P];
 #pragma unroll
-  for (int u = 0; u < P; ++u) acc[u] = 0.0;
+  for (int u = 0; u < P; ++u) { acc[0][u] = 0.0; acc[1][u] = 0.0; }
 #pragma unroll
   for (int t = 0; t < TBB; ++t) {
-    const int c = cstart + NW * t;
+    const int c = cstart + 2 * NW * t;
     if (c < ce) {
+      const double ay = (c > ra) ? a0[t].y : 0.0;                    // (c == ra: below the diagonal lies L11^-1's entry)
 #pragma unroll
-      for (int u = 0; u < P; ++u) acc[u] += a0[t] * sv[c * P + u];
+      for (int u = 0; u < P; ++u) {
+        const double v = sv[c * P + u];
+        acc[0][u] += a0[t].x * v;
+        acc[1][u] += ay * v;
+      }
     }
   }
-  for (int c = cstart + NW * TBB; c < ce; c += TBB * NW) {
-    double a[TBB];
+  for (int c0 = cstart + 2 * NW * TBB; c0 < ce; c0 += 2 * NW * TBB) {
+    double2 a[TBB];
 #pragma unroll
-    for (int t = 0; t < TBB; ++t) a[t] = (c + NW * t < ce) ? entry(c + NW * t) : 0.0;
+    for (int t = 0; t < TBB; ++t) a[t] = (c0 + 2 * NW * t < ce) ? entry(c0 + 2 * NW * t) : make_double2(0.0, 0.0);
 #pragma unroll
     for (int t = 0; t < TBB; ++t) {
-      if (c + NW * t < ce) {
+      const int c = c0 + 2 * NW * t;
+      if (c < ce) {
 #pragma unroll
-        for (int u = 0; u < P; ++u) acc[u] += a[t] * sv[(c + NW * t) * P + u];
+        for (int u = 0; u < P; ++u) {
+          const double v = sv[c * P + u];
+          acc[0][u] += a[t].x * v;
+          acc[1][u] += a[t].y * v;                                   // (c > ra here: past the first batch)
+        }
       }
     }
   }
 #pragma unroll
-  for (int u = 0; u < P; ++u) red[(wave * P + u) * 64 + lane] = acc[u];
+  for (int u = 0; u < P; ++u) {
+    acc[0][u] += __shfl_xor(acc[0][u], 32);
+    acc[1][u] += __shfl_xor(acc[1][u], 32);
+  }
+  if (h == 0) {
+#pragma unroll
+    for (int u = 0; u < P; ++u)
+      *reinterpret_cast<double2*>(&red[(wave * P + u) * 64 + 2 * lane]) = make_double2(acc[0][u], acc[1][u]);
+  }
   __syncthreads();
   if (wave == 0 && valid) {
 #pragma unroll
@@ -435,11 +495,11 @@ __device__ __forceinline__ void bwd_tile_body(const SweepArgs& A, const SweepJob
 }
 
 // Backward sweep, row form: x_j = sum_{i >= j} [L11^-1 ; Z](i, j) v_i with v = [ys ; -x_b] staged in LDS.
-// Column j of the lower storage is contiguous in i, so a wave reads 512-byte runs; a wave owns R rows
-// (j0 + wave + NW q) and keeps R x 8/R loads in flight; a block (NW waves) shares one staged vector for NW R rows.
-template <int P, int NW, int R>
+// Column j of the lower storage is contiguous in i, so a wave reads 1-KB runs (two entries per lane, 16-byte loads); a wave
+// owns R rows (j0 + wave + NW q) and keeps R x 8/R loads in flight; a block (NW waves) shares one staged vector for NW R rows.
+template <int P, int NW, int R, int LOADS = PLFEM_SWEEP_ROWLOADS>
 __device__ __forceinline__ void bwd_rows_body(const SweepArgs& A, const SweepJob& J, double* __restrict__ sv) {
-  constexpr int RB = NW * R, UNR = PLFEM_SWEEP_ROWLOADS / R, V = R * P;
+  constexpr int RB = NW * R, UNR = LOADS / R, V = R * P;
   const int rb = J.rb, m = J.m, s2 = J.s2;
   if (A.dbg && ((A.dbg == 1) == (s2 > 128))) return;
   const int j0 = rb * RB;
@@ -458,12 +518,12 @@ __device__ __forceinline__ void bwd_rows_body(const SweepArgs& A, const SweepJob
     jq[q] = j < s2 ? j : m;                                   // rows past the owned block: every term masked
   }
   const int c0 = (j0 + wave) & ~63;
-  double a0[UNR][R];
+  double2 a0[UNR][R];
 #pragma unroll
   for (int t = 0; t < UNR; ++t) {
-    const int i = c0 + 64 * t + lane;
+    const int i = c0 + 128 * t + 2 * lane;
 #pragma unroll
-    for (int q = 0; q < R; ++q) a0[t][q] = (i < m && i >= jq[q]) ? F[i + (int64_t)jq[q] * m] : 0.0;
+    for (int q = 0; q < R; ++q) a0[t][q] = (i < m && i + 1 >= jq[q]) ? *reinterpret_cast<const double2*>(F + i + (int64_t)jq[q] * m) : make_double2(0.0, 0.0);
   }
   st.request_value(A, npp);
   stage_bwd_rest<P, true>(A, sv, lo, m, s2, np, npp, NW * 64, tid, publish);
@@ -474,39 +534,33 @@ __device__ __forceinline__ void bwd_rows_body(const SweepArgs& A, const SweepJob
   double acc[V];
 #pragma unroll
   for (int v = 0; v < V; ++v) acc[v] = 0.0;
-#pragma unroll
-  for (int t = 0; t < UNR; ++t) {
-    const int i = c0 + 64 * t + lane;
-    if (i < m) {
-#pragma unroll
-      for (int u = 0; u < P; ++u) {
-        const double vi = sv[u * A.ldv + i];
-#pragma unroll
-        for (int q = 0; q < R; ++q) acc[q * P + u] += a0[t][q] * vi;
-      }
-    }
+  // (an entry above its column's start -- i == jq - 1 for an odd jq -- is masked: it belongs to the other triangle; the
+  // staged vector is finite from lo on)
+#define PLFEM_BWD_ROWS_CONSUME(a, c)                                                                   \
+  _Pragma("unroll") for (int t = 0; t < UNR; ++t) {                                                    \
+    const int i = (c) + 128 * t + 2 * lane;                                                            \
+    if (i < m) {                                                                                       \
+      _Pragma("unroll") for (int u = 0; u < P; ++u) {                                                  \
+        const double2 vi = *reinterpret_cast<const double2*>(&sv[u * A.ldv + i]);                      \
+        _Pragma("unroll") for (int q = 0; q < R; ++q) {                                                \
+          const double ax = (i >= jq[q]) ? a[t][q].x : 0.0;                                            \
+          acc[q * P + u] = fma(a[t][q].y, vi.y, fma(ax, vi.x, acc[q * P + u]));                        \
+        }                                                                                              \
+      }                                                                                                \
+    }                                                                                                  \
   }
-  for (int c = c0 + 64 * UNR; c < m; c += 64 * UNR) {
-    double a[UNR][R];
+  PLFEM_BWD_ROWS_CONSUME(a0, c0)
+  for (int c = c0 + 128 * UNR; c < m; c += 128 * UNR) {
+    double2 a[UNR][R];
 #pragma unroll
     for (int t = 0; t < UNR; ++t) {
-      const int i = c + 64 * t + lane;
+      const int i = c + 128 * t + 2 * lane;
 #pragma unroll
-      for (int q = 0; q < R; ++q) a[t][q] = (i < m && i >= jq[q]) ? F[i + (int64_t)jq[q] * m] : 0.0;
+      for (int q = 0; q < R; ++q) a[t][q] = (i < m && i + 1 >= jq[q]) ? *reinterpret_cast<const double2*>(F + i + (int64_t)jq[q] * m) : make_double2(0.0, 0.0);
     }
-#pragma unroll
-    for (int t = 0; t < UNR; ++t) {
-      const int i = c + 64 * t + lane;
-      if (i < m) {
-#pragma unroll
-        for (int u = 0; u < P; ++u) {
-          const double vi = sv[u * A.ldv + i];
-#pragma unroll
-          for (int q = 0; q < R; ++q) acc[q * P + u] += a[t][q] * vi;
-        }
-      }
-    }
+    PLFEM_BWD_ROWS_CONSUME(a, c)
   }
+#undef PLFEM_BWD_ROWS_CONSUME
   multi_reduce<V>(acc, lane);
   if (lane < V && oj < s2) A.xl[(2 * np + oj) * P + oidx % P] = acc[0];
 }
@@ -519,45 +573,47 @@ __device__ __forceinline__ void bwd_rows_body(const SweepArgs& A, const SweepJob
 // them for 4 long fronts alone), every other front tile-form workgroups (64 rows, 4 waves splitting the columns).
 // Measured and dropped: 8-wave tiles in the mixed launch (the leaf level twice as slow), the tile form for the short
 // fronts of the backward mid levels (every level slower than the row form).
-template <int P, int R>
+// LD = 16-byte matrix loads in flight per lane and trip (8: twice the bytes of round 3's eight 8-byte loads, at the price of
+// 16-28 more registers; 4: the same bytes in half the instructions); chosen per kernel form in sweeps() below
+template <int P, int R, int LD>
 __global__ __launch_bounds__(512) void k_fwd_rows(SweepArgs A) {
-  extern __shared__ double sv[];
+  extern __shared__ __attribute__((aligned(16))) double sv[];
   const SweepJob job = A.blk[blockIdx.x];
-  fwd_rows_body<P, 8, R>(A, job, sv);
+  fwd_rows_body<P, 8, R, (LD < R ? R : LD)>(A, job, sv);
 }
 
-template <int P, int R>
+template <int P, int R, int LD>
 __global__ __launch_bounds__(512) void k_bwd_rows(SweepArgs A) {
-  extern __shared__ double sv[];
+  extern __shared__ __attribute__((aligned(16))) double sv[];
   const SweepJob job = A.blk[blockIdx.x];
-  bwd_rows_body<P, 8, R>(A, job, sv);
+  bwd_rows_body<P, 8, R, (LD < R ? R : LD)>(A, job, sv);
 }
 
 // forward, tile form only (levels without a long front: the mixed kernel's register budget costs occupancy there)
-template <int P>
+template <int P, int LD>
 __global__ __launch_bounds__(256) void k_fwd(SweepArgs A) {
-  extern __shared__ double sv[];
-  __shared__ double red[4 * P * 64];
+  extern __shared__ __attribute__((aligned(16))) double sv[];
+  __shared__ __attribute__((aligned(16))) double red[4 * P * 64];
   const SweepJob job = A.blk[blockIdx.x];
-  fwd_tile_body<P, 4, PLFEM_SWEEP_TB_FWD_TILE>(A, job, sv, red);
+  fwd_tile_body<P, 4, LD>(A, job, sv, red);
 }
 
-template <int P>
+template <int P, int LD>
 __global__ __launch_bounds__(256) void k_fwd_mix(SweepArgs A) {
-  extern __shared__ double sv[];
-  __shared__ double red[4 * P * 64];
+  extern __shared__ __attribute__((aligned(16))) double sv[];
+  __shared__ __attribute__((aligned(16))) double red[4 * P * 64];
   const SweepJob job = A.blk[blockIdx.x];
-  if (job.rb & SWEEP_ROW_JOB_FLAG) fwd_rows_body<P, 4, 4>(A, job, sv);
-  else fwd_tile_body<P, 4>(A, job, sv, red);
+  if (job.rb & SWEEP_ROW_JOB_FLAG) fwd_rows_body<P, 4, 4, (LD < 4 ? 4 : LD)>(A, job, sv);
+  else fwd_tile_body<P, 4, LD>(A, job, sv, red);
 }
 
 // backward, leaf level: tile form (leaf fronts have about as many owned rows as boundary columns)
-template <int P>
+template <int P, int LD>
 __global__ __launch_bounds__(512) void k_bwd(SweepArgs A) {
-  extern __shared__ double sv[];
-  __shared__ double red[8 * P * 64];
+  extern __shared__ __attribute__((aligned(16))) double sv[];
+  __shared__ __attribute__((aligned(16))) double red[8 * P * 64];
   const SweepJob job = A.blk[blockIdx.x];
-  bwd_tile_body<P, 8>(A, job, sv, red);
+  bwd_tile_body<P, 8, LD>(A, job, sv, red);
 }
 
 // ---- global order <-> front order ---------------------------------------------------------------------------------
@@ -596,6 +652,9 @@ void sweeps(plfem_ctx* c) {
   A.cinv0 = c->d_cinv0; A.cinv1 = c->d_cinv1; A.prow = c->d_prow;
   A.front = c->d_front; A.dinv2 = reinterpret_cast<const double2*>(c->d_delta);
   A.fr = c->d_fvec; A.u0 = c->d_u0; A.u1 = c->d_u1; A.ys = c->d_fvec2; A.xl = c->d_xl;
+  // 16-byte loads in flight per lane: tile forms / row forms (PLFEM_SWEEP_LD_TILE, PLFEM_SWEEP_LD_ROWS = 4 | 8: tuning aid)
+  static const int ld_tile = getenv("PLFEM_SWEEP_LD_TILE") ? atoi(getenv("PLFEM_SWEEP_LD_TILE")) : PLFEM_SWEEP_LD_TILE_DEFAULT;
+  static const int ld_rows = getenv("PLFEM_SWEEP_LD_ROWS") ? atoi(getenv("PLFEM_SWEEP_LD_ROWS")) : PLFEM_SWEEP_LD_ROWS_DEFAULT;
   double sweep_total = 0.0;                     // algorithmic bytes of one whole sweep (either direction)
   for (const LevelInfo& li : c->levels) sweep_total += li.sweep_bytes + 8.0 * (P - 1) * li.sweep_vec_doubles;
   // Kernel form by level: fwd_block_rows / bwd_block_rows (device.h); workgroups come from the compact launch
@@ -609,17 +668,24 @@ void sweeps(plfem_ctx* c) {
     if (li.fwd_n == 0) continue;
     A.leaf_level = lev == c->L ? 1 : 0;
     A.blk = c->d_blk + li.fwd_off;
-    const size_t lds = sizeof(double) * P * (li.max_s2 + 1);
-    A.ldv = li.max_s2 + 1;
-    if (li.fwd_rows == 8)
-      hipLaunchKernelGGL((k_fwd_rows<P, 1>), dim3(li.fwd_n), dim3(512), lds, st, A);
-    else if (li.fwd_rows == 16)
-      hipLaunchKernelGGL((k_fwd_rows<P, 2>), dim3(li.fwd_n), dim3(512), lds, st, A);
-    else {
+    A.ldv = (li.max_s2 + 2) & ~1;                   // even: the row forms read the staged planes as double2
+    const size_t lds = sizeof(double) * P * A.ldv;
+    if (li.fwd_rows == 8) {
+      if (ld_rows == 8) hipLaunchKernelGGL((k_fwd_rows<P, 1, 8>), dim3(li.fwd_n), dim3(512), lds, st, A);
+      else hipLaunchKernelGGL((k_fwd_rows<P, 1, 4>), dim3(li.fwd_n), dim3(512), lds, st, A);
+    } else if (li.fwd_rows == 16) {
+      if (ld_rows == 8) hipLaunchKernelGGL((k_fwd_rows<P, 2, 8>), dim3(li.fwd_n), dim3(512), lds, st, A);
+      else hipLaunchKernelGGL((k_fwd_rows<P, 2, 4>), dim3(li.fwd_n), dim3(512), lds, st, A);
+    } else {
       // optional live timing of this kernel (bench.py roofline): HIP events on the launch stream
       const int pid = time_launches ? prof_open(c, PLFEM_PROF_KFWD, li.sweep_bytes + 8.0 * (P - 1) * li.sweep_vec_doubles) : -1;
-      if (li.fwd_mixed) hipLaunchKernelGGL((k_fwd_mix<P>), dim3(li.fwd_n), dim3(256), lds, st, A);
-      else hipLaunchKernelGGL((k_fwd<P>), dim3(li.fwd_n), dim3(256), lds, st, A);
+      if (li.fwd_mixed) {
+        if (ld_tile == 8) hipLaunchKernelGGL((k_fwd_mix<P, 8>), dim3(li.fwd_n), dim3(256), lds, st, A);
+        else hipLaunchKernelGGL((k_fwd_mix<P, 4>), dim3(li.fwd_n), dim3(256), lds, st, A);
+      } else {
+        if (ld_tile == 8) hipLaunchKernelGGL((k_fwd<P, 8>), dim3(li.fwd_n), dim3(256), lds, st, A);
+        else hipLaunchKernelGGL((k_fwd<P, 4>), dim3(li.fwd_n), dim3(256), lds, st, A);
+      }
       prof_close(c, pid);
     }
   }
@@ -630,14 +696,18 @@ void sweeps(plfem_ctx* c) {
     if (li.bwd_n == 0) continue;
     A.leaf_level = lev == c->L ? 1 : 0;
     A.blk = c->d_blk + li.bwd_off;
-    const size_t lds = sizeof(double) * P * (li.max_m + 1);
-    A.ldv = li.max_m + 1;
-    if (li.bwd_rows == 8)          // few large fronts: one row per wave, most blocks
-      hipLaunchKernelGGL((k_bwd_rows<P, 1>), dim3(li.bwd_n), dim3(512), lds, st, A);
-    else if (li.bwd_rows == 16)
-      hipLaunchKernelGGL((k_bwd_rows<P, 2>), dim3(li.bwd_n), dim3(512), lds, st, A);
-    else                           // leaf level: tile form
-      hipLaunchKernelGGL((k_bwd<P>), dim3(li.bwd_n), dim3(512), lds, st, A);
+    A.ldv = (li.max_m + 2) & ~1;
+    const size_t lds = sizeof(double) * P * A.ldv;
+    if (li.bwd_rows == 8) {        // few large fronts: one row per wave, most blocks
+      if (ld_rows == 8) hipLaunchKernelGGL((k_bwd_rows<P, 1, 8>), dim3(li.bwd_n), dim3(512), lds, st, A);
+      else hipLaunchKernelGGL((k_bwd_rows<P, 1, 4>), dim3(li.bwd_n), dim3(512), lds, st, A);
+    } else if (li.bwd_rows == 16) {
+      if (ld_rows == 8) hipLaunchKernelGGL((k_bwd_rows<P, 2, 8>), dim3(li.bwd_n), dim3(512), lds, st, A);
+      else hipLaunchKernelGGL((k_bwd_rows<P, 2, 4>), dim3(li.bwd_n), dim3(512), lds, st, A);
+    } else {                       // leaf level: tile form
+      if (ld_tile == 8) hipLaunchKernelGGL((k_bwd<P, 8>), dim3(li.bwd_n), dim3(512), lds, st, A);
+      else hipLaunchKernelGGL((k_bwd<P, 4>), dim3(li.bwd_n), dim3(512), lds, st, A);
+    }
   }
   prof_close(c, pid_bwd);
 }

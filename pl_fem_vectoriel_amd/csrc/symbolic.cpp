@@ -448,61 +448,63 @@ std::string p2_edges_and_dofs(int nv, int ne, const double* p, Symbolic& S) {
   return "";
 }
 
-// node -> adjacent elements (CSR), elements ascending within each node: a parallel counting sort by node.  Thread t of
-// the team takes a contiguous range of ELEMENTS and counts, in a private array, how many of their nodes are node i; a
-// pass over the nodes turns the counts into each thread's first slot inside every node's list (thread 0's elements first:
-// ascending element ids without any sorting, the same result for every team size); then every thread files its elements.
-// Plain loads and stores only.  (Round 3: every thread scanned the WHOLE element table and filed the nodes of its own range
-// -- O(6 ne) per thread, 0.8 ms at C1 however many threads; relaxed atomic increments instead of the private counts were
-// tried and are far slower on the x86 host: a locked read-modify-write costs ~20 cycles uncontended, 1.8-4.8 ms.)
+// node -> adjacent elements (CSR), elements ascending within each node.  No two threads ever write the same node's list
+// (adjacent lists share cache lines: element-range partitions, tried in round 4 with private counters and with atomic
+// cursors, bounce those lines between cores and get SLOWER with every thread added on the 256-CPU host: 0.9 ms on 5
+// threads, 4.6 ms on 8, against 0.4 ms serial).  Instead the NODES are partitioned: vertex nodes only occur in rows 0-2 of
+// the element table, edge nodes only in rows 3-5, and each class is cut into contiguous node ranges; a thread scans the
+// three rows of its class in element order and files the nodes of its range -- half the table per thread (round 3: all of
+// it), ascending element ids without sorting, the same result for every team size.
 void node_to_elem(Symbolic& S, int nthreads) {
-  const int N = S.N, ne = S.ne;
+  const int N = S.N, ne = S.ne, nv = S.nv;
   std::vector<int32_t>& ptr = S.nptr;
   std::vector<int32_t>& adj = S.nadj;
   std::vector<uint8_t>& loc = S.nloc;
-  ptr.resize((size_t)N + 1);
+  ptr.assign((size_t)N + 1, 0);
   adj.resize((size_t)6 * ne);
   loc.resize((size_t)6 * ne);
   const int32_t* d = S.edof.data();
-  const int nt = (nthreads > 1 && ne >= 4096) ? std::min(team_size(), 8) : 1;     // (nt private arrays of N counters)
-  const int64_t chunk = ((int64_t)ne + nt - 1) / nt;
-  rawvec_i32 cnt((size_t)nt * N);
-  team_run([&](int rank) {
-    if (rank >= nt) return;
-    int32_t* c = cnt.data() + (size_t)rank * N;
-    std::memset(c, 0, sizeof(int32_t) * (size_t)N);
-    const int64_t e0 = rank * chunk, e1 = std::min<int64_t>(ne, e0 + chunk);
-    for (int a = 0; a < 6; ++a) {
+  const int nt = (nthreads > 1 && ne >= 4096) ? team_size() : 1;
+  // parts: (class, range).  With one thread: one part per class, run in sequence.
+  const int per_class = std::max(1, nt / 2);
+  struct Part { int a0, lo, hi; };
+  std::vector<Part> parts;
+  for (int cls = 0; cls < 2; ++cls) {
+    const int base = cls == 0 ? 0 : nv, count = cls == 0 ? nv : N - nv;
+    for (int r = 0; r < per_class; ++r)
+      parts.push_back(Part{3 * cls, base + (int)((int64_t)count * r / per_class), base + (int)((int64_t)count * (r + 1) / per_class)});
+  }
+  auto for_parts = [&](auto&& body) {
+    if (nt <= 1) { for (const Part& p : parts) body(p); return; }
+    team_run([&](int rank) { for (size_t q = rank; q < parts.size(); q += nt) body(parts[q]); });
+  };
+  for_parts([&](const Part& p) {
+    for (int a = p.a0; a < p.a0 + 3; ++a) {
       const int32_t* row = d + (size_t)a * ne;
-      for (int64_t e = e0; e < e1; ++e) c[row[e]]++;
+      for (int e = 0; e < ne; ++e) {
+        const int32_t i = row[e];
+        if (i >= p.lo && i < p.hi) ptr[i + 1]++;
+      }
     }
   });
-  // degree of every node and, in place of the counts, thread t's offset inside the node's list
-  parallel_for(N, nthreads, [&](int64_t b, int64_t e_, int) {
-    for (int64_t i = b; i < e_; ++i) {
-      int32_t run = 0;
-      for (int t = 0; t < nt; ++t) {
-        int32_t& c = cnt[(size_t)t * N + i];
-        const int32_t k = c;
-        c = run;
-        run += k;
-      }
-      ptr[i + 1] = run;
-    }
-  }, 8192);
-  ptr[0] = 0;
   for (int i = 0; i < N; ++i) ptr[i + 1] += ptr[i];
-  team_run([&](int rank) {
-    if (rank >= nt) return;
-    int32_t* c = cnt.data() + (size_t)rank * N;
-    const int64_t e0 = rank * chunk, e1 = std::min<int64_t>(ne, e0 + chunk);
-    for (int64_t e = e0; e < e1; ++e)
-      for (int a = 0; a < 6; ++a) {
-        const int32_t i = d[(size_t)a * ne + e];
-        const int32_t slot = ptr[i] + c[i]++;
-        adj[slot] = (int32_t)e;
-        loc[slot] = (uint8_t)a;
+  for_parts([&](const Part& p) {
+    std::vector<int32_t> fill(ptr.begin() + p.lo, ptr.begin() + p.hi);
+    const int32_t* r0 = d + (size_t)p.a0 * ne;
+    const int32_t* r1 = r0 + ne;
+    const int32_t* r2 = r1 + ne;
+    for (int e = 0; e < ne; ++e) {
+      const int32_t ii[3] = {r0[e], r1[e], r2[e]};
+      for (int k = 0; k < 3; ++k) {
+        const int32_t i = ii[k];
+        if (i >= p.lo && i < p.hi) {
+          int32_t& f = fill[i - p.lo];
+          adj[f] = e;
+          loc[f] = (uint8_t)(p.a0 + k);
+          ++f;
+        }
       }
+    }
   });
 }
 
@@ -893,79 +895,56 @@ std::string build_fronts(Symbolic& S, int nthreads) {
   const int leaf0 = (1 << L) - 1, nleaf = 1 << L;
   S.epos.resize((size_t)6 * ne);                 // uninitialised: every (element, local node) entry is written below
   {
-    // Leaf fronts from the NODE side: node i belongs to the leaves of its adjacent elements.  Visiting the nodes
-    // in ascending order (chunk t of the pool takes an ascending range, with per-chunk cursors inside every leaf
-    // list) yields ascending lists without sorting, and the position of node i in a leaf list is known when it is
-    // written -- which is exactly epos for every (element, local node) pair of that node in that leaf.
+    // Leaf fronts from the ELEMENT side, one leaf per task: the nodes of a leaf's elements (6 per element, ~130 in all),
+    // sorted and made unique, split into owned and boundary nodes -- ascending lists by construction -- and the position of
+    // every (element, local node) pair in them (epos) by binary search.  The leaves are independent: no counters shared
+    // between threads, one pass, everything a task touches fits its L1.  (Round 3 walked the NODES twice with per-thread
+    // cursors inside every leaf list: 0.55-0.85 ms of the analysis of C1 against ~0.15 ms this way.)
     LevelBuf& lb = lv[L];
     lb.off.assign((size_t)nleaf + 1, 0);
     for (int lf = 0; lf < nleaf; ++lf) lb.off[lf + 1] = lb.off[lf] + 6 * (int64_t)(S.leaf_elem_ptr[lf + 1] - S.leaf_elem_ptr[lf]);
     lb.own.resize(lb.off[nleaf]);
     lb.bnd.resize(lb.off[nleaf]);
-    const int nt = (nthreads > 1 && N >= 8192) ? team_size() : 1;
-    // cnt[(t * nleaf + lf) * 2 + {0: own, 1: boundary}]: first counts, then start cursors of chunk t in leaf lf
-    std::vector<int32_t> cnt((size_t)nt * nleaf * 2, 0);
-    auto leaves_of = [&](int64_t i, int32_t* lfs) {      // distinct leaves of node i, in order of first appearance
-      int n = 0;
-      for (int32_t q = nptr[i]; q < nptr[i + 1]; ++q) {
-        const int32_t lf = S.leaf_of_elem[nadj[q]];
-        bool seen = false;
-        for (int k = 0; k < n; ++k) seen = seen || lfs[k] == lf;
-        if (!seen) lfs[n++] = lf;
-      }
-      return n;
-    };
-    int maxdeg = 0;
-    for (int i = 0; i < N; ++i) maxdeg = std::max(maxdeg, nptr[i + 1] - nptr[i]);
-    parallel_for(N, nt, [&](int64_t b, int64_t e_, int tid) {
-      std::vector<int32_t> lfs((size_t)maxdeg + 1);
-      int32_t* c = cnt.data() + (size_t)tid * nleaf * 2;
-      for (int64_t i = b; i < e_; ++i) {
-        if (S.bmask[i]) continue;
-        const int n = leaves_of(i, lfs.data());
-        for (int k = 0; k < n; ++k) c[2 * lfs[k] + (S.owner[i] == leaf0 + lfs[k] ? 0 : 1)]++;
-      }
-    }, 1);
-    for (int lf = 0; lf < nleaf; ++lf) {
-      int32_t no = 0, nb = 0;
-      for (int t = 0; t < nt; ++t) {
-        int32_t* c = cnt.data() + ((size_t)t * nleaf + lf) * 2;
-        const int32_t a = c[0], b2 = c[1];
-        c[0] = no; c[1] = nb;
-        no += a; nb += b2;
-      }
-      S.fs_true[leaf0 + lf] = no;
-      S.fb_true[leaf0 + lf] = nb;
-    }
-    parallel_for(N, nt, [&](int64_t b, int64_t e_, int tid) {
-      std::vector<int32_t> lfs((size_t)maxdeg + 1), pos((size_t)maxdeg + 1);
-      int32_t* c = cnt.data() + (size_t)tid * nleaf * 2;
-      for (int64_t i = b; i < e_; ++i) {
-        if (S.bmask[i]) {
-          for (int32_t q = nptr[i]; q < nptr[i + 1]; ++q) S.epos[(size_t)S.nloc[q] * ne + nadj[q]] = -1;
-          continue;
-        }
-        const int n = leaves_of(i, lfs.data());
-        for (int k = 0; k < n; ++k) {
-          const int32_t lf = lfs[k];
-          if (S.owner[i] == leaf0 + lf) {
-            const int32_t p = c[2 * lf]++;
-            lb.own[lb.off[lf] + p] = (int32_t)i;
-            pos[k] = p;
-          } else {
-            const int32_t p = c[2 * lf + 1]++;
-            lb.bnd[lb.off[lf] + p] = (int32_t)i;
-            pos[k] = pad_nodes(S.fs_true[leaf0 + lf], S.dpn) + p;
+    const int32_t* ed = S.edof.data();
+    constexpr int LB = 8;                          // leaves per task
+    parallel_tasks((nleaf + LB - 1) / LB, nthreads, [&](int task) {
+      std::vector<int32_t> nodes;
+      for (int lf = task * LB; lf < std::min(nleaf, (task + 1) * LB); ++lf) {
+        const int e0 = S.leaf_elem_ptr[lf], e1 = S.leaf_elem_ptr[lf + 1];
+        nodes.clear();
+        for (int q = e0; q < e1; ++q) {
+          const int32_t e = S.leaf_elems[q];
+          for (int a = 0; a < 6; ++a) {
+            const int32_t i = ed[(size_t)a * ne + e];
+            if (!S.bmask[i]) nodes.push_back(i);
           }
         }
-        for (int32_t q = nptr[i]; q < nptr[i + 1]; ++q) {
-          const int32_t lf = S.leaf_of_elem[nadj[q]];
-          int k = 0;
-          while (lfs[k] != lf) ++k;
-          S.epos[(size_t)S.nloc[q] * ne + nadj[q]] = pos[k];
+        std::sort(nodes.begin(), nodes.end());
+        nodes.erase(std::unique(nodes.begin(), nodes.end()), nodes.end());
+        int32_t* own = lb.own.data() + lb.off[lf];
+        int32_t* bnd = lb.bnd.data() + lb.off[lf];
+        int no = 0, nb = 0;
+        for (int32_t i : nodes) {
+          if (S.owner[i] == leaf0 + lf) own[no++] = i;
+          else bnd[nb++] = i;
+        }
+        S.fs_true[leaf0 + lf] = no;
+        S.fb_true[leaf0 + lf] = nb;
+        const int pad = pad_nodes(no, S.dpn);
+        for (int q = e0; q < e1; ++q) {
+          const int32_t e = S.leaf_elems[q];
+          for (int a = 0; a < 6; ++a) {
+            const int32_t i = ed[(size_t)a * ne + e];
+            int32_t pos = -1;                      // Dirichlet node
+            if (!S.bmask[i]) {
+              if (S.owner[i] == leaf0 + lf) pos = (int32_t)(std::lower_bound(own, own + no, i) - own);
+              else pos = pad + (int32_t)(std::lower_bound(bnd, bnd + nb, i) - bnd);
+            }
+            S.epos[(size_t)a * ne + e] = pos;
+          }
         }
       }
-    }, 1);
+    });
   }
   tr.lap("fronts: leaves");
   for (int lev = L - 1; lev >= 0; --lev) {
