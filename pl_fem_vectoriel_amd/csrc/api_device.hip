@@ -88,6 +88,36 @@ void events_give(int device, std::vector<hipEvent_t>& mine) {
 }  // namespace
 
 namespace {
+// The dozen events a context owns (phase timing pairs, block-step completion, copy hand-over) come from process-wide
+// pools too, by kind (0 = timing, 1 = hipEventDisableTiming): creating and destroying them cost ~0.15 ms per cold solve.
+std::vector<hipEvent_t>& ctx_event_pool(int device, int kind) {
+  static auto* v = new std::vector<std::vector<hipEvent_t>>();
+  const size_t idx = (size_t)device * 2 + kind;
+  if (v->size() <= idx) v->resize(idx + 1);
+  return (*v)[idx];
+}
+hipError_t ctx_event_acquire(int device, int kind, hipEvent_t* out) {
+  {
+    std::lock_guard<std::mutex> lk(event_mutex());
+    auto& pool = ctx_event_pool(device, kind);
+    if (!pool.empty()) {
+      *out = pool.back();
+      pool.pop_back();
+      return hipSuccess;
+    }
+  }
+  return kind == 0 ? hipEventCreate(out) : hipEventCreateWithFlags(out, hipEventDisableTiming);
+}
+void ctx_event_release(int device, int kind, hipEvent_t e) {
+  if (!e) return;
+  std::lock_guard<std::mutex> lk(event_mutex());
+  auto& pool = ctx_event_pool(device, kind);
+  if (pool.size() < 256) pool.push_back(e);
+  else (void)hipEventDestroy(e);
+}
+}  // namespace
+
+namespace {
 // Side streams for the device-to-host copy of the mode vectors (plfem_solve_modes), one pool per device ordinal: a
 // stream costs ~50 us to create and cold solves create a context each.
 std::mutex& stream_mutex() { static std::mutex* m = new std::mutex(); return *m; }
@@ -147,11 +177,12 @@ int upload(plfem_ctx* c, std::vector<UploadItem>& items, T** dst, const std::vec
 
 // staging: pinned block of at least `span` bytes (the uploads occupy slab offsets [0, span)).  The block is filled and
 // sent in a few pieces, so that the DMA of one piece runs while the host fills the next (filling 14 MB takes about as long
-// as sending them: 0.28 + 0.25 ms in sequence at C1, round 3).
+// as sending them: 0.28 + 0.25 ms in sequence at C1, round 3); the filling runs on a worker pool of the host analysis
+// (parked threads from the process-wide cache: no thread creation here).
 int flush_uploads(plfem_ctx* c, const std::vector<UploadItem>& items, size_t span, char* staging) {
   size_t total = 0;
   for (const auto& it : items) total += it.bytes;
-  const int nthreads = total > (4u << 20) ? 4 : 1;
+  const int nthreads = total > (4u << 20) ? 8 : 1;
   const int npieces = total > (2u << 20) ? 4 : 1;
   // pieces = runs of consecutive items (they are in slab order) of about total / npieces bytes
   std::vector<size_t> first(1, 0);
@@ -163,26 +194,35 @@ int flush_uploads(plfem_ctx* c, const std::vector<UploadItem>& items, size_t spa
     }
     first.push_back(items.size());
   }
-  // the helper threads run through the pieces on their own (created once); the calling thread sends a piece as soon as
-  // every thread has filled its share of it
+  // the helpers run through the pieces on their own; the calling thread (rank 0) sends a piece as soon as every thread
+  // has filled its share of it.  A share = a contiguous byte range of the piece (items are cut where a range ends).
   const size_t npc = first.size() - 1;
   std::unique_ptr<std::atomic<int>[]> done(new std::atomic<int>[npc]);
   for (size_t pc = 0; pc < npc; ++pc) done[pc].store(0, std::memory_order_relaxed);
-  auto fill = [&](int t, size_t pc) {               // thread t copies the items q0 + t, q0 + t + nthreads, ... (sizes are mixed)
-    for (size_t q = first[pc] + t; q < first[pc + 1]; q += nthreads) std::memcpy(staging + items[q].off, items[q].src, items[q].bytes);
-    done[pc].fetch_add(1, std::memory_order_release);
-  };
-  std::vector<std::thread> th;
-  for (int t = 1; t < nthreads; ++t)
-    th.emplace_back([&, t] { for (size_t pc = 0; pc < npc; ++pc) fill(t, pc); });
-  struct Join { std::vector<std::thread>& th; ~Join() { for (auto& x : th) x.join(); } } join{th};
-  for (size_t pc = 0; pc < npc; ++pc) {
-    fill(0, pc);
-    while (done[pc].load(std::memory_order_acquire) < nthreads) __builtin_ia32_pause();
-    const size_t q0 = first[pc], q1 = first[pc + 1];
-    if (q0 == q1) continue;
-    const size_t lo = items[q0].off, hi = q1 < items.size() ? items[q1].off : span;
-    HIP_TRY(c, hipMemcpyAsync(c->slab + lo, staging + lo, hi - lo, hipMemcpyHostToDevice, c->stream));
+  hipError_t herr = hipSuccess;
+  plfem::host_parallel(nthreads, [&](int t, int nt) {
+    for (size_t pc = 0; pc < npc; ++pc) {
+      size_t bytes = 0;
+      for (size_t q = first[pc]; q < first[pc + 1]; ++q) bytes += items[q].bytes;
+      const size_t lo = bytes * t / nt, hi = bytes * (t + 1) / nt;      // this thread's byte range of the piece
+      size_t pos = 0;
+      for (size_t q = first[pc]; q < first[pc + 1] && pos < hi; ++q) {
+        const size_t b0 = std::max(lo, pos), b1 = std::min(hi, pos + items[q].bytes);
+        if (b0 < b1) std::memcpy(staging + items[q].off + (b0 - pos), (const char*)items[q].src + (b0 - pos), b1 - b0);
+        pos += items[q].bytes;
+      }
+      done[pc].fetch_add(1, std::memory_order_release);
+      if (t != 0) continue;
+      while (done[pc].load(std::memory_order_acquire) < nt) __builtin_ia32_pause();
+      const size_t q0 = first[pc], q1 = first[pc + 1];
+      if (q0 == q1 || herr != hipSuccess) continue;
+      const size_t plo = items[q0].off, phi = q1 < items.size() ? items[q1].off : span;
+      herr = hipMemcpyAsync(c->slab + plo, staging + plo, phi - plo, hipMemcpyHostToDevice, c->stream);
+    }
+  });
+  if (herr != hipSuccess) {
+    c->err = std::string("hipMemcpyAsync (index upload): ") + hipGetErrorString(herr);
+    return PLFEM_EHIP;
   }
   return PLFEM_OK;
 }
@@ -209,18 +249,17 @@ void free_all(plfem_ctx* c) {
     (void)hipStreamSynchronize(c->stream);              // (the upload out of the block has long completed)
     pinned_release(c->h_staging, c->h_staging_bytes);
   }
+  // (the stream has been synchronised by plfem_destroy: none of these events is pending)
   for (auto& pr : c->ev)
-    for (auto& e : pr)
-      if (e) (void)hipEventDestroy(e);
-  for (auto& e : c->ev_step)
-    if (e) (void)hipEventDestroy(e);
+    for (auto& e : pr) ctx_event_release(c->device, 0, e);
+  for (auto& e : c->ev_step) ctx_event_release(c->device, 1, e);
   if (!c->prof_ev.empty()) events_give(c->device, c->prof_ev);
   if (c->copy_stream) {
     (void)hipStreamSynchronize(c->copy_stream);
     copy_stream_release(c->device, c->copy_stream);
     c->copy_stream = nullptr;
   }
-  if (c->ev_copy) (void)hipEventDestroy(c->ev_copy);
+  ctx_event_release(c->device, 1, c->ev_copy);
 }
 
 static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
@@ -234,8 +273,8 @@ int create_impl(plfem_ctx* c, const plfem_symbolic* sym, int device, void* strea
   if (!size_only) {
     HIP_TRY(c, hipSetDevice(device));
     for (int q = 0; q < 6; ++q)
-      for (int r = 0; r < 2; ++r) HIP_TRY(c, hipEventCreate(&c->ev[q][r]));
-    for (int r = 0; r < 2; ++r) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_step[r], hipEventDisableTiming));
+      for (int r = 0; r < 2; ++r) HIP_TRY(c, ctx_event_acquire(device, 0, &c->ev[q][r]));
+    for (int r = 0; r < 2; ++r) HIP_TRY(c, ctx_event_acquire(device, 1, &c->ev_step[r]));
     HIP_TRY(c, hipEventRecord(c->ev[4][0], c->stream));
   }
   c->nv = S.nv; c->ne = S.ne; c->N = S.N; c->nnz = S.rowptr.empty() ? 0 : (int)S.rowptr[S.N]; c->nsolve = S.nsolve;
@@ -673,10 +712,16 @@ static int lanczos_block(plfem_ctx* c, int k, int ncv, double tol, int maxiter, 
   auto launch_step = [&](int c0_, int slot) -> int {
     const int nc = c0_ + P;
     const int lo = (c0_ == cycle_start) ? 0 : std::max(0, nc - 2 * P);
-    solve_block_refined(c, c->d_BV + (size_t)c0_ * n, c->d_w, il_ready == c0_, c->refine_steps);   // W = OP V_j
     double* Hblk = c->d_Hcols + (size_t)c0_ * ld;                             // T[0:nc, c0:c0+P] (zero before the step)
-    plfem::launch_panel_dot_block(c, c->d_BV + (size_t)lo * n, nc - lo, c->d_w, n, Hblk + lo, ld);
-    plfem::launch_panel_axpy_block(c, c->d_V + (size_t)lo * n, nc - lo, Hblk + lo, ld, c->d_w, n);
+    if (c->refine_steps == 0 && nc - lo <= 8) {
+      // W = OP V_j left in front order by the sweeps; the first pass permutes it on the way (two launches instead of four)
+      plfem::launch_solve_block(c, c->d_BV + (size_t)c0_ * n, nullptr, n, il_ready == c0_);
+      plfem::launch_first_pass_block(c, c->d_BV + (size_t)lo * n, c->d_V + (size_t)lo * n, nc - lo, c->d_w, n, Hblk + lo, ld);
+    } else {
+      solve_block_refined(c, c->d_BV + (size_t)c0_ * n, c->d_w, il_ready == c0_, c->refine_steps);   // W = OP V_j
+      plfem::launch_panel_dot_block(c, c->d_BV + (size_t)lo * n, nc - lo, c->d_w, n, Hblk + lo, ld);
+      plfem::launch_panel_axpy_block(c, c->d_V + (size_t)lo * n, nc - lo, Hblk + lo, ld, c->d_w, n);
+    }
     plfem::launch_panel_dot_block(c, c->d_BV, nc, c->d_w, n, c->d_hblk, ld, Hblk, ld);  // second pass, T += h2
     // (the second pass also leaves the block interleaved in d_t1 -- idle in this driver -- for the SpMV's gathers)
     plfem::launch_panel_axpy_block(c, c->d_V, nc, c->d_hblk, ld, c->d_w, n, c->d_t1);
@@ -1068,7 +1113,7 @@ extern "C" int plfem_solve_modes(plfem_ctx* c, const double* cores_host, int32_t
   const double th0 = now_ms();
   HIP_TRY(c, hipSetDevice(c->device));
   if (!c->copy_stream) HIP_TRY(c, copy_stream_acquire(c->device, &c->copy_stream));
-  if (!c->ev_copy) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_copy, hipEventDisableTiming));
+  if (!c->ev_copy) HIP_TRY(c, ctx_event_acquire(c->device, 1, &c->ev_copy));
   struct Defer {                                   // the Lanczos drivers leave their final synchronisation to this call
     plfem_ctx* c;
     int saved_refine;
@@ -1098,15 +1143,24 @@ extern "C" int plfem_solve_modes(plfem_ctx* c, const double* cores_host, int32_t
     double* modes = c->modes_dev;
     double* modes_int = c->d_BV2 != modes ? c->d_BV2 : c->d_BV;   // (a restart swaps the double buffers: take the idle one)
     HIP_TRY(c, hipEventRecord(c->ev[3][0], c->stream));
-    plfem::post_enqueue(c, k, modes, ncore, modes_int_host ? modes_int : nullptr);
+    // The copy of the mode vectors (~30 MB at C1: 0.58 ms on the host link, the longest item behind the Lanczos run) leaves
+    // on its own stream, group of modes by group of modes as their post-processing completes, while the later groups and
+    // the check below occupy this stream.
+    hipError_t copy_err = hipSuccess;
+    const size_t row_bytes = sizeof(double) * (size_t)c->dpn * c->nsolve;
+    const std::function<void(int, int)> send_group = [&](int g0, int kg) {
+      if (copy_err != hipSuccess) return;
+      copy_err = hipEventRecord(c->ev_copy, c->stream);
+      if (copy_err == hipSuccess) copy_err = hipStreamWaitEvent(c->copy_stream, c->ev_copy, 0);
+      if (copy_err == hipSuccess)
+        copy_err = hipMemcpyAsync(reinterpret_cast<char*>(modes_int_host) + g0 * row_bytes, reinterpret_cast<char*>(modes_int) + g0 * row_bytes,
+                                  kg * row_bytes, hipMemcpyDeviceToHost, c->copy_stream);
+    };
+    plfem::post_enqueue(c, k, modes, ncore, modes_int_host ? modes_int : nullptr, modes_int_host ? &send_group : nullptr);
     HIP_TRY(c, hipEventRecord(c->ev[3][1], c->stream));
     c->ev_used[3] = true;
-    if (modes_int_host) {
-      // the copy of the mode vectors (~30 MB at C1) leaves on its own stream while the check below occupies this one
-      HIP_TRY(c, hipEventRecord(c->ev_copy, c->stream));
-      HIP_TRY(c, hipStreamWaitEvent(c->copy_stream, c->ev_copy, 0));
-      HIP_TRY(c, hipMemcpyAsync(modes_int_host, modes_int, modes_bytes, hipMemcpyDeviceToHost, c->copy_stream));
-    }
+    HIP_TRY(c, copy_err);
+    (void)modes_bytes;
     HIP_TRY(c, hipEventRecord(c->ev[5][0], c->stream));
     plfem::resid_enqueue(c, k, evals_host, modes);
     HIP_TRY(c, hipEventRecord(c->ev[5][1], c->stream));

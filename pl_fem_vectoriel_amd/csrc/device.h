@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -149,7 +150,8 @@ void launch_residuals(plfem_ctx* c, int k, const double* lam_host, const double*
 // kernels_front.hip (factorisation), kernels_sweep.hip (solve sweeps)
 void launch_factor(plfem_ctx* c, double sigma, int stop_level = -1, int stop_step = 0, int stop_stage = 0);
 void launch_solve(plfem_ctx* c, const double* rhs, double* x);
-void launch_solve_block(plfem_ctx* c, const double* rhs, double* x, int64_t ldx, bool rhs_in_front_order = false);   // BLOCK_P right-hand sides
+// BLOCK_P right-hand sides; x == nullptr: the result stays in front order in d_xl (the caller permutes it itself)
+void launch_solve_block(plfem_ctx* c, const double* rhs, double* x, int64_t ldx, bool rhs_in_front_order = false);
 // kernels_lanczos.hip
 void launch_panel_dot(plfem_ctx* c, const double* P, int ncols, const double* w, double* h);   // h = P^T w
 void launch_panel_axpy(plfem_ctx* c, const double* P, int ncols, const double* h, double* w);  // w -= P h
@@ -167,6 +169,9 @@ void launch_panel_dot_block(plfem_ctx* c, const double* Pm, int ncols, const dou
                             double* hacc = nullptr, int ldacc = 0);
 void launch_panel_axpy_block(plfem_ctx* c, const double* Pm, int ncols, const double* H, int ldh, double* W, int64_t ldw,
                              double* w_interleaved = nullptr);   // w_interleaved: see k_spmv_b_block_il
+// first Gram-Schmidt pass of a block step over ncols <= 8 columns in two launches: reads the sweeps' result d_xl (front
+// order), writes W in global order (what k_permute_out would have done), h = BVm^T W -> Hout, W -= Vm h
+void launch_first_pass_block(plfem_ctx* c, const double* BVm, const double* Vm, int ncols, double* W, int64_t ldw, double* Hout, int ldh);
 void launch_mat_add(plfem_ctx* c, int ncols, double* acc, int lda, const double* h, int ldh);
 void launch_gram_chol_block(plfem_ctx* c, const double* W, const double* BW, int64_t ldw, double* Tblk, int ldT, double* Rinv);
 void launch_chol_block(plfem_ctx* c, const double* G, int ldg, double* Tblk, int ldT, double* Rinv);
@@ -176,7 +181,7 @@ void launch_block_scale(plfem_ctx* c, const double* W, const double* BW, int64_t
 void launch_start_field(plfem_ctx* c, int nvec, double* out);
 void launch_post(plfem_ctx* c, int k, double* evecs, int ncore, double* out_host, double* frac_core, double* modes_int);
 // the same in two halves (plfem_solve_modes: one stream synchronisation for everything behind the Lanczos run)
-void post_enqueue(plfem_ctx* c, int k, double* evecs, int ncore, double* modes_int);
+void post_enqueue(plfem_ctx* c, int k, double* evecs, int ncore, double* modes_int, const std::function<void(int, int)>* group_done);
 void post_finish(plfem_ctx* c, int k, double* out_host, double* frac_core);
 void resid_enqueue(plfem_ctx* c, int k, const double* lam_host, const double* evecs);
 void resid_finish(plfem_ctx* c, int k, double* out_host);

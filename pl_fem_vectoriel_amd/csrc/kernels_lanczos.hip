@@ -7,6 +7,7 @@
 // reference solver_fem.py:200-225.
 #include <algorithm>
 #include <cmath>
+#include <functional>
 
 #include "device.h"
 
@@ -200,6 +201,100 @@ __global__ __launch_bounds__(256) void k_panel_axpy_p(int64_t n, int ncols, cons
 // double-buffered column batches: scripts/micro/panel_bench.hip.  At 72-96 columns k_panel_axpy_p already streams at
 // 5.6-5.9 TB/s, what a plain streaming read of the same panel reaches on this chip (5.4-5.9), and k_panel_dot_p at 4.2;
 // every variant was equal or slower, so the kernels above stay.  Below ~24 columns both are at their launch-latency floor.)
+
+// ---- first Gram-Schmidt pass of a block step in TWO launches instead of four (round 4) ----------------------------
+// The first pass runs over the last two blocks of the basis only (8 columns): its four launches -- the permutation of the
+// sweeps' result into global order, the panel dot, the sum of its partials, the panel axpy -- are each at their 5-8 us
+// latency floor.  k_permute_dot_first does the permutation and the dot in one pass over the rows (the block is read from
+// the sweeps' front-order result where k_permute_out would read it, written out in global order, and multiplied with the
+// up to 8 panel columns on the way); k_axpy_first sums the partials in its prologue (32 values x nseg partials, every
+// workgroup for itself in the same fixed order: the same bits everywhere) before it applies the update.
+constexpr int FIRST_ROWS = 1024;       // rows per workgroup of k_permute_dot_first = per partial sum
+template <int P>
+__global__ __launch_bounds__(256) void k_permute_dot_first(int64_t n2, int N, int nseg, int ncols, const int32_t* __restrict__ npos,
+                                                           const double* __restrict__ xl, double* __restrict__ W, int64_t ldw,
+                                                           const double* __restrict__ Pm, double* __restrict__ partial) {
+  constexpr int CW = 8;
+  __shared__ double red[4][CW * P];
+  const int seg = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  double acc[CW * P];
+#pragma unroll
+  for (int v = 0; v < CW * P; ++v) acc[v] = 0.0;
+  const double* col[CW];
+#pragma unroll
+  for (int t = 0; t < CW; ++t) col[t] = Pm + (int64_t)min(t, ncols - 1) * n2;      // (clamped: the result is dropped)
+#pragma unroll
+  for (int j = 0; j < FIRST_ROWS / 256; ++j) {
+    const int64_t g = (int64_t)seg * FIRST_ROWS + j * 256 + threadIdx.x;
+    if (g >= n2) break;
+    const int c = g >= N, node = (int)(g - (int64_t)c * N);
+    const int pos = npos[node];
+    double a[CW];
+#pragma unroll
+    for (int t = 0; t < CW; ++t) a[t] = col[t][g];
+    double w[P];
+#pragma unroll
+    for (int q = 0; q < P; ++q) w[q] = pos >= 0 ? xl[((int64_t)pos + c) * P + q] : 0.0;
+#pragma unroll
+    for (int q = 0; q < P; ++q) W[(int64_t)q * ldw + g] = w[q];
+#pragma unroll
+    for (int t = 0; t < CW; ++t)
+#pragma unroll
+      for (int q = 0; q < P; ++q) acc[t * P + q] = fma(a[t], w[q], acc[t * P + q]);
+  }
+#pragma unroll
+  for (int v = 0; v < CW * P; ++v) {
+    double x = acc[v];
+    for (int off = 32; off >= 1; off >>= 1) x += __shfl_xor(x, off);
+    if (lane == 0) red[wave][v] = x;
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < CW * P) {
+    const int v = threadIdx.x, t = v / P;
+    if (t < ncols) partial[(int64_t)v * nseg + seg] = (red[0][v] + red[1][v]) + (red[2][v] + red[3][v]);
+  }
+}
+
+// W[i, q] -= sum_c Pm[i, c] h[c][q] with h[c][q] = sum over the nseg partials of k_permute_dot_first (prologue); workgroup 0
+// also stores h into the projected matrix (Hout[c + q ldh])
+template <int P>
+__global__ __launch_bounds__(256) void k_axpy_first(int64_t n, int ncols, int nseg, const double* __restrict__ Pm,
+                                                    const double* __restrict__ partial, double* __restrict__ Hout, int ldh,
+                                                    double* __restrict__ W, int64_t ldw) {
+  constexpr int CW = 8;
+  __shared__ double sh[CW * P];
+  {
+    // 8 threads per value: thread part p adds partials p, p + 8, ... in order, then a fixed butterfly over the 8 parts
+    const int v = threadIdx.x >> 3, part = threadIdx.x & 7;
+    double x = 0.0;
+    if (v / P < ncols)
+      for (int k = part; k < nseg; k += 8) x += partial[(int64_t)v * nseg + k];
+    x += __shfl_xor(x, 1, 8);
+    x += __shfl_xor(x, 2, 8);
+    x += __shfl_xor(x, 4, 8);
+    if (part == 0) {
+      sh[v] = x;
+      if (blockIdx.x == 0 && v / P < ncols) Hout[(v / P) + (int64_t)(v % P) * ldh] = x;
+    }
+  }
+  __syncthreads();
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  double a[CW];
+#pragma unroll
+  for (int t = 0; t < CW; ++t) a[t] = Pm[(int64_t)min(t, ncols - 1) * n + i];
+  double acc[P];
+#pragma unroll
+  for (int q = 0; q < P; ++q) acc[q] = 0.0;
+#pragma unroll
+  for (int t = 0; t < CW; ++t)
+    if (t < ncols) {
+#pragma unroll
+      for (int q = 0; q < P; ++q) acc[q] = fma(a[t], sh[t * P + q], acc[q]);
+    }
+#pragma unroll
+  for (int q = 0; q < P; ++q) W[(int64_t)q * ldw + i] -= acc[q];
+}
 
 // acc[c + q*lda] += h[c + q*ldh]
 __global__ void k_mat_add(int ncols, int P, double* __restrict__ acc, int lda, const double* __restrict__ h, int ldh) {
@@ -655,6 +750,18 @@ void launch_panel_axpy_block(plfem_ctx* c, const double* Pm, int ncols, const do
                      c->stream, c->n2, ncols, Pm, H, ldh, W, ldw, w_interleaved, c->N, c->dpn);
 }
 
+// first Gram-Schmidt pass over ncols <= 8 columns, fused with the permutation of the sweeps' result (d_xl, front order)
+// into W (global order): h -> Hout, W -= Vm h
+void launch_first_pass_block(plfem_ctx* c, const double* BVm, const double* Vm, int ncols, double* W, int64_t ldw, double* Hout,
+                             int ldh) {
+  constexpr int P = BLOCK_P;
+  const int nseg = (int)((c->n2 + FIRST_ROWS - 1) / FIRST_ROWS);      // (= npartial: PANEL_CHUNK rows per partial sum)
+  hipLaunchKernelGGL(k_permute_dot_first<P>, dim3(nseg), dim3(256), 0, c->stream, c->n2, c->N, nseg, ncols, c->d_npos, c->d_xl, W, ldw,
+                     BVm, c->d_partial);
+  hipLaunchKernelGGL(k_axpy_first<P>, dim3((unsigned)((c->n2 + 255) / 256)), dim3(256), 0, c->stream, c->n2, ncols, nseg, Vm,
+                     c->d_partial, Hout, ldh, W, ldw);
+}
+
 void launch_mat_add(plfem_ctx* c, int ncols, double* acc, int lda, const double* h, int ldh) {
   const int n = ncols * BLOCK_P;
   hipLaunchKernelGGL(k_mat_add, dim3((n + 255) / 256), dim3(256), 0, c->stream, ncols, BLOCK_P, acc, lda, h, ldh);
@@ -724,31 +831,41 @@ void launch_rotate(plfem_ctx* c, const double* V, int m, const double* Smat, int
   }
 }
 
-void post_enqueue(plfem_ctx* c, int k, double* evecs, int ncore, double* modes_int) {
+// group_done (may be null): called after the kernels of every group of POST_GROUP modes [g0, g0 + kg) have been enqueued
+// -- their interior copies in modes_int are then complete in stream order -- so that the caller can start sending them to
+// the host while the next group is still being processed (plfem_solve_modes)
+constexpr int POST_GROUP = 8;
+void post_enqueue(plfem_ctx* c, int k, double* evecs, int ncore, double* modes_int, const std::function<void(int, int)>* group_done) {
   hipStream_t st = c->stream;
   const int N = c->N;
   (void)hipMemsetAsync(c->d_counters + 1, 0, sizeof(int32_t), st);
   hipLaunchKernelGGL(k_core_mask, dim3((N + 255) / 256), dim3(256), 0, st, N, c->d_doflocs, c->d_cores, ncore,
                      c->d_bmask, c->d_coremask, c->d_counters);
   const int nblocks = (N + POST_ROWS - 1) / POST_ROWS;
-  double* partial = c->d_post;                       // [k][nblocks][5]
-  double* sums = c->d_post + (int64_t)k * nblocks * 5;   // [k][5]
-  if (c->dpn == 1)      // scalar solver: v.M v with M = the MINV slot
-    hipLaunchKernelGGL(k_post_sums<1>, dim3(nblocks, (k + POST_MB - 1) / POST_MB), dim3(256), 0, st, N, k, nblocks, c->d_rowptr, c->d_colind,
-                       c->d_vals[PLFEM_BLK_MINV], c->d_vals[PLFEM_BLK_DXY], c->d_vals[PLFEM_BLK_DYY], c->d_coremask, evecs,
-                       partial);
-  else
-    hipLaunchKernelGGL(k_post_sums<2>, dim3(nblocks, (k + POST_MB - 1) / POST_MB), dim3(256), 0, st, N, k, nblocks, c->d_rowptr, c->d_colind,
-                       c->d_vals[PLFEM_BLK_DXX], c->d_vals[PLFEM_BLK_DXY], c->d_vals[PLFEM_BLK_DYY], c->d_coremask, evecs,
-                       partial);
-  hipLaunchKernelGGL(k_post_finish, dim3(k * 5), dim3(64), 0, st, k, nblocks, partial, sums);
-  hipLaunchKernelGGL(k_post_scale, dim3((unsigned)((c->n2 + 255) / 256), k), dim3(256), 0, st, N, c->dpn, sums, evecs);
-  if (modes_int)
-    hipLaunchKernelGGL(k_gather_interior, dim3((unsigned)((c->dpn * (int64_t)c->nsolve + 255) / 256), k), dim3(256), 0, st,
-                       N, c->nsolve, c->dpn, c->d_interior, evecs, modes_int);
+  const int group = group_done ? POST_GROUP : k;
+  for (int g0 = 0; g0 < k; g0 += group) {
+    const int kg = std::min(group, k - g0);
+    double* ev = evecs + (int64_t)g0 * c->n2;
+    double* partial = c->d_post + (int64_t)g0 * nblocks * 5;          // [k][nblocks][5]
+    double* sums = c->d_post + (int64_t)k * nblocks * 5 + (int64_t)g0 * 5;   // [k][5]
+    if (c->dpn == 1)      // scalar solver: v.M v with M = the MINV slot
+      hipLaunchKernelGGL(k_post_sums<1>, dim3(nblocks, (kg + POST_MB - 1) / POST_MB), dim3(256), 0, st, N, kg, nblocks, c->d_rowptr, c->d_colind,
+                         c->d_vals[PLFEM_BLK_MINV], c->d_vals[PLFEM_BLK_DXY], c->d_vals[PLFEM_BLK_DYY], c->d_coremask, ev,
+                         partial);
+    else
+      hipLaunchKernelGGL(k_post_sums<2>, dim3(nblocks, (kg + POST_MB - 1) / POST_MB), dim3(256), 0, st, N, kg, nblocks, c->d_rowptr, c->d_colind,
+                         c->d_vals[PLFEM_BLK_DXX], c->d_vals[PLFEM_BLK_DXY], c->d_vals[PLFEM_BLK_DYY], c->d_coremask, ev,
+                         partial);
+    hipLaunchKernelGGL(k_post_finish, dim3(kg * 5), dim3(64), 0, st, kg, nblocks, partial, sums);
+    hipLaunchKernelGGL(k_post_scale, dim3((unsigned)((c->n2 + 255) / 256), kg), dim3(256), 0, st, N, c->dpn, sums, ev);
+    if (modes_int)
+      hipLaunchKernelGGL(k_gather_interior, dim3((unsigned)((c->dpn * (int64_t)c->nsolve + 255) / 256), kg), dim3(256), 0, st,
+                         N, c->nsolve, c->dpn, c->d_interior, ev, modes_int + (int64_t)g0 * c->dpn * c->nsolve);
+    if (group_done) (*group_done)(g0, kg);
+  }
   // results to the host
   double* hs = c->h_pinned;
-  (void)hipMemcpyAsync(hs, sums, sizeof(double) * k * 5, hipMemcpyDeviceToHost, st);
+  (void)hipMemcpyAsync(hs, c->d_post + (int64_t)k * nblocks * 5, sizeof(double) * k * 5, hipMemcpyDeviceToHost, st);
   int32_t* hc = reinterpret_cast<int32_t*>(c->h_pinned + 4096);
   (void)hipMemcpyAsync(hc, c->d_counters, sizeof(int32_t) * 4, hipMemcpyDeviceToHost, st);
 }
@@ -775,7 +892,7 @@ void post_finish(plfem_ctx* c, int k, double* out_host, double* frac_core) {
 
 void launch_post(plfem_ctx* c, int k, double* evecs, int ncore, double* out_host, double* frac_core,
                  double* modes_int) {
-  post_enqueue(c, k, evecs, ncore, modes_int);
+  post_enqueue(c, k, evecs, ncore, modes_int, nullptr);
   (void)hipStreamSynchronize(c->stream);
   post_finish(c, k, out_host, frac_core);
 }

@@ -729,7 +729,7 @@ void launch_solve_block(plfem_ctx* c, const double* rhs, double* x, int64_t ldx,
   if (!rhs_in_front_order)
     hipLaunchKernelGGL(k_permute_in<BLOCK_P>, dim3(grid), dim3(256), 0, c->stream, c->n2, c->N, c->d_npos, rhs, ldx, c->d_fvec);
   sweeps<BLOCK_P>(c);
-  hipLaunchKernelGGL(k_permute_out<BLOCK_P>, dim3(grid), dim3(256), 0, c->stream, c->n2, c->N, c->d_npos, c->d_xl, x, ldx);
+  if (x) hipLaunchKernelGGL(k_permute_out<BLOCK_P>, dim3(grid), dim3(256), 0, c->stream, c->n2, c->N, c->d_npos, c->d_xl, x, ldx);
 }
 
 }  // namespace plfem

@@ -62,6 +62,7 @@ struct Pool {
   std::mutex mu;
   std::condition_variable cv;
   std::atomic<bool> active{false}, stop{false}, failed{false};
+  const double linger_ms = getenv("PLFEM_POOL_LINGER_MS") ? atof(getenv("PLFEM_POOL_LINGER_MS")) : 0.0;
   std::exception_ptr error;              // first exception thrown inside a worker's job (rethrown by the leader's join)
   explicit Pool(int n);
   ~Pool() {
@@ -122,16 +123,33 @@ Pool::Pool(int n) : nt(n), slots(new Slot[n]) {
       Slot& s = slots[t];
       uint32_t seen = 0;
       while (true) {
+        // Wait for the next job.  Inside an analysis (active): spin.  Between analyses the workers park on the condition
+        // variable -- after lingering (still spinning, as OpenMP runtimes do after a parallel region) for PLFEM_POOL_LINGER_MS
+        // if that is set.  Workers woken from a condition variable come up on idle cores (deep C-state, cold caches): measured
+        // on the MI355X host, the analysis of C1 takes 3.7 ms that way against 2.85 ms back to back.  But lingering is OFF by
+        // default: the GPU boxes give a process a CPU QUOTA (16 cores per GPU), and 15 + 7 workers spinning through the 17 ms
+        // of GPU work between two cold solves exhaust it -- the kernel then throttles the whole process for the rest of the
+        // accounting period: every third step of the bench took 50 ms instead of 21 (measured with a linger of 30 ms).
+        clk::time_point idle_since{};
+        bool idle = false;
         for (int spins = 0; s.seq.load(std::memory_order_acquire) == seen; ++spins) {
-          if (!active.load(std::memory_order_acquire) && spins > 256) {
-            std::unique_lock<std::mutex> lk(mu);
-            cv.wait(lk, [&] { return active.load(std::memory_order_acquire) || stop.load(std::memory_order_acquire); });
-            if (stop.load(std::memory_order_acquire)) return;
-            spins = 0;
+          if (stop.load(std::memory_order_acquire)) return;
+          if (active.load(std::memory_order_acquire)) {
+            if (idle) { idle = false; spins = 0; }
+            cpu_relax(spins);
             continue;
           }
+          if (spins <= 256) { __builtin_ia32_pause(); continue; }     // (the owner may be about to post the last jobs)
+          if (!idle) { idle = true; idle_since = clk::now(); }
+          if (linger_ms > 0 && ((spins & 1023) != 0 || secs(idle_since, clk::now()) * 1e3 < linger_ms)) {
+            __builtin_ia32_pause();
+            continue;
+          }
+          std::unique_lock<std::mutex> lk(mu);
+          cv.wait(lk, [&] { return active.load(std::memory_order_acquire) || stop.load(std::memory_order_acquire); });
           if (stop.load(std::memory_order_acquire)) return;
-          cpu_relax(spins);
+          idle = false;
+          spins = 0;
         }
         seen = s.seq.load(std::memory_order_acquire);
         try {
@@ -897,8 +915,8 @@ std::string build_fronts(Symbolic& S, int nthreads) {
   {
     // Leaf fronts from the ELEMENT side, one leaf per task: the nodes of a leaf's elements (6 per element, ~130 in all),
     // sorted and made unique, split into owned and boundary nodes -- ascending lists by construction -- and the position of
-    // every (element, local node) pair in them (epos) by binary search.  The leaves are independent: no counters shared
-    // between threads, one pass, everything a task touches fits its L1.  (Round 3 walked the NODES twice with per-thread
+    // every (element, local node) pair in them (epos) through a per-thread node -> position table.  The leaves are
+    // independent: no counters shared between threads, one pass.  (Round 3 walked the NODES twice with per-thread
     // cursors inside every leaf list: 0.55-0.85 ms of the analysis of C1 against ~0.15 ms this way.)
     LevelBuf& lb = lv[L];
     lb.off.assign((size_t)nleaf + 1, 0);
@@ -909,6 +927,9 @@ std::string build_fronts(Symbolic& S, int nthreads) {
     constexpr int LB = 8;                          // leaves per task
     parallel_tasks((nleaf + LB - 1) / LB, nthreads, [&](int task) {
       std::vector<int32_t> nodes;
+      // node -> position in this leaf's lists; only entries written for the current leaf are ever read (no clearing)
+      static thread_local rawvec_i32 pos_of;
+      if ((int)pos_of.size() < N) pos_of.resize(N);
       for (int lf = task * LB; lf < std::min(nleaf, (task + 1) * LB); ++lf) {
         const int e0 = S.leaf_elem_ptr[lf], e1 = S.leaf_elem_ptr[lf + 1];
         nodes.clear();
@@ -925,8 +946,8 @@ std::string build_fronts(Symbolic& S, int nthreads) {
         int32_t* bnd = lb.bnd.data() + lb.off[lf];
         int no = 0, nb = 0;
         for (int32_t i : nodes) {
-          if (S.owner[i] == leaf0 + lf) own[no++] = i;
-          else bnd[nb++] = i;
+          if (S.owner[i] == leaf0 + lf) { pos_of[i] = no; own[no++] = i; }
+          else { pos_of[i] = -2 - nb; bnd[nb++] = i; }       // (boundary positions are offset by the padded owned count below)
         }
         S.fs_true[leaf0 + lf] = no;
         S.fb_true[leaf0 + lf] = nb;
@@ -937,8 +958,8 @@ std::string build_fronts(Symbolic& S, int nthreads) {
             const int32_t i = ed[(size_t)a * ne + e];
             int32_t pos = -1;                      // Dirichlet node
             if (!S.bmask[i]) {
-              if (S.owner[i] == leaf0 + lf) pos = (int32_t)(std::lower_bound(own, own + no, i) - own);
-              else pos = pad + (int32_t)(std::lower_bound(bnd, bnd + nb, i) - bnd);
+              const int32_t pp = pos_of[i];
+              pos = pp >= 0 ? pp : pad + (-2 - pp);
             }
             S.epos[(size_t)a * ne + e] = pos;
           }
@@ -1072,6 +1093,17 @@ std::string build_fronts(Symbolic& S, int nthreads) {
 }
 
 }  // namespace
+
+void host_parallel(int nthreads, const std::function<void(int, int)>& f) {
+  if (nthreads <= 1) { f(0, 1); return; }
+  struct Lease {
+    Pool* pool;
+    explicit Lease(int n) : pool(pool_acquire(n)) { pool->begin(); }
+    ~Lease() { pool->end(); pool_release(pool); }
+  } lease(nthreads);
+  TeamScope whole(lease.pool, 0, nthreads);
+  team_run([&](int rank) { f(rank, nthreads); });
+}
 
 std::string numbering_only(int nv, int ne, const double* p, const int32_t* t, Symbolic& S) {
   if (nv < 3 || ne < 1) return "empty mesh";

@@ -10,6 +10,7 @@
 //     complete binary tree of dense frontal matrices.
 #pragma once
 #include <cstdint>
+#include <functional>
 #include <memory>
 #include <string>
 #include <vector>
@@ -96,6 +97,11 @@ std::string build_symbolic(int nv, int ne, const double* p, const int32_t* t, in
 // Host copy of the CSR column lists (sorted union of the DOFs of the elements adjacent to each node); no-op
 // if already built.  Not thread-safe against concurrent first calls on the same Symbolic.
 void ensure_pattern(const Symbolic& S);
+
+// f(rank, nthreads) on nthreads threads (the caller is rank 0) of a worker pool from the process-wide cache of idle pools
+// the analysis uses -- for short host-side bursts outside the analysis (the staging copy of plfem_create), which would
+// otherwise pay a thread creation per helper.
+void host_parallel(int nthreads, const std::function<void(int, int)>& f);
 
 // P2 numbering only (fills nv..int_index of S): what uniform red refinement needs, since the refined
 // mesh's vertices are exactly the P2 nodes of the coarse mesh (new vertex id = nv + edge id).

@@ -281,30 +281,31 @@ class TrueVectorialMaxwellSolver:
             ctx.close()
             ent["ctx"] = None
 
+        # The per-mode scalars of solver_fem.py:205-225 for all k pairs at once (the same IEEE operations as the reference's
+        # scalar NumPy arithmetic; 22 x a dozen NumPy scalar calls cost 0.3 ms of a 21-ms solve when done one by one)
         n_core, n_clad = g.n_core, g.n_clad
-        modes_raw = []
-        for i in range(len(evals)):
-            b2 = float(evals[i])
-            if b2 <= 0:
-                continue
-            beta = np.sqrt(b2)
+        b2 = np.asarray(evals, dtype=np.float64)
+        with np.errstate(invalid="ignore", divide="ignore"):
+            beta = np.sqrt(np.where(b2 > 0, b2, 0.0))
             ne_ = beta / self.k0
-            if ne_ <= n_clad or ne_ >= n_core * 1.01:
-                continue
-            div_energy, cx, cy, ax, ay = post[i, 1], post[i, 2], post[i, 3], post[i, 4], post[i, 5]
-            div_ratio = float(div_energy / max(b2, 1e-12))
-            conf_raw = float((cx + cy) / (ax + ay))
+            keep = (b2 > 0) & ~((ne_ <= n_clad) | (ne_ >= n_core * 1.01))          # :208, :210
+            div_ratio = post[:, 1] / np.maximum(b2, 1e-12)                             # :214
+            cx, cy, ax, ay = post[:, 2], post[:, 3], post[:, 4], post[:, 5]
+            conf = (cx + cy) / (ax + ay)
             # _polarization_from_interp (solver_fem.py:88-107); whole-domain fallback if no core DOF
-            if frac_core > 0:
-                P_x, P_y = float(cx) + 1e-30, float(cy) + 1e-30
-            else:
-                P_x, P_y = float(ax) + 1e-30, float(ay) + 1e-30
-            PDL = float(np.clip(10.0 * np.log10(max(P_x, P_y) / min(P_x, P_y)), 0.0, 50.0))
+            P_x, P_y = ((cx, cy) if frac_core > 0 else (ax, ay))
+            P_x, P_y = P_x + 1e-30, P_y + 1e-30
+            PDL = np.clip(10.0 * np.log10(np.maximum(P_x, P_y) / np.minimum(P_x, P_y)), 0.0, 50.0)
+            ratio = P_x / P_y
+        cols = [c.tolist() for c in (ne_, beta, P_x, P_y, PDL, ratio, conf, div_ratio)]
+        modes_raw = []
+        for i in np.nonzero(keep)[0].tolist():
+            conf_raw = cols[6][i]
             modes_raw.append(ModeDict({
-                "n_eff": float(ne_), "beta": float(beta),
+                "n_eff": cols[0][i], "beta": cols[1][i],
                 "Ex_dofs": vecs[i, :N_solve], "Ey_dofs": vecs[i, N_solve:],
-                "P_x": P_x, "P_y": P_y, "PDL_dB": PDL, "polarization": _classify(P_x / P_y),
-                "confinement": conf_raw, "core_overlap": conf_raw, "div_ratio": div_ratio,
+                "P_x": cols[2][i], "P_y": cols[3][i], "PDL_dB": cols[4][i], "polarization": _classify(cols[5][i]),
+                "confinement": conf_raw, "core_overlap": conf_raw, "div_ratio": cols[7][i],
                 "is_vectorial": True, "method": "H-field_V18.10"}))
         # beta_sq: the n_req eigenvalues as the eigen-solver returned them (ascending), before the reference's filters
         self.last_stats = dict(st, sigma=sigma, n_req=n_req, ncv=ncv, N=sym.N, N_solve=N_solve, n=2 * N_solve,

@@ -3,35 +3,42 @@
 #   profiles/<tag>_bench_line.json     the bench line of a plain run (with the CPU baseline)
 #   profiles/<tag>_kernel_stats.csv    rocprofv3 --kernel-trace --stats of `bench.py --steps 3 --warmup 1`
 #   profiles/<tag>_levels_*.txt        per-level sweep table / per-level factorisation table from that kernel trace
-#   profiles/<tag>_pmc_families.json   FETCH_SIZE / WRITE_SIZE per kernel family (separate --pmc passes) + MFMA counters
+#   profiles/<tag>_pmc_families_L<L>.json   FETCH_SIZE / WRITE_SIZE per kernel family (separate --pmc passes) + MFMA counters,
+#                                      one file per ladder rung L = 1 (C1), 0, 2: bench.py reads the file of ITS workload
 #   profiles/<tag>_ladder.json         bench.py --ladder (BASELINE configs[2]: L = 0, 1, 2)
 #   profiles/<tag>_sweep_1gpu.json     bench.py --sweep on one GPU (BASELINE configs[3]), 1 / 2 / 4 lanes
 #   profiles/<tag>_lane_overlap.txt    kernel-trace summary of the 4-lane sweep (how many kernels overlap, per HW queue)
 # usage: gpu_profile_round.sh <tag>      (outputs land in gpurun_out/profiles_<tag>/ for copying into profiles/)
 set -e
-TAG=${1:-r03}
+TAG=${1:-r04}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/profiles_$TAG
 rm -rf $OUT gpurun_out/prof_stats gpurun_out/prof_fetch gpurun_out/prof_write gpurun_out/prof_mfma gpurun_out/prof_lanes && mkdir -p $OUT
-python3 bench.py > $OUT/bench_full.log 2>&1
-grep '^{' $OUT/bench_full.log > $OUT/${TAG}_bench_line.json
-echo "bench line done"
 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_stats -o st --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/bench_under_rocprof.log 2>&1
 cp gpurun_out/prof_stats/st_kernel_stats.csv $OUT/${TAG}_kernel_stats.csv
 python3 scripts/level_roofline.py gpurun_out/prof_stats/st_kernel_trace.csv > $OUT/${TAG}_levels_solve.txt
 python3 scripts/factor_levels.py gpurun_out/prof_stats/st_kernel_trace.csv > $OUT/${TAG}_levels_factor.txt
 rm -rf gpurun_out/prof_stats
 echo "kernel stats done"
-rocprofv3 --pmc FETCH_SIZE -d gpurun_out/prof_fetch -o f --output-format csv -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline > $OUT/bench_fetch.log 2>&1
-echo "fetch pass done"
-rocprofv3 --pmc WRITE_SIZE -d gpurun_out/prof_write -o w --output-format csv -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline > $OUT/bench_write.log 2>&1
-echo "write pass done"
-rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES -d gpurun_out/prof_mfma -o m --output-format csv -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline > $OUT/bench_mfma.log 2>&1 || echo "mfma pass failed"
-MF=gpurun_out/prof_mfma/m_counter_collection.csv
-[ -f $MF ] || MF=-
-python3 scripts/pmc_families.py gpurun_out/prof_fetch/f_counter_collection.csv gpurun_out/prof_write/w_counter_collection.csv $MF $OUT/${TAG}_pmc_families.json | tee $OUT/pmc_families.txt
+for L in 1 0 2; do
+  rm -rf gpurun_out/prof_fetch gpurun_out/prof_write gpurun_out/prof_mfma
+  rocprofv3 --pmc FETCH_SIZE -d gpurun_out/prof_fetch -o f --output-format csv -- python3 bench.py --levels $L --steps 1 --warmup 1 --no-cpu-baseline > $OUT/bench_fetch_L$L.log 2>&1
+  echo "fetch pass L=$L done"
+  rocprofv3 --pmc WRITE_SIZE -d gpurun_out/prof_write -o w --output-format csv -- python3 bench.py --levels $L --steps 1 --warmup 1 --no-cpu-baseline > $OUT/bench_write_L$L.log 2>&1
+  echo "write pass L=$L done"
+  MF=-
+  if [ $L = 1 ]; then
+    rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES -d gpurun_out/prof_mfma -o m --output-format csv -- python3 bench.py --levels $L --steps 1 --warmup 1 --no-cpu-baseline > $OUT/bench_mfma.log 2>&1 || echo "mfma pass failed"
+    [ -f gpurun_out/prof_mfma/m_counter_collection.csv ] && MF=gpurun_out/prof_mfma/m_counter_collection.csv
+  fi
+  python3 scripts/pmc_families.py gpurun_out/prof_fetch/f_counter_collection.csv gpurun_out/prof_write/w_counter_collection.csv $MF $OUT/${TAG}_pmc_families_L$L.json | tee $OUT/pmc_families_L$L.txt
+done
 rm -rf gpurun_out/prof_fetch gpurun_out/prof_write gpurun_out/prof_mfma
+cp $OUT/${TAG}_pmc_families_L*.json profiles/     # (on the box: the bench lines below read the traffic of THIS round's passes)
 echo "pmc done"
+python3 bench.py --cpu-all-cores > $OUT/bench_full.log 2>&1
+grep '^{' $OUT/bench_full.log > $OUT/${TAG}_bench_line.json
+echo "bench line done"
 python3 bench.py --ladder --steps 5 --warmup 2 > $OUT/ladder.log 2>&1
 grep '^{' $OUT/ladder.log > $OUT/${TAG}_ladder.json
 echo "ladder done"
