@@ -80,7 +80,8 @@ int plfem_symbolic_info(const plfem_symbolic* sym, int64_t* info /* [PLFEM_INFO_
  * (node -> adjacent elements), "edges"[2][nedges] i32,
  * "leaf_of_elem"[ne] i32, "owner"[N] i32, "fs","fb"[nfronts] i32, "fnode_ptr","foff"[nfronts+1] i64, "soff"[nfronts] i64
  * (foff: kept part of a front = [F11; F21] m x s2 then Z^T s2 x b2; soff: its Schur complement inside the level's arena),
- * "fnodes","cinv0","cinv1"[fnode_ptr[nfronts]] i32, "epos"[6][ne] i32.
+ * "fnodes","cinv0","cinv1"[fnode_ptr[nfronts]] i32, "epos"[6][ne] i32 (by element id), "epos_leaf"[ne][6] i32 (in the order of
+ * "leaf_elems": what the device reads).
  * plfem_symbolic_array_bytes returns the size in bytes or a negative error. */
 int64_t plfem_symbolic_array_bytes(const plfem_symbolic* sym, const char* name);
 int plfem_symbolic_get(const plfem_symbolic* sym, const char* name, void* out_host, int64_t nbytes);

@@ -48,7 +48,7 @@ PROF_SLOTS = ("k_fwd", "fwd_sweep", "bwd_sweep", "spmv_b")
 _ARRAY_DTYPES = {
     "edof": np.int32, "tsorted": np.int32, "edges": np.int32, "doflocs": np.float64, "bmask": np.uint8,
     "interior": np.int32, "int_index": np.int32, "rowptr": np.int32, "colind": np.int32, "slot_row": np.int32,
-    "nptr": np.int32, "nadj": np.int32, "nloc": np.uint8, "leaf_of_elem": np.int32, "leaf_elem_ptr": np.int32, "leaf_elems": np.int32, "epos": np.int32,
+    "nptr": np.int32, "nadj": np.int32, "nloc": np.uint8, "leaf_of_elem": np.int32, "leaf_elem_ptr": np.int32, "leaf_elems": np.int32, "epos": np.int32, "epos_leaf": np.int32,
     "owner": np.int32, "fs": np.int32, "fb": np.int32, "fs_true": np.int32, "fb_true": np.int32,
     "fnode_ptr": np.int64, "fnodes": np.int32, "cinv0": np.int32, "cinv1": np.int32, "foff": np.int64, "soff": np.int64, "prow": np.int32, "npos": np.int32,
 }

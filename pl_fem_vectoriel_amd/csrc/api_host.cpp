@@ -107,7 +107,15 @@ bool lookup(const Symbolic& S, const char* name, ArrayRef& r) {
   else if (n == "leaf_of_elem") r = aref(S.leaf_of_elem);
   else if (n == "leaf_elem_ptr") r = aref(S.leaf_elem_ptr);
   else if (n == "leaf_elems") r = aref(S.leaf_elems);
-  else if (n == "epos") r = aref(S.epos);
+  else if (n == "epos") {                       // by element id, [6][ne] (the analysis keeps it in leaf order)
+    if (S.epos_by_elem.size() != S.epos.size()) {
+      S.epos_by_elem.resize(S.epos.size());
+      for (int q = 0; q < S.ne; ++q)
+        for (int a = 0; a < 6; ++a) S.epos_by_elem[(size_t)a * S.ne + S.leaf_elems[q]] = S.epos[(size_t)q * 6 + a];
+    }
+    r = aref(S.epos_by_elem);
+  }
+  else if (n == "epos_leaf") r = aref(S.epos);
   else if (n == "owner") r = aref(S.owner);
   else if (n == "fs") r = aref(S.fs);
   else if (n == "fb") r = aref(S.fb);

@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) void k_leaf_assemble(
       val[t] = 0.0;
       if (worker && t < nb) {
         const int e = leaf_elems[q0 + t];
-        const int pa = epos[(size_t)a * ne + e], pb = epos[(size_t)b * ne + e];
+        const int pa = epos[(size_t)(q0 + t) * 6 + a], pb = epos[(size_t)(q0 + t) * 6 + b];    // (leaf order: [ne][6])
         const double* em = elem + (size_t)e * ELEM_STRIDE + a * 6 + b;
         double v = em[blk_a * 36];
         if (diag_blk) v -= sigma * em[PLFEM_BLK_MINV * 36];

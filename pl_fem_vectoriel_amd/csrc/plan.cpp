@@ -3,12 +3,13 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <functional>
 
 #include "symbolic.h"
 
 namespace plfem {
 
-void build_launch_plan(const Symbolic& S, LaunchPlan& P) {
+void build_launch_plan(const Symbolic& S, LaunchPlan& P, const std::function<void(const std::function<void()>&, const std::function<void()>&)>& run2) {
   const int nf = S.nfronts, L = S.L, dpn = S.dpn;
   // per-front DOF counts + level table
   P.fs2.resize(nf);
@@ -40,7 +41,6 @@ void build_launch_plan(const Symbolic& S, LaunchPlan& P) {
   std::vector<int32_t>& forder = P.forder;
   P.forder_s2.assign(nf, 0);
   P.forder_maxm.assign(nf, 0);
-  std::vector<Tile> blk;
   const int mix_big_s2 = getenv("PLFEM_MIX_BIG_S2") ? atoi(getenv("PLFEM_MIX_BIG_S2")) : MIX_BIG_S2;   // (tuning aid)
   {
     std::vector<int32_t> bucket;
@@ -60,6 +60,15 @@ void build_launch_plan(const Symbolic& S, LaunchPlan& P) {
       }
       li.fwd_rows = fwd_block_rows(li.count);
       li.bwd_rows = bwd_block_rows(li.count, lev == L);
+    }
+  }
+  // the two families of lists are independent of one another (both follow the launch order above): side by side when the
+  // caller offers a second thread
+  auto sweep_lists = [&] {
+    std::vector<Tile> blk;
+    for (int lev = 0; lev <= L; ++lev) {
+      LevelInfo& li = P.levels[lev];
+      const int32_t* o = forder.data() + li.first;
       li.fwd_off = (int64_t)blk.size();
       for (int q = 0; q < li.count; ++q) {
         const int f = o[q];
@@ -80,7 +89,6 @@ void build_launch_plan(const Symbolic& S, LaunchPlan& P) {
       }
       li.bwd_n = (int)(blk.size() - li.bwd_off);
     }
-  }
   P.jobs.resize(blk.size());
   for (size_t q = 0; q < P.jobs.size(); ++q) {
     const int f = blk[q].x;
@@ -91,9 +99,10 @@ void build_launch_plan(const Symbolic& S, LaunchPlan& P) {
     const int f = forder[q];
     P.frec[q] = FrontRec{f, fm[f], fs2[f], 0, S.foff[f], S.fnode_ptr[f]};
   }
+  };
   // 64 x 64 tile lists of the factorisation kernels: only workgroups with work are launched (a dense
   // (tiles of the largest front)^2 x fronts grid is 85-90 % empty workgroups, which cost ~3 ns each)
-  {
+  auto tile_lists = [&] {
     auto cdiv = [](int a, int b) { return (a + b - 1) / b; };
     // pass 0 counts, pass 1 fills
     int64_t ntiles = 0;
@@ -175,7 +184,9 @@ void build_launch_plan(const Symbolic& S, LaunchPlan& P) {
       P.mirrorx_all_n = (int)(pos - P.mirrorx_all_off);
       ntiles = pos;
     }
-  }
+  };
+  if (run2) run2(sweep_lists, tile_lists);
+  else { sweep_lists(); tile_lists(); }
   // panel / block-row scratch of the factorisation: one tree level is in flight at a time, so these are sized by the
   // level with the most (padded) nodes and addressed relative to the level's first front (launch_factor)
   int64_t level_nodes = 0;

@@ -4,6 +4,7 @@
 // lists) and shared by every device context on that analysis; plfem_create only uploads it.  Host-only header (no HIP).
 #pragma once
 #include <cstdint>
+#include <functional>
 #include <vector>
 
 namespace plfem {
@@ -79,6 +80,8 @@ struct LaunchPlan {
   int64_t level_nodes_max = 0;         // sum of (padded) nodes over the fronts of one tree level, largest level
   int32_t worst_m = 0;                 // largest front order (LDS staging limit of the sweeps)
 };
-void build_launch_plan(const Symbolic& S, LaunchPlan& P);
+// run2 (may be empty): runs its two arguments side by side (the analysis lends a second thread)
+void build_launch_plan(const Symbolic& S, LaunchPlan& P,
+                       const std::function<void(const std::function<void()>&, const std::function<void()>&)>& run2 = {});
 
 }  // namespace plfem

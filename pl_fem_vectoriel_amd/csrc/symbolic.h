@@ -61,7 +61,9 @@ struct Symbolic {
   std::vector<int32_t> leaf_of_elem;   // [ne]
   std::vector<int32_t> leaf_elem_ptr;  // [2^L + 1]
   std::vector<int32_t> leaf_elems;     // [ne] element ids grouped by leaf
-  rawvec_i32 epos;                     // [6][ne] local node index of each element node in its leaf front, -1 = Dirichlet
+  rawvec_i32 epos;                     // [ne][6] in the order of leaf_elems: local node index of node a of element leaf_elems[q] in its
+                                       // leaf front at epos[6 q + a], -1 = Dirichlet
+  mutable rawvec_i32 epos_by_elem;     // [6][ne] the same by element id (built on demand: plfem_symbolic_get("epos"))
   std::vector<int32_t> fs, fb;         // [nfronts] padded (to 16 / dpn nodes = 16 DOFs) counts of owned / boundary nodes
   std::vector<int32_t> fs_true, fb_true;
   std::vector<int64_t> fnode_ptr;      // [nfronts+1] offsets into fnodes/cinv*
