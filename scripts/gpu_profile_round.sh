@@ -20,28 +20,13 @@ python3 scripts/level_roofline.py gpurun_out/prof_stats/st_kernel_trace.csv > $O
 python3 scripts/factor_levels.py gpurun_out/prof_stats/st_kernel_trace.csv > $OUT/${TAG}_levels_factor.txt
 rm -rf gpurun_out/prof_stats
 echo "kernel stats done"
-for L in 1 0 2; do
-  rm -rf gpurun_out/prof_fetch gpurun_out/prof_write gpurun_out/prof_mfma
-  rocprofv3 --pmc FETCH_SIZE -d gpurun_out/prof_fetch -o f --output-format csv -- python3 bench.py --levels $L --steps 1 --warmup 1 --no-cpu-baseline > $OUT/bench_fetch_L$L.log 2>&1
-  echo "fetch pass L=$L done"
-  rocprofv3 --pmc WRITE_SIZE -d gpurun_out/prof_write -o w --output-format csv -- python3 bench.py --levels $L --steps 1 --warmup 1 --no-cpu-baseline > $OUT/bench_write_L$L.log 2>&1
-  echo "write pass L=$L done"
-  MF=-
-  if [ $L = 1 ]; then
-    rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES -d gpurun_out/prof_mfma -o m --output-format csv -- python3 bench.py --levels $L --steps 1 --warmup 1 --no-cpu-baseline > $OUT/bench_mfma.log 2>&1 || echo "mfma pass failed"
-    [ -f gpurun_out/prof_mfma/m_counter_collection.csv ] && MF=gpurun_out/prof_mfma/m_counter_collection.csv
-  fi
-  python3 scripts/pmc_families.py gpurun_out/prof_fetch/f_counter_collection.csv gpurun_out/prof_write/w_counter_collection.csv $MF $OUT/${TAG}_pmc_families_L$L.json | tee $OUT/pmc_families_L$L.txt
-done
-rm -rf gpurun_out/prof_fetch gpurun_out/prof_write gpurun_out/prof_mfma
+bash scripts/gpu_pmc_round.sh $TAG > $OUT/pmc_round.log 2>&1      # (PMC passes per ladder rung + the ladder lines that read them)
+tail -4 $OUT/pmc_round.log
 cp $OUT/${TAG}_pmc_families_L*.json profiles/     # (on the box: the bench lines below read the traffic of THIS round's passes)
 echo "pmc done"
 python3 bench.py --cpu-all-cores > $OUT/bench_full.log 2>&1
 grep '^{' $OUT/bench_full.log > $OUT/${TAG}_bench_line.json
 echo "bench line done"
-python3 bench.py --ladder --steps 5 --warmup 2 > $OUT/ladder.log 2>&1
-grep '^{' $OUT/ladder.log > $OUT/${TAG}_ladder.json
-echo "ladder done"
 : > $OUT/${TAG}_sweep_1gpu.json
 for L in 1 2 4; do
   python3 bench.py --sweep --steps 2 --warmup 1 --lanes $L > $OUT/sweep_$L.log 2>&1

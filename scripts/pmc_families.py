@@ -18,8 +18,8 @@ import sys
 
 FAMILIES = [
     # name, kernel regex, marker regex (one dispatch per unit), unit
-    ("forward sweep (k_fwd, k_fwd_mix, k_fwd_rows)", r"k_fwd(_mix|_rows)?<4", r"k_permute_out<4", "block solve (P = 4)"),
-    ("backward sweep (k_bwd, k_bwd_rows)", r"k_bwd(_rows)?<4", r"k_permute_out<4", "block solve (P = 4)"),
+    ("forward sweep (k_fwd, k_fwd_mix, k_fwd_rows)", r"k_fwd(_mix|_rows)?<4", r"k_permute_out<4|k_permute_dot_first<4", "block solve (P = 4)"),
+    ("backward sweep (k_bwd, k_bwd_rows)", r"k_bwd(_rows)?<4", r"k_permute_out<4|k_permute_dot_first<4", "block solve (P = 4)"),
     ("k_fwd / k_fwd_mix (tile-form forward levels)", r"k_fwd(_mix)?<4", None, "launch"),
     ("k_bwd_rows", r"k_bwd_rows<4", None, "launch"),
     ("k_bwd (leaf level)", r"k_bwd<4", None, "launch"),
@@ -52,7 +52,7 @@ def matched_names(name, pattern):
     """Distinct kernel names a family's regex matched (argument lists cut off): bench.py refuses the file when one of them
     is no longer in the built library (the counters were then collected on other code)."""
     pat = re.compile(pattern)
-    return sorted({re.sub(r"^void ", "", n).split("(")[0].replace("plfem::(anonymous namespace)::", "") for n in name.values() if pat.search(n)})
+    return sorted({re.sub(r"^void ", "", n).replace("plfem::(anonymous namespace)::", "").split("(")[0] for n in name.values() if pat.search(n)})
 
 
 def main():
