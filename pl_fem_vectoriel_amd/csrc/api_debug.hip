@@ -51,6 +51,10 @@ extern "C" int plfem_debug_set_perturb(plfem_ctx* c, double value) {
 extern "C" int plfem_debug_factor_until(plfem_ctx* c, double sigma, int32_t level, int32_t step, int32_t stage) {
   if (!c) return PLFEM_EINVAL;
   if (!c->assembled) { c->err = "debug factor before assemble"; return PLFEM_ESTATE; }
+  if (c->upload_pending) {               // (as plfem_factor: the front-level index arrays travel on the copy stream)
+    HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_upload, 0));
+    c->upload_pending = false;
+  }
   plfem::launch_factor(c, sigma, level, step, stage);
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   return check_launch(c, "debug factor");

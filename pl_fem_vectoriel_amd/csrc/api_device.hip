@@ -179,21 +179,26 @@ int upload(plfem_ctx* c, std::vector<UploadItem>& items, T** dst, const std::vec
 // sent in a few pieces, so that the DMA of one piece runs while the host fills the next (filling 14 MB takes about as long
 // as sending them: 0.28 + 0.25 ms in sequence at C1, round 3); the filling runs on a worker pool of the host analysis
 // (parked threads from the process-wide cache: no thread creation here).
-int flush_uploads(plfem_ctx* c, const std::vector<UploadItem>& items, size_t span, char* staging) {
+int flush_uploads(plfem_ctx* c, const std::vector<UploadItem>& items, size_t span, char* staging, size_t mesh_items) {
   size_t total = 0;
   for (const auto& it : items) total += it.bytes;
   const int nthreads = total > (4u << 20) ? 8 : 1;
   const int npieces = total > (2u << 20) ? 4 : 1;
   // pieces = runs of consecutive items (they are in slab order) of about total / npieces bytes
+  // (the first piece = the mesh-level arrays, sent on the context's stream; the others follow on the copy stream)
   std::vector<size_t> first(1, 0);
+  if (mesh_items > 0 && mesh_items < items.size()) first.push_back(mesh_items);
   {
-    size_t acc = 0;
-    for (size_t q = 0; q < items.size(); ++q) {
-      if ((int)first.size() < npieces && acc >= total * first.size() / npieces && q > first.back()) first.push_back(q);
+    size_t acc = 0, rest = 0;
+    for (size_t q = first.back(); q < items.size(); ++q) rest += items[q].bytes;
+    const size_t q0 = first.back(), base = first.size();
+    for (size_t q = q0; q < items.size(); ++q) {
+      if ((int)first.size() < npieces && acc >= rest * (first.size() - base + 1) / (npieces - base + 1) && q > first.back()) first.push_back(q);
       acc += items[q].bytes;
     }
     first.push_back(items.size());
   }
+  const bool split = c->copy_stream != nullptr && mesh_items > 0 && mesh_items < items.size();
   // the helpers run through the pieces on their own; the calling thread (rank 0) sends a piece as soon as every thread
   // has filled its share of it.  A share = a contiguous byte range of the piece (items are cut where a range ends).
   const size_t npc = first.size() - 1;
@@ -217,9 +222,13 @@ int flush_uploads(plfem_ctx* c, const std::vector<UploadItem>& items, size_t spa
       const size_t q0 = first[pc], q1 = first[pc + 1];
       if (q0 == q1 || herr != hipSuccess) continue;
       const size_t plo = items[q0].off, phi = q1 < items.size() ? items[q1].off : span;
-      herr = hipMemcpyAsync(c->slab + plo, staging + plo, phi - plo, hipMemcpyHostToDevice, c->stream);
+      herr = hipMemcpyAsync(c->slab + plo, staging + plo, phi - plo, hipMemcpyHostToDevice, (split && pc > 0) ? c->copy_stream : c->stream);
     }
   });
+  if (herr == hipSuccess && split) {
+    herr = hipEventRecord(c->ev_upload, c->copy_stream);
+    c->upload_pending = true;              // (plfem_factor, the first reader of the front-level arrays, waits for it)
+  }
   if (herr != hipSuccess) {
     c->err = std::string("hipMemcpyAsync (index upload): ") + hipGetErrorString(herr);
     return PLFEM_EHIP;
@@ -243,6 +252,7 @@ int check_launch(plfem_ctx* c, const char* what) {
 }
 
 void free_all(plfem_ctx* c) {
+  if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);   // (the tail of the index upload reads the staging block)
   if (c->own_slab && c->slab) (void)hipFree(c->slab);
   if (c->h_pinned) pinned_release(c->h_pinned, c->h_pinned_bytes);
   if (c->h_staging) {
@@ -260,6 +270,7 @@ void free_all(plfem_ctx* c) {
     c->copy_stream = nullptr;
   }
   ctx_event_release(c->device, 1, c->ev_copy);
+  ctx_event_release(c->device, 1, c->ev_upload);
 }
 
 static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
@@ -275,6 +286,8 @@ int create_impl(plfem_ctx* c, const plfem_symbolic* sym, int device, void* strea
     for (int q = 0; q < 6; ++q)
       for (int r = 0; r < 2; ++r) HIP_TRY(c, ctx_event_acquire(device, 0, &c->ev[q][r]));
     for (int r = 0; r < 2; ++r) HIP_TRY(c, ctx_event_acquire(device, 1, &c->ev_step[r]));
+    HIP_TRY(c, ctx_event_acquire(device, 1, &c->ev_upload));
+    HIP_TRY(c, copy_stream_acquire(device, &c->copy_stream));
     HIP_TRY(c, hipEventRecord(c->ev[4][0], c->stream));
   }
   c->nv = S.nv; c->ne = S.ne; c->N = S.N; c->nnz = S.rowptr.empty() ? 0 : (int)S.rowptr[S.N]; c->nsolve = S.nsolve;
@@ -311,14 +324,12 @@ int create_impl(plfem_ctx* c, const plfem_symbolic* sym, int device, void* strea
   const double tt0 = now_ms();
   const double tt1 = now_ms();
   std::vector<UploadItem> items;
-  size_t upload_span = 0;
+  size_t upload_span = 0, mesh_items = 0;
   auto place = [&]() -> int {
   c->slab_off = 0;
   items.clear();
-  TRY(upload(c, items, &c->d_blk, P.jobs));
-  TRY(upload(c, items, reinterpret_cast<plfem::Tile**>(&c->d_tiles), P.tiles));   // (Tile has int2's layout)
-  TRY(upload(c, items, &c->d_forder, P.forder));
-  TRY(upload(c, items, &c->d_frec, P.frec));
+  // mesh-level arrays first: all that the CSR pattern kernel and the assembly read.  They go up on the context's stream,
+  // the front-level arrays behind them on the copy stream, so that pattern and assembly run beside the rest of the upload
   TRY(upload(c, items, &c->d_edof, S.edof));
   c->d_tsorted = c->d_edof;          // rows 0-2 of the element DOF table ARE the column-sorted vertex table
   TRY(upload(c, items, &c->d_rowptr, S.rowptr));
@@ -328,6 +339,11 @@ int create_impl(plfem_ctx* c, const plfem_symbolic* sym, int device, void* strea
   TRY(upload(c, items, &c->d_interior, S.interior));
   TRY(upload(c, items, &c->d_bmask, S.bmask));
   TRY(upload(c, items, &c->d_doflocs, S.doflocs));
+  mesh_items = items.size();
+  TRY(upload(c, items, &c->d_blk, P.jobs));
+  TRY(upload(c, items, reinterpret_cast<plfem::Tile**>(&c->d_tiles), P.tiles));   // (Tile has int2's layout)
+  TRY(upload(c, items, &c->d_forder, P.forder));
+  TRY(upload(c, items, &c->d_frec, P.frec));
   TRY(upload(c, items, &c->d_fs2, P.fs2));
   TRY(upload(c, items, &c->d_fm, P.fm));
   TRY(upload(c, items, &c->d_fnode_ptr, S.fnode_ptr));
@@ -416,7 +432,7 @@ int create_impl(plfem_ctx* c, const plfem_symbolic* sym, int device, void* strea
   HIP_TRY(c, pinned_acquire(upload_span, &staging, &staging_bytes));
   c->h_staging = staging;               // owned by the context from here on: released with it (free_all), so that
   c->h_staging_bytes = staging_bytes;   // creation does not have to wait for the copy
-  TRY(flush_uploads(c, items, upload_span, reinterpret_cast<char*>(staging)));
+  TRY(flush_uploads(c, items, upload_span, reinterpret_cast<char*>(staging), mesh_items));
   const double tt3 = now_ms();
   HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, 4 * sizeof(int32_t), c->stream));
   // the padding rows of the front-ordered right-hand side are never written and are multiplied by exact zeros of the
@@ -436,6 +452,15 @@ int create_impl(plfem_ctx* c, const plfem_symbolic* sym, int device, void* strea
   // later use of the context is ordered behind them on the stream)
   if (ctx_trace) fprintf(stderr, "[ctx] lists %.3f  size pass %.3f  upload pass %.3f  pinned+launch %.3f  sync %.3f ms\n", tt1 - tt0, tt2 - tt1, tt3 - tt2, tt4 - tt3, now_ms() - tt4);
   c->ev_used[4] = true;
+  return PLFEM_OK;
+}
+
+// the front-level index arrays travel on the copy stream (flush_uploads): their first reader orders the context's stream
+// behind them
+int wait_for_upload(plfem_ctx* c) {
+  if (!c->upload_pending) return PLFEM_OK;
+  HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_upload, 0));
+  c->upload_pending = false;
   return PLFEM_OK;
 }
 
@@ -607,6 +632,7 @@ extern "C" int plfem_factor(plfem_ctx* c, double sigma) {
   if (!c) return PLFEM_EINVAL;
   if (!c->assembled) { c->err = "plfem_factor before plfem_assemble_hfield"; return PLFEM_ESTATE; }
   HIP_TRY(c, hipSetDevice(c->device));
+  TRY(wait_for_upload(c));
   HIP_TRY(c, hipEventRecord(c->ev[1][0], c->stream));
   HIP_TRY(c, hipMemsetAsync(c->d_fvec, 0, sizeof(double) * 2 * c->fnodes_total * plfem::BLOCK_P, c->stream));   // (see plfem_create)
   plfem::launch_factor(c, sigma);

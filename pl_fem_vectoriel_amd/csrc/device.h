@@ -90,6 +90,8 @@ struct plfem_ctx {
   bool defer_sync = false;        // plfem_solve_modes: the Lanczos drivers leave their final stream synchronisation to it
   hipStream_t copy_stream = nullptr;   // plfem_solve_modes: side stream of the device-to-host copy of the mode vectors
   hipEvent_t ev_copy = nullptr;        // "mode vectors ready" (main stream -> copy stream)
+  hipEvent_t ev_upload = nullptr;      // "front-level index arrays uploaded" (copy stream -> main stream)
+  bool upload_pending = false;
   // live kernel timing (plfem_profile_*): event pairs around every tile-form forward-sweep launch
   bool prof_on = false;
   unsigned prof_toggle = 0;       // block solves alternate between timing whole sweeps and timing single launches

@@ -52,9 +52,11 @@ FnRef fn_ref(F& f) {
 struct Pool {
   struct alignas(128) Slot {
     std::atomic<uint32_t> seq{0};       // bumped by the dispatcher when a job is posted
+    std::atomic<uint32_t> taken{0};     // = seq once somebody has claimed the job: the worker, or the leader in its stead
     std::atomic<uint32_t> ack{0};       // = seq once the job is done
     FnRef fn;
     int rank = 0, team_first = 0, team_count = 1;
+    bool stealable = false;             // (a plain share of a parallel loop: whoever runs it, the result is the same)
   };
   const int nt;
   std::unique_ptr<Slot[]> slots;
@@ -92,14 +94,33 @@ struct Pool {
     }
     if (e) std::rethrow_exception(e);
   }
-  void post(int thread, FnRef fn, int rank, int team_first, int team_count) {
+  void post(int thread, FnRef fn, int rank, int team_first, int team_count, bool stealable) {
     Slot& s = slots[thread];
-    s.fn = fn; s.rank = rank; s.team_first = team_first; s.team_count = team_count;
+    s.fn = fn; s.rank = rank; s.team_first = team_first; s.team_count = team_count; s.stealable = stealable;
     s.seq.store(s.seq.load(std::memory_order_relaxed) + 1, std::memory_order_release);
   }
+  // Leader side.  A member that has not STARTED its share yet -- still waking from its condition variable after 17 ms of
+  // GPU work, or pushed off its core by another tenant of the shared host -- does not hold the team up: the leader claims
+  // the share and runs it itself (the share is a function of the rank alone, so the result is the same); only a member
+  // that is in the middle of its share has to be waited for.
   void join(int thread) {
     Slot& s = slots[thread];
     const uint32_t want = s.seq.load(std::memory_order_relaxed);
+    if (s.ack.load(std::memory_order_acquire) == want) return;
+    if (s.stealable) {
+      uint32_t expect = want - 1;
+      if (s.taken.compare_exchange_strong(expect, want, std::memory_order_acq_rel)) {
+        try {
+          s.fn.call(s.fn.obj, s.rank);
+        } catch (...) {                  // (join runs inside a destructor: recorded like a worker's, rethrown by rethrow())
+          std::lock_guard<std::mutex> lk(mu);
+          if (!error) error = std::current_exception();
+          failed.store(true, std::memory_order_release);
+        }
+        s.ack.store(want, std::memory_order_release);
+        return;
+      }
+    }
     for (int spins = 0; s.ack.load(std::memory_order_acquire) != want; ++spins) cpu_relax(spins);
   }
 };
@@ -152,6 +173,10 @@ Pool::Pool(int n) : nt(n), slots(new Slot[n]) {
           spins = 0;
         }
         seen = s.seq.load(std::memory_order_acquire);
+        {
+          uint32_t expect = seen - 1;
+          if (!s.taken.compare_exchange_strong(expect, seen, std::memory_order_acq_rel)) continue;   // the leader ran it
+        }
         try {
           TeamScope scope(this, s.team_first, s.team_count);
           s.fn.call(s.fn.obj, s.rank);
@@ -223,14 +248,13 @@ void team_run(F&& f) {
   if (!T.pool || T.count <= 1) { f(0); return; }
   auto body = [&](int rank) { f(rank); };
   FnRef ref = fn_ref(body);
-  for (int r = 1; r < T.count; ++r) T.pool->post(T.first + r, ref, r, T.first + r, 1);
-  struct Join {                          // the members reference this frame: join them on every way out
-    const TeamCtx& T;
-    ~Join() { for (int r = 1; r < T.count; ++r) T.pool->join(T.first + r); }
-  };
+  for (int r = 1; r < T.count; ++r) T.pool->post(T.first + r, ref, r, T.first + r, 1, true);
   {
-    Join join{T};
-    TeamScope alone(T.pool, T.first, 1);
+    TeamScope alone(T.pool, T.first, 1);   // (also while the leader runs shares it claimed from members that had not started)
+    struct Join {                          // the members reference this frame: join them on every way out
+      const TeamCtx& T;
+      ~Join() { for (int r = 1; r < T.count; ++r) T.pool->join(T.first + r); }
+    } join{T};
     f(0);
   }
   T.pool->rethrow();
@@ -244,7 +268,7 @@ void team_fork2(int count_a, FA&& fa, FB&& fb) {
   auto body = [&](int) { fb(); };
   FnRef ref = fn_ref(body);
   const int mid = T.first + count_a;
-  T.pool->post(mid, ref, 0, mid, T.count - count_a);
+  T.pool->post(mid, ref, 0, mid, T.count - count_a, false);   // (the other half needs its own leader: never claimed back)
   struct Join {
     Pool* pool; int mid;
     ~Join() { pool->join(mid); }
@@ -929,12 +953,11 @@ std::string build_fronts(Symbolic& S, int nthreads) {
     {
       const int32_t* ed = S.edof.data();
       parallel_for(ne, nthreads, [&](int64_t b, int64_t e_, int) {
-        for (int a = 0; a < 6; ++a) {
-          const int32_t* row = ed + (size_t)a * ne;
-          for (int64_t e = b; e < e_; ++e) ed6[(size_t)e * 6 + a] = row[e];
-        }
+        for (int64_t e = b; e < e_; ++e)
+          for (int a = 0; a < 6; ++a) ed6[(size_t)e * 6 + a] = ed[(size_t)a * ne + e];      // six read streams, one write stream
       });
     }
+    tr.lap("fronts: leaves (transpose)");
     constexpr int LB = 8;                          // leaves per task
     parallel_tasks((nleaf + LB - 1) / LB, nthreads, [&](int task) {
       std::vector<int32_t> nodes;
