@@ -831,17 +831,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   }
 }
 
-// lower(F11) = L11^-1 from its transpose in the upper triangle, once the front is factorised: the block row k (rows
-// [k0, k0 + 32), columns < k0) of one front per workgroup, 32 x 32 tiles through LDS.  job = (front, kb).
-__global__ __launch_bounds__(256) void k_mirror_x(const int2* __restrict__ jobs, const int32_t* __restrict__ fs2,
-                                                  const int32_t* __restrict__ fm, const int64_t* __restrict__ foff,
-                                                  double* __restrict__ front) {
-  const int2 job = jobs[blockIdx.x];
+// ---- after the LDL^T of a front: what only the solve sweeps read --------------------------------------------------------
+// ONE launch (round 4; rounds 2-3: k_form_z, k_mirror_z, k_mirror_x: 0.40 ms at C1, the fronts' 0.3 GB of Z written and read
+// once more than necessary) with two kinds of workgroups:
+//  * Z = L21 L11^-1 (with Z in place of L21 the forward sweep of a front is ONE product [L11^-1; Z] r and the backward sweep
+//    ONE product [L11^-1; -Z]^T [D^-1 y; x_b]), written IN PLACE over L21 and, transposed (s2 x b2, leading dimension s2),
+//    behind [F11; F21].  In place works because a workgroup owns a 64-row block of Z and takes its columns in ASCENDING
+//    order: Z[:, c] = sum_{j >= c} L21[:, j] Linv[j, c] needs the columns j >= c of L21 only, so what has been overwritten
+//    (columns < c) is never read again; inside a step of 64 columns the four waves (2 row halves x 2 column halves, a 32 x 32
+//    tile each on v_mfma_f64_16x16x4_f64) finish their reads before a barrier and write behind it.  The tile goes through
+//    LDS on its way into F21, so that both copies leave in runs of 128 B or more.
+//  * lower(F11) = L11^-1 from its transpose in the upper triangle (the factorisation keeps X^T there): the block row k (rows
+//    [k0, k0 + 32), columns < k0) of one front per workgroup, 32 x 32 tiles through LDS.  job = (front, kb).
+// The Z workgroups read the upper triangle of F11, the others write the lower one: independent.
+__device__ __forceinline__ void mirror_x_block(const int2 job, const int32_t* __restrict__ fs2, const int32_t* __restrict__ fm,
+                                               const int64_t* __restrict__ foff, double* __restrict__ front,
+                                               double (*tile)[33]) {
   const int f = job.x, k0 = job.y * NB;
   const int m = fm[f], s2 = fs2[f];
   const int nbk = min(NB, s2 - k0);
   double* F = front + foff[f];
-  __shared__ double tile[32][33];
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
   for (int c0 = 0; c0 < k0; c0 += 32) {
     for (int yy = ty; yy < 32; yy += 8)                     // X^T: column k0 + yy, rows c0 + tx (contiguous)
@@ -853,83 +862,74 @@ __global__ __launch_bounds__(256) void k_mirror_x(const int2* __restrict__ jobs,
   }
 }
 
-// ---- Z = L21 L11^-1 (formed once per front after its LDL^T): with Z in place of L21 the forward
-// sweep of a front is ONE product [L11^-1; Z] r and the backward sweep ONE product [L11^-1; -Z]^T [D^-1 y; x_b].
-// Z^T (s2 x b2) is written behind [F11; F21] (F21 = L21 and the upper mirror of L11^-1 are only read), 32x32 tile per
-// wave on v_mfma_f64_16x16x4_f64; k_mirror_z then copies it back into F21.
-__global__ __launch_bounds__(256) void k_form_z(const int2* __restrict__ tiles, const int32_t* __restrict__ fs2,
-                                                const int32_t* __restrict__ fm, const int64_t* __restrict__ foff,
-                                                double* __restrict__ front) {
-  const int2 job = tiles[blockIdx.x];                    // (front, tx | ty << 16): 64 x 64 entries of Z
-  const int f = job.x;
+__global__ __launch_bounds__(256) void k_form_z_mirror(const int2* __restrict__ jobs, int nz, const int32_t* __restrict__ fs2,
+                                                       const int32_t* __restrict__ fm, const int64_t* __restrict__ foff,
+                                                       double* __restrict__ front) {
+  __shared__ double lds[4][32][33];
+  const int2 job = jobs[blockIdx.x];
+  if ((int)blockIdx.x >= nz) {
+    mirror_x_block(job, fs2, fm, foff, front, lds[0]);
+    return;
+  }
+  const int f = job.x;                                   // (front, 64-row block of Z)
   const int m = fm[f], s2 = fs2[f];
   const int b2 = m - s2;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int b0 = ((job.y & 0xffff) * 2 + (wave & 1)) * 32;     // rows of Z (boundary DOFs)
-  const int c0 = ((job.y >> 16) * 2 + (wave >> 1)) * 32;       // columns of Z (owned DOFs)
-  if (b0 >= b2 || c0 >= s2) return;
+  const int b0 = (job.y * 2 + (wave & 1)) * 32;          // rows of Z (boundary DOFs) of this wave
+  const bool rows_on = b0 < b2;
   double* F = front + foff[f];
-  const int lr = lane & 15, lk = lane >> 4;
-  const bool bv1 = b0 + 16 < b2, cv1 = c0 + 16 < s2;
-  v4d acc[2][2];
-  for (int tb = 0; tb < 2; ++tb)
-    for (int tc = 0; tc < 2; ++tc) acc[tb][tc] = (v4d){0.0, 0.0, 0.0, 0.0};
-  // Z[b, c] = sum_{j >= c} L21[b, j] Linv[j, c];  A <- L21 rows (contiguous in b), B <- Linv via the upper mirror
-  // s2 - c0 is a multiple of 16: four k-steps (16 loads) are requested before their MFMAs
-  const int cA = c0 + lr, cB = c0 + 16 + lr;
-  for (int j0 = c0; j0 < s2; j0 += 16) {
-    double a0[4], a1[4], x0[4], x1[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const int j = j0 + 4 * t + lk;
-      a0[t] = F[(int64_t)j * m + s2 + b0 + lr];
-      a1[t] = bv1 ? F[(int64_t)j * m + s2 + b0 + 16 + lr] : 0.0;
-      x0[t] = (j >= cA) ? F[(int64_t)j * m + cA] : 0.0;
-      x1[t] = (cv1 && j >= cB) ? F[(int64_t)j * m + cB] : 0.0;
-    }
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[t], x0[t], acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[t], x1[t], acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[t], x0[t], acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[t], x1[t], acc[1][1], 0, 0, 0);
-    }
-  }
-  // D[row = b (lk + 4r)][col = c (lr)] -> Z^T[c, b] at FZ[c + b s2] (FZ: s2 x b2 behind [F11; F21]): lanes lr contiguous
   double* FZ = F + (int64_t)m * s2;
-  for (int tb = 0; tb < 2; ++tb) {
-    if (tb == 1 && !bv1) continue;
-    for (int tc = 0; tc < 2; ++tc) {
-      if (tc == 1 && !cv1) continue;
+  const int lr = lane & 15, lk = lane >> 4;
+  const bool bv1 = b0 + 16 < b2;
+  double (*tile)[33] = lds[wave];
+  for (int cstep = 0; cstep < s2; cstep += 64) {
+    const int c0 = cstep + 32 * (wave >> 1);             // columns of Z (owned DOFs) of this wave in this step
+    const bool on = rows_on && c0 < s2;
+    const bool cv1 = c0 + 16 < s2;
+    v4d acc[2][2];
+    for (int tb = 0; tb < 2; ++tb)
+      for (int tc = 0; tc < 2; ++tc) acc[tb][tc] = (v4d){0.0, 0.0, 0.0, 0.0};
+    if (on) {
+      // Z[b, c] = sum_{j >= c} L21[b, j] Linv[j, c];  A <- L21 rows (contiguous in b), B <- Linv via the upper mirror
+      // s2 - c0 is a multiple of 16: four k-steps (16 loads) are requested before their MFMAs
+      const int cA = c0 + lr, cB = c0 + 16 + lr;
+      for (int j0 = c0; j0 < s2; j0 += 16) {
+        double a0[4], a1[4], x0[4], x1[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-        FZ[(int64_t)(b0 + 16 * tb + lk + 4 * r) * s2 + (c0 + 16 * tc + lr)] = acc[tb][tc][r];
+        for (int t = 0; t < 4; ++t) {
+          const int j = j0 + 4 * t + lk;
+          a0[t] = F[(int64_t)j * m + s2 + b0 + lr];
+          a1[t] = bv1 ? F[(int64_t)j * m + s2 + b0 + 16 + lr] : 0.0;
+          x0[t] = (j >= cA) ? F[(int64_t)j * m + cA] : 0.0;
+          x1[t] = (cv1 && j >= cB) ? F[(int64_t)j * m + cB] : 0.0;
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[t], x0[t], acc[0][0], 0, 0, 0);
+          acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[t], x1[t], acc[0][1], 0, 0, 0);
+          acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[t], x0[t], acc[1][0], 0, 0, 0);
+          acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[t], x1[t], acc[1][1], 0, 0, 0);
+        }
+      }
+      // D[row = b (lk + 4r)][col = c (lr)]: the tile into LDS as tile[c][b] for the in-place copy, and Z^T[c, b] at
+      // FZ[c + b s2] straight from the registers (lanes lr contiguous)
+      for (int tb = 0; tb < 2; ++tb)
+        for (int tc = 0; tc < 2; ++tc)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int bb = 16 * tb + lk + 4 * r, cc = 16 * tc + lr;
+            tile[cc][bb] = acc[tb][tc][r];
+            if ((tb == 0 || bv1) && (tc == 0 || cv1)) FZ[(int64_t)(b0 + bb) * s2 + (c0 + cc)] = acc[tb][tc][r];
+          }
     }
-  }
-}
-
-// F21[b, c] = Z^T[c, b] through a 32x32 LDS tile
-__global__ __launch_bounds__(256) void k_mirror_z(const int2* __restrict__ tiles, const int32_t* __restrict__ fs2,
-                                                  const int32_t* __restrict__ fm, const int64_t* __restrict__ foff,
-                                                  double* __restrict__ front) {
-  // one 64 x 64 entry of the k_form_z list = four 32 x 32 tiles, blockIdx.y picks one
-  const int2 job = tiles[blockIdx.x];
-  const int f = job.x;
-  const int m = fm[f], s2 = fs2[f];
-  const int b2 = m - s2;
-  const int b0 = ((job.y & 0xffff) * 2 + (blockIdx.y & 1)) * 32, c0 = ((job.y >> 16) * 2 + (blockIdx.y >> 1)) * 32;
-  if (b0 >= b2 || c0 >= s2) return;
-  __shared__ double tile[32][33];
-  double* F = front + foff[f];
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
-  for (int yy = ty; yy < 32; yy += 8) {
-    int c = c0 + tx, b = b0 + yy;
-    tile[yy][tx] = (c < s2 && b < b2) ? F[(int64_t)m * s2 + (int64_t)b * s2 + c] : 0.0;       // Z^T[c, b]
-  }
-  __syncthreads();
-  for (int yy = ty; yy < 32; yy += 8) {
-    int b = b0 + tx, c = c0 + yy;
-    if (b < b2 && c < s2) F[(int64_t)c * m + s2 + b] = tile[tx][yy];               // Z[b, c]
+    __syncthreads();          // every wave of the block has read the columns of L21 it needs: now they may be overwritten
+    if (on) {
+      // Z[b, c] -> F[c m + s2 + b]: 32 consecutive rows b per column c (lane = b, two columns per pass)
+      const int bb = lane & 31;
+#pragma unroll 4
+      for (int cc = lane >> 5; cc < 32; cc += 2)
+        if (b0 + bb < b2 && c0 + cc < s2) F[(int64_t)(c0 + cc) * m + s2 + b0 + bb] = tile[cc][bb];
+    }
   }
 }
 
@@ -1044,28 +1044,16 @@ void launch_factor(plfem_ctx* c, double sigma, int stop_level, int stop_step, in
                            dinv_nxt, c->d_delta, wb, rb, wb_prev, rb_prev, wb_next, rb_next, c->d_counters);
       if (stop_here && (stop_stage == 3 || stop_stage == 4)) return;
     }
-    if (stop_level >= 0) {                             // (debug run that stops after a level: its Z and lower(F11) now)
-      if (li.formz_n > 0) {
-        const int2* zt = c->d_tiles + li.formz_off;
-        hipLaunchKernelGGL(k_form_z, dim3(li.formz_n), dim3(256), 0, st, zt, c->d_fs2, c->d_fm, c->d_foff, c->d_front);
-        hipLaunchKernelGGL(k_mirror_z, dim3(li.formz_n, 4), dim3(256), 0, st, zt, c->d_fs2, c->d_fm, c->d_foff, c->d_front);
-      }
-      if (li.mirrorx_n > 0)
-        hipLaunchKernelGGL(k_mirror_x, dim3(li.mirrorx_n), dim3(256), 0, st, c->d_tiles + li.mirrorx_off, c->d_fs2, c->d_fm,
-                           c->d_foff, c->d_front);
-    }
+    if (stop_level >= 0 && li.formz_n + li.mirrorx_n > 0)     // (debug run that stops after a level: its Z and lower(F11) now)
+      hipLaunchKernelGGL(k_form_z_mirror, dim3(li.formz_n + li.mirrorx_n), dim3(256), 0, st, c->d_tiles + li.formz_off, li.formz_n,
+                         c->d_fs2, c->d_fm, c->d_foff, c->d_front);
     if (lev == stop_level && stop_stage == 5) return;
   }
-  // Z = L21 L11^-1 and its mirror, and lower(F11) = the mirror of upper(F11), for every front at once: only the solve
-  // sweeps read them (k_form_z itself reads the upper triangle)
-  if (stop_level < 0 && c->formz_all_n > 0) {
-    const int2* zt = c->d_tiles + c->formz_all_off;
-    hipLaunchKernelGGL(k_form_z, dim3(c->formz_all_n), dim3(256), 0, st, zt, c->d_fs2, c->d_fm, c->d_foff, c->d_front);
-    hipLaunchKernelGGL(k_mirror_z, dim3(c->formz_all_n, 4), dim3(256), 0, st, zt, c->d_fs2, c->d_fm, c->d_foff, c->d_front);
-  }
-  if (stop_level < 0 && c->mirrorx_all_n > 0)
-    hipLaunchKernelGGL(k_mirror_x, dim3(c->mirrorx_all_n), dim3(256), 0, st, c->d_tiles + c->mirrorx_all_off, c->d_fs2, c->d_fm,
-                       c->d_foff, c->d_front);
+  // Z = L21 L11^-1 (in place and transposed) and lower(F11) = the mirror of upper(F11), for every front at once: only the
+  // solve sweeps read them (the two job lists are adjacent in d_tiles: Z blocks first)
+  if (stop_level < 0 && c->formz_all_n + c->mirrorx_all_n > 0)
+    hipLaunchKernelGGL(k_form_z_mirror, dim3(c->formz_all_n + c->mirrorx_all_n), dim3(256), 0, st, c->d_tiles + c->formz_all_off,
+                       c->formz_all_n, c->d_fs2, c->d_fm, c->d_foff, c->d_front);
 }
 
 }  // namespace plfem

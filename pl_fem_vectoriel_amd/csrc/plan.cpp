@@ -115,19 +115,19 @@ void build_launch_plan(const Symbolic& S, LaunchPlan& P, const std::function<voi
       P.upd_off.clear();
       P.upd_n.clear();
       int64_t pos = 0;
-      auto rect = [&](int f, int ntx, int nty) {         // ntx x nty blocks of front f, x fastest
-        if (out)
-          for (int ty = 0; ty < nty; ++ty)
-            for (int tx = 0; tx < ntx; ++tx) out[pos++] = Tile{f, tx | (ty << 16)};
-        else
-          pos += (int64_t)ntx * nty;
-      };
       auto lower = [&](int f, int nt) {                  // blocks tx >= ty of an nt x nt square (symmetric trailing matrix)
         if (out)
           for (int ty = 0; ty < nt; ++ty)
             for (int tx = ty; tx < nt; ++tx) out[pos++] = Tile{f, tx | (ty << 16)};
         else
           pos += (int64_t)nt * (nt + 1) / 2;
+      };
+      auto z_blocks = [&](int f) {                       // (f, tb) for the 64-row blocks of Z = rows of F21 (k_form_z_mirror)
+        for (int tb = 0; tb < cdiv(fm[f] - fs2[f], 64); ++tb) {
+          if (fs2[f] == 0) break;
+          if (out) out[pos] = Tile{f, tb};
+          ++pos;
+        }
       };
       auto block_rows = [&](int f) {                     // (f, kb) for the block rows kb >= 1 of F11, last (longest) first
         for (int kb = cdiv(fs2[f], NB) - 1; kb >= 1; --kb) {
@@ -158,7 +158,7 @@ void build_launch_plan(const Symbolic& S, LaunchPlan& P, const std::function<voi
           P.upd_n.push_back((int)(pos - P.upd_off.back()));
         }
         li.formz_off = pos;
-        for (int q = 0; q < li.count; ++q) rect(o[q], cdiv(fm[o[q]] - fs2[o[q]], 64), cdiv(fs2[o[q]], 64));
+        for (int q = 0; q < li.count; ++q) z_blocks(o[q]);
         li.formz_n = (int)(pos - li.formz_off);
         li.mirrorx_off = pos;
         for (int q = 0; q < li.count; ++q) block_rows(o[q]);
@@ -171,7 +171,7 @@ void build_launch_plan(const Symbolic& S, LaunchPlan& P, const std::function<voi
       for (int lev = 0; lev <= L; ++lev) {
         const LevelInfo& li = P.levels[lev];
         const int32_t* o = forder.data() + li.first;
-        for (int q = 0; q < li.count; ++q) rect(o[q], cdiv(fm[o[q]] - fs2[o[q]], 64), cdiv(fs2[o[q]], 64));
+        for (int q = 0; q < li.count; ++q) z_blocks(o[q]);
       }
       P.formz_all_n = (int)(pos - P.formz_all_off);
       // block rows >= 1 of every F11 (k_mirror_x), largest first within a level

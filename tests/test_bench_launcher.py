@@ -90,3 +90,36 @@ def test_only_a_rendezvous_failure_is_retried():
     if not torch.cuda.is_available():
         res = _run("--gpus", "2", "--steps", "1", "--warmup", "0", env=env)
         assert res.returncode != 0 and "retrying" not in res.stderr and "bench.py needs a GPU" in res.stderr
+
+
+def test_pmc_summaries_are_keyed_by_rung_and_checked_against_the_library(tmp_path, monkeypatch):
+    """bench.py read C1's PMC file for every ladder rung (traffic ratios of 5.9 and 0.23), and
+    nothing noticed when the committed counters no longer belonged to the code.  pmc_for_levels takes the file of ITS rung,
+    latest round first, and refuses one whose kernel regexes / counted kernels are not in the built library."""
+    sys.path.insert(0, ROOT)
+    import bench
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    fam = lambda regex, names: {"families": {"k_spmv_b_block": {"regex": regex, "hbm_bytes": 5.0e7, "kernel_names": names}}, "mfma": {}}
+    (prof / "r09_pmc_families_L2.json").write_text(json.dumps(fam("k_spmv_b_block", ["k_spmv_b_block_il<4, 2>"])))
+    (prof / "r10_pmc_families_L2.json").write_text(json.dumps(fam("k_kernel_that_is_gone", [])))
+    (prof / "r11_pmc_families_L2.json").write_text(json.dumps(fam("k_spmv_b_block", ["k_spmv_b_block_old<4>"])))
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    monkeypatch.setattr(bench, "library_kernel_names", lambda: ["k_spmv_b_block_il<4, 2>(int, long, int const*)", "k_fwd<4, 4>(SweepArgs)"])
+    fams, _mfma, path, check = bench.pmc_for_levels(2)
+    assert path.endswith("r09_pmc_families_L2.json") and check == "ok" and fams["k_spmv_b_block"]["hbm_bytes"] == 5.0e7
+    fams, _mfma, path, check = bench.pmc_for_levels(0)          # no pass for this rung: null, never another rung's bytes
+    assert fams == {} and path is None and "no PMC pass" in check
+    (prof / "r09_pmc_families_L2.json").unlink()
+    fams, _mfma, path, check = bench.pmc_for_levels(2)          # only stale files left: refused, with the reason
+    assert fams == {} and path is None and ("is not in the built library" in check or "matches no kernel" in check)
+    # the committed files of this repository against the library that is built here: accepted with their families, or
+    # refused with a reason and NO traffic (a kernel was renamed since the passes were collected: scripts/gpu_pmc_round.sh)
+    monkeypatch.undo()
+    for levels in (0, 1, 2):
+        fams, _mfma, path, check = bench.pmc_for_levels(levels)
+        if path is not None:
+            assert check.startswith("ok") and len(fams) >= 8, (levels, path, check)
+        else:
+            assert fams == {} and isinstance(check, str) and check, (levels, check)
+            print(f"rung L = {levels}: committed PMC summary refused ({check}): bench.py reports traffic: null until it is regenerated")
