@@ -402,7 +402,9 @@ int create_impl(plfem_ctx* c, const plfem_symbolic* sym, int device, void* strea
   c->npartial = (int)((c->n2 + plfem::PANEL_CHUNK - 1) / plfem::PANEL_CHUNK);
   TRY(dalloc(c, &c->d_h, nc1 + 8));
   TRY(dalloc(c, &c->d_hacc, nc1 + 8));
-  TRY(dalloc(c, &c->d_partial, (size_t)c->npartial * (nc1 + 8) * plfem::BLOCK_P));
+  // (also the Gram partials of the fused block B product: P x P entries x one partial per workgroup of 32 rows)
+  TRY(dalloc(c, &c->d_partial, std::max((size_t)c->npartial * (nc1 + 8) * plfem::BLOCK_P,
+                                        (size_t)plfem::BLOCK_P * plfem::BLOCK_P * (((size_t)S.N * 8 + 255) / 256) + 64)));
   TRY(dalloc(c, &c->d_scal, 16));
   TRY(dalloc(c, &c->d_S, nc1 * nc1));
   TRY(dalloc(c, &c->d_Hcols, (nc1 + 1) * (nc1 + 1)));
@@ -753,10 +755,11 @@ static int lanczos_block(plfem_ctx* c, int k, int ncv, double tol, int maxiter, 
     plfem::launch_panel_axpy_block(c, c->d_V, nc, c->d_hblk, ld, c->d_w, n, c->d_t1);
     {
       const int pid = plfem::prof_open(c, PLFEM_PROF_SPMV_B, 12.0 * c->nnz + 4.0 * (c->N + 1) + 2.0 * 8.0 * P * (double)n);
-      plfem::launch_spmv_b_block_il(c, c->d_t1, c->d_bw, n);
+      // (the B product also leaves the chunk partials of the Gram matrix W^T B W: no panel-dot launch for the CholQR)
+      const int nparts = plfem::launch_spmv_b_block_il(c, c->d_t1, c->d_bw, n, c->d_partial);
       plfem::prof_close(c, pid);
+      plfem::launch_chol_from_partials(c, nparts, Hblk + nc, ld, c->d_Rinv);          // W^T B W = R^T R, R -> T[nc:nc+P, c0:c0+P]
     }
-    plfem::launch_gram_chol_block(c, c->d_w, c->d_bw, n, Hblk + nc, ld, c->d_Rinv);   // W^T B W = R^T R, R -> T[nc:nc+P, c0:c0+P]
     // the last kernel of the step also stores the new columns and the counters into the pinned slot (no copies)
     plfem::launch_block_scale(c, c->d_w, c->d_bw, n, c->d_Rinv, c->d_V + (size_t)nc * n, c->d_BV + (size_t)nc * n, n,
                               Hblk, ld * P, slots_dev + (size_t)slot * ld * P, hcnt_dev + 4 * slot, c->d_fvec);

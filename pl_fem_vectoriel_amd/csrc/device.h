@@ -145,7 +145,9 @@ void launch_csr_gather(plfem_ctx* c);
 void launch_pattern_fill(plfem_ctx* c);   // colind / slot_row from the node -> element adjacency (once per context)
 void launch_spmv(plfem_ctx* c, int which, const double* x, double* y);
 void launch_spmv_b_block(plfem_ctx* c, const double* x, double* y, int64_t ld);   // y_q = B x_q, BLOCK_P vectors
-void launch_spmv_b_block_il(plfem_ctx* c, const double* x_interleaved, double* y, int64_t ld);   // same, x as [node][component][q]
+// same, x as [node][component][q]; gram != nullptr: also the chunk partials of the Gram matrix x^T (B x), gram[(p P + q) nb + b]
+// for workgroup b of nb (returned)
+int launch_spmv_b_block_il(plfem_ctx* c, const double* x_interleaved, double* y, int64_t ld, double* gram = nullptr);
 void launch_spmv_a_block(plfem_ctx* c, const double* x, double* y, int64_t ld);   // y_q = A x_q, BLOCK_P vectors
 // out_host[i] = ||A v_i - lambda_i B v_i|| / ||A v_i||  (k vectors, row i of evecs; synchronises)
 void launch_residuals(plfem_ctx* c, int k, const double* lam_host, const double* evecs, double* out_host);
@@ -176,6 +178,8 @@ void launch_panel_axpy_block(plfem_ctx* c, const double* Pm, int ncols, const do
 void launch_first_pass_block(plfem_ctx* c, const double* BVm, const double* Vm, int ncols, double* W, int64_t ldw, double* Hout, int ldh);
 void launch_mat_add(plfem_ctx* c, int ncols, double* acc, int lda, const double* h, int ldh);
 void launch_gram_chol_block(plfem_ctx* c, const double* W, const double* BW, int64_t ldw, double* Tblk, int ldT, double* Rinv);
+// the Cholesky half alone, from nchunks Gram partials per entry already in d_partial (launch_spmv_b_block_il with gram)
+void launch_chol_from_partials(plfem_ctx* c, int nchunks, double* Tblk, int ldT, double* Rinv);
 void launch_chol_block(plfem_ctx* c, const double* G, int ldg, double* Tblk, int ldT, double* Rinv);
 void launch_block_scale(plfem_ctx* c, const double* W, const double* BW, int64_t ldw, const double* Rinv, double* Vn,
                         double* BVn, int64_t ldv, const double* exp_src = nullptr, int exp_n = 0, double* exp_dst = nullptr,

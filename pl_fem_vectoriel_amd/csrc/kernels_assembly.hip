@@ -376,11 +376,16 @@ __global__ __launch_bounds__(256) void k_spmv_b_block(int N, int64_t ld, const i
 // one 32 P-byte run (64 B for the vectorial pencil) instead of DPN P doubles in DPN P different cache lines.  The
 // Lanczos step gets this layout for free from the orthogonalisation kernel that writes the block (k_panel_axpy_p).
 // Measured at C1: 23.3 -> 19.5 us per launch (HIP events); requesting a lane's three entries together: no faster.
-template <int P, int DPN>
+// GRAM (round 4): the same launch also leaves the chunk partials of the Gram matrix X^T (B X) of the block -- what the
+// CholQR of a block Lanczos step needs next and used to get from a panel-dot launch of its own (8 us at its latency
+// floor): gram[(p P + q) gridDim.x + blockIdx.x] = sum over the workgroup's 32 rows and the components of x[row, p] (B x)[row, q],
+// summed in a fixed order (k_chol_small adds the workgroups' partials).
+template <int P, int DPN, bool GRAM>
 __global__ __launch_bounds__(256) void k_spmv_b_block_il(int N, int64_t ld, const int32_t* __restrict__ rowptr,
                                                          const int32_t* __restrict__ colind,
                                                          const uint8_t* __restrict__ bmask, const double* __restrict__ vm,
-                                                         const double* __restrict__ xi, double* __restrict__ y) {
+                                                         const double* __restrict__ xi, double* __restrict__ y,
+                                                         double* __restrict__ gram) {
   int gt = blockIdx.x * blockDim.x + threadIdx.x;
   int row = gt >> 3, sub = gt & 7;
   double s[DPN * P];
@@ -406,6 +411,38 @@ __global__ __launch_bounds__(256) void k_spmv_b_block_il(int N, int64_t ld, cons
     for (int comp = 0; comp < DPN; ++comp)
 #pragma unroll
       for (int q = 0; q < P; ++q) y[(int64_t)q * ld + (int64_t)comp * N + row] = s[comp * P + q];
+  }
+  if (GRAM) {
+    static_assert(!GRAM || P * P == 16, "two Gram entries per sub-lane");
+    __shared__ double red[4][P * P];
+    // every one of the row's 8 lanes holds (B x)[row] now: lane `sub` takes the entries 2 sub, 2 sub + 1 of the P x P matrix
+    double g[2] = {0.0, 0.0};
+    if (row < N) {
+      const double* xr = xi + (int64_t)row * (DPN * P);
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int idx = 2 * sub + t, p = idx / P, q = idx % P;
+#pragma unroll
+        for (int comp = 0; comp < DPN; ++comp) {
+          double sq = s[comp * P];
+#pragma unroll
+          for (int qq = 1; qq < P; ++qq) sq = (q == qq) ? s[comp * P + qq] : sq;
+          g[t] = fma(xr[comp * P + p], sq, g[t]);
+        }
+      }
+    }
+    // the 8 rows of a wave, then its 4 waves: fixed order
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      g[t] += __shfl_xor(g[t], 8);
+      g[t] += __shfl_xor(g[t], 16);
+      g[t] += __shfl_xor(g[t], 32);
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane < 8) { red[wave][2 * lane] = g[0]; red[wave][2 * lane + 1] = g[1]; }
+    __syncthreads();
+    if ((int)threadIdx.x < P * P)
+      gram[(int64_t)threadIdx.x * gridDim.x + blockIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
   }
 }
 
@@ -522,15 +559,27 @@ void launch_spmv_b_block(plfem_ctx* c, const double* x, double* y, int64_t ld) {
                        c->d_bmask, c->d_vals[PLFEM_BLK_MINV], x, y);
 }
 
-void launch_spmv_b_block_il(plfem_ctx* c, const double* xi, double* y, int64_t ld) {
+// gram != nullptr: also the Gram partials of the block, gram[(p P + q) nblocks + block]; returns the number of workgroups
+// (= partials per entry)
+int launch_spmv_b_block_il(plfem_ctx* c, const double* xi, double* y, int64_t ld, double* gram) {
   int64_t threads = (int64_t)c->N * 8;
   int grid = (int)((threads + 255) / 256);
-  if (c->dpn == 1)
-    hipLaunchKernelGGL((k_spmv_b_block_il<BLOCK_P, 1>), dim3(grid), dim3(256), 0, c->stream, c->N, ld, c->d_rowptr, c->d_colind,
-                       c->d_bmask, c->d_vals[PLFEM_BLK_MINV], xi, y);
-  else
-    hipLaunchKernelGGL((k_spmv_b_block_il<BLOCK_P, 2>), dim3(grid), dim3(256), 0, c->stream, c->N, ld, c->d_rowptr, c->d_colind,
-                       c->d_bmask, c->d_vals[PLFEM_BLK_MINV], xi, y);
+  if (c->dpn == 1) {
+    if (gram)
+      hipLaunchKernelGGL((k_spmv_b_block_il<BLOCK_P, 1, true>), dim3(grid), dim3(256), 0, c->stream, c->N, ld, c->d_rowptr, c->d_colind,
+                         c->d_bmask, c->d_vals[PLFEM_BLK_MINV], xi, y, gram);
+    else
+      hipLaunchKernelGGL((k_spmv_b_block_il<BLOCK_P, 1, false>), dim3(grid), dim3(256), 0, c->stream, c->N, ld, c->d_rowptr, c->d_colind,
+                         c->d_bmask, c->d_vals[PLFEM_BLK_MINV], xi, y, gram);
+  } else {
+    if (gram)
+      hipLaunchKernelGGL((k_spmv_b_block_il<BLOCK_P, 2, true>), dim3(grid), dim3(256), 0, c->stream, c->N, ld, c->d_rowptr, c->d_colind,
+                         c->d_bmask, c->d_vals[PLFEM_BLK_MINV], xi, y, gram);
+    else
+      hipLaunchKernelGGL((k_spmv_b_block_il<BLOCK_P, 2, false>), dim3(grid), dim3(256), 0, c->stream, c->N, ld, c->d_rowptr, c->d_colind,
+                         c->d_bmask, c->d_vals[PLFEM_BLK_MINV], xi, y, gram);
+  }
+  return grid;
 }
 
 void launch_spmv(plfem_ctx* c, int which, const double* x, double* y) {

@@ -781,6 +781,12 @@ void launch_gram_chol_block(plfem_ctx* c, const double* W, const double* BW, int
                      Tblk, ldT, Rinv, c->d_counters);
 }
 
+void launch_chol_from_partials(plfem_ctx* c, int nchunks, double* Tblk, int ldT, double* Rinv) {
+  constexpr int P = BLOCK_P;
+  hipLaunchKernelGGL(k_chol_small<P>, dim3(1), dim3(64 * P * P), 0, c->stream, (const double*)nullptr, 0, c->d_partial, nchunks,
+                     Tblk, ldT, Rinv, c->d_counters);
+}
+
 void launch_block_scale(plfem_ctx* c, const double* W, const double* BW, int64_t ldw, const double* Rinv, double* Vn,
                         double* BVn, int64_t ldv, const double* exp_src, int exp_n, double* exp_dst, int32_t* cnt_dst,
                         double* bv_front) {
