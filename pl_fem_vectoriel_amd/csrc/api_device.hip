@@ -404,7 +404,8 @@ int create_impl(plfem_ctx* c, const plfem_symbolic* sym, int device, void* strea
   TRY(dalloc(c, &c->d_hacc, nc1 + 8));
   // (also the Gram partials of the fused block B product: P x P entries x one partial per workgroup of 32 rows)
   TRY(dalloc(c, &c->d_partial, std::max((size_t)c->npartial * (nc1 + 8) * plfem::BLOCK_P,
-                                        (size_t)plfem::BLOCK_P * plfem::BLOCK_P * (((size_t)S.N * 8 + 255) / 256) + 64)));
+                                        (size_t)plfem::BLOCK_P * plfem::BLOCK_P * (((size_t)S.N * 8 + 255) / 256) + 64 +
+                                            (size_t)8 * plfem::BLOCK_P * (n2 / 256 + 2))));   // (and the fused first pass: 8 columns x P per 512 rows or fewer)
   TRY(dalloc(c, &c->d_scal, 16));
   TRY(dalloc(c, &c->d_S, nc1 * nc1));
   TRY(dalloc(c, &c->d_Hcols, (nc1 + 1) * (nc1 + 1)));

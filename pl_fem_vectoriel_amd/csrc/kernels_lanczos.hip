@@ -209,7 +209,7 @@ __global__ __launch_bounds__(256) void k_panel_axpy_p(int64_t n, int ncols, cons
 // the sweeps' front-order result where k_permute_out would read it, written out in global order, and multiplied with the
 // up to 8 panel columns on the way); k_axpy_first sums the partials in its prologue (32 values x nseg partials, every
 // workgroup for itself in the same fixed order: the same bits everywhere) before it applies the update.
-constexpr int FIRST_ROWS = 1024;       // rows per workgroup of k_permute_dot_first = per partial sum
+constexpr int FIRST_ROWS = 512;        // rows per workgroup of k_permute_dot_first = per partial sum (1024: 177 workgroups for 256 CUs)
 template <int P>
 __global__ __launch_bounds__(256) void k_permute_dot_first(int64_t n2, int N, int nseg, int ncols, const int32_t* __restrict__ npos,
                                                            const double* __restrict__ xl, double* __restrict__ W, int64_t ldw,
@@ -223,24 +223,37 @@ __global__ __launch_bounds__(256) void k_permute_dot_first(int64_t n2, int N, in
   const double* col[CW];
 #pragma unroll
   for (int t = 0; t < CW; ++t) col[t] = Pm + (int64_t)min(t, ncols - 1) * n2;      // (clamped: the result is dropped)
+  // the thread's four rows: every load that does not depend on another is requested first (the index of a row's
+  // front-order slot and its 8 panel entries), then the 16 gathers; a row-by-row loop was a chain of 8 memory round trips
+  constexpr int RPT = FIRST_ROWS / 256;
+  int64_t g[RPT];
+  int pos[RPT];
+  double a[RPT][CW], w[RPT][P];
 #pragma unroll
-  for (int j = 0; j < FIRST_ROWS / 256; ++j) {
-    const int64_t g = (int64_t)seg * FIRST_ROWS + j * 256 + threadIdx.x;
-    if (g >= n2) break;
-    const int c = g >= N, node = (int)(g - (int64_t)c * N);
-    const int pos = npos[node];
-    double a[CW];
+  for (int j = 0; j < RPT; ++j) {
+    g[j] = (int64_t)seg * FIRST_ROWS + j * 256 + threadIdx.x;
+    const bool on = g[j] < n2;
+    const int c = on && g[j] >= N;
+    pos[j] = on ? npos[(int)(g[j] - (int64_t)c * N)] : -1;
 #pragma unroll
-    for (int t = 0; t < CW; ++t) a[t] = col[t][g];
-    double w[P];
+    for (int t = 0; t < CW; ++t) a[j][t] = on ? col[t][g[j]] : 0.0;
+  }
 #pragma unroll
-    for (int q = 0; q < P; ++q) w[q] = pos >= 0 ? xl[((int64_t)pos + c) * P + q] : 0.0;
+  for (int j = 0; j < RPT; ++j) {
+    const int c = g[j] >= N;
 #pragma unroll
-    for (int q = 0; q < P; ++q) W[(int64_t)q * ldw + g] = w[q];
+    for (int q = 0; q < P; ++q) w[j][q] = pos[j] >= 0 ? xl[((int64_t)pos[j] + c) * P + q] : 0.0;
+  }
+#pragma unroll
+  for (int j = 0; j < RPT; ++j) {
+    if (g[j] < n2) {
+#pragma unroll
+      for (int q = 0; q < P; ++q) W[(int64_t)q * ldw + g[j]] = w[j][q];
+    }
 #pragma unroll
     for (int t = 0; t < CW; ++t)
 #pragma unroll
-      for (int q = 0; q < P; ++q) acc[t * P + q] = fma(a[t], w[q], acc[t * P + q]);
+      for (int q = 0; q < P; ++q) acc[t * P + q] = fma(a[j][t], w[j][q], acc[t * P + q]);
   }
 #pragma unroll
   for (int v = 0; v < CW * P; ++v) {
@@ -267,8 +280,18 @@ __global__ __launch_bounds__(256) void k_axpy_first(int64_t n, int ncols, int ns
     // 8 threads per value: thread part p adds partials p, p + 8, ... in order, then a fixed butterfly over the 8 parts
     const int v = threadIdx.x >> 3, part = threadIdx.x & 7;
     double x = 0.0;
-    if (v / P < ncols)
-      for (int k = part; k < nseg; k += 8) x += partial[(int64_t)v * nseg + k];
+    if (v / P < ncols) {
+      const double* pp = partial + (int64_t)v * nseg;
+      int k = part;
+      for (; k + 7 * 8 < nseg; k += 8 * 8) {               // eight loads in flight (a load per add was a chain of ~22 round trips)
+        double t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = pp[k + 8 * u];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) x += t[u];
+      }
+      for (; k < nseg; k += 8) x += pp[k];
+    }
     x += __shfl_xor(x, 1, 8);
     x += __shfl_xor(x, 2, 8);
     x += __shfl_xor(x, 4, 8);
@@ -319,8 +342,18 @@ __global__ __launch_bounds__(64 * P * P) void k_chol_small(const double* __restr
   } else {
     const int lane = threadIdx.x & 63;
     for (int cq = threadIdx.x >> 6; cq < P * P; cq += blockDim.x >> 6) {   // one wave per entry; cq = c P + q  ->  G[c + q ldg]
+      // (up to ~3000 partials per entry since the fused B product delivers them: eight loads in flight per lane, fixed order)
+      const double* pp = partial + (int64_t)cq * nchunks;
       double acc = 0.0;
-      for (int t = lane; t < nchunks; t += 64) acc += partial[(int64_t)cq * nchunks + t];
+      int t = lane;
+      for (; t + 7 * 64 < nchunks; t += 8 * 64) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = pp[t + 64 * u];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += v[u];
+      }
+      for (; t < nchunks; t += 64) acc += pp[t];
       for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
       if (lane == 0) sG[(cq / P) + (cq % P) * P] = acc;
     }
