@@ -241,10 +241,12 @@ def debug_symeig_band(a, b: int, nsel: int):
 
 
 def default_host_threads() -> int:
-    """Workers of the symbolic analysis.  Measured on the MI355X host (256 logical CPUs, C1): 4.3 ms with 8 workers, 4.0
-    with 16, 5.5 with 24 -- so 16 at most, and no more than this process's share of the physical cores when several
-    ranks run on the node (``LOCAL_WORLD_SIZE``, set by torchrun and by ``bench.py --gpus N``): the ranks of a sweep
-    analyse their meshes at the same time."""
+    """Workers of the symbolic analysis.  Measured on the MI355X host (256 logical CPUs, C1, round 4: teams, persistent
+    pools): 3.0 ms with 12 workers, 3.2 with 16, 3.0 with 20, 2.55 with 24, 2.6 with 32; inside the cold-solve loop of
+    ``bench.py`` 20.3 / 20.6 / 20.2 / 19.95 ms per step with 12 / 16 / 20 / 24 -- so 24 at most (round 3: 16), and no more
+    than this process's share of the physical cores when several ranks run on the node (``LOCAL_WORLD_SIZE``, set by
+    torchrun and by ``bench.py --gpus N``): the ranks of a sweep analyse their meshes at the same time.  (The workers spin
+    for the ~3 ms of an analysis only: 24 of them stay far below the 16-CPU quota of a GPU box averaged over a step.)"""
     ncpu = os.cpu_count() or 1
     if ncpu < 64:
         return max(1, min(ncpu, 8))
@@ -252,7 +254,7 @@ def default_host_threads() -> int:
         local_world = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))
     except ValueError:
         local_world = 1
-    return max(2, min(16, (ncpu // 2) // local_world))
+    return max(2, min(24, (ncpu // 2) // local_world))
 
 
 class Symbolic:

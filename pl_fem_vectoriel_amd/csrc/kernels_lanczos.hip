@@ -209,7 +209,7 @@ __global__ __launch_bounds__(256) void k_panel_axpy_p(int64_t n, int ncols, cons
 // the sweeps' front-order result where k_permute_out would read it, written out in global order, and multiplied with the
 // up to 8 panel columns on the way); k_axpy_first sums the partials in its prologue (32 values x nseg partials, every
 // workgroup for itself in the same fixed order: the same bits everywhere) before it applies the update.
-constexpr int FIRST_ROWS = 512;        // rows per workgroup of k_permute_dot_first = per partial sum (1024: 177 workgroups for 256 CUs)
+constexpr int FIRST_ROWS = 1024;       // rows per workgroup of k_permute_dot_first = per partial sum (512 measured: 17.1 + 11.1 us against 15.8 + 9.5)
 template <int P>
 __global__ __launch_bounds__(256) void k_permute_dot_first(int64_t n2, int N, int nseg, int ncols, const int32_t* __restrict__ npos,
                                                            const double* __restrict__ xl, double* __restrict__ W, int64_t ldw,
