@@ -742,7 +742,7 @@ static int lanczos_block(plfem_ctx* c, int k, int ncv, double tol, int maxiter, 
     const int nc = c0_ + P;
     const int lo = (c0_ == cycle_start) ? 0 : std::max(0, nc - 2 * P);
     double* Hblk = c->d_Hcols + (size_t)c0_ * ld;                             // T[0:nc, c0:c0+P] (zero before the step)
-    if (c->refine_steps == 0 && nc - lo <= 8) {
+    if (P == 4 && c->refine_steps == 0 && nc - lo <= 8) {
       // W = OP V_j left in front order by the sweeps; the first pass permutes it on the way (two launches instead of four)
       plfem::launch_solve_block(c, c->d_BV + (size_t)c0_ * n, nullptr, n, il_ready == c0_);
       plfem::launch_first_pass_block(c, c->d_BV + (size_t)lo * n, c->d_V + (size_t)lo * n, nc - lo, c->d_w, n, Hblk + lo, ld);

@@ -413,15 +413,18 @@ __global__ __launch_bounds__(256) void k_spmv_b_block_il(int N, int64_t ld, cons
       for (int q = 0; q < P; ++q) y[(int64_t)q * ld + (int64_t)comp * N + row] = s[comp * P + q];
   }
   if (GRAM) {
-    static_assert(!GRAM || P * P == 16, "two Gram entries per sub-lane");
+    constexpr int GE = P * P / 8;                        // Gram entries per sub-lane (P = 4: two)
+    static_assert(!GRAM || GE * 8 == P * P, "the 8 lanes of a row share the P x P entries");
     __shared__ double red[4][P * P];
-    // every one of the row's 8 lanes holds (B x)[row] now: lane `sub` takes the entries 2 sub, 2 sub + 1 of the P x P matrix
-    double g[2] = {0.0, 0.0};
+    // every one of the row's 8 lanes holds (B x)[row] now: lane `sub` takes the entries GE sub .. GE sub + GE - 1 of the P x P matrix
+    double g[GE];
+#pragma unroll
+    for (int t = 0; t < GE; ++t) g[t] = 0.0;
     if (row < N) {
       const double* xr = xi + (int64_t)row * (DPN * P);
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        const int idx = 2 * sub + t, p = idx / P, q = idx % P;
+      for (int t = 0; t < GE; ++t) {
+        const int idx = GE * sub + t, p = idx / P, q = idx % P;
 #pragma unroll
         for (int comp = 0; comp < DPN; ++comp) {
           double sq = s[comp * P];
@@ -433,13 +436,16 @@ __global__ __launch_bounds__(256) void k_spmv_b_block_il(int N, int64_t ld, cons
     }
     // the 8 rows of a wave, then its 4 waves: fixed order
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
+    for (int t = 0; t < GE; ++t) {
       g[t] += __shfl_xor(g[t], 8);
       g[t] += __shfl_xor(g[t], 16);
       g[t] += __shfl_xor(g[t], 32);
     }
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if (lane < 8) { red[wave][2 * lane] = g[0]; red[wave][2 * lane + 1] = g[1]; }
+    if (lane < 8) {
+#pragma unroll
+      for (int t = 0; t < GE; ++t) red[wave][GE * lane + t] = g[t];
+    }
     __syncthreads();
     if ((int)threadIdx.x < P * P)
       gram[(int64_t)threadIdx.x * gridDim.x + blockIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);

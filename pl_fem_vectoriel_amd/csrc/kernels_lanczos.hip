@@ -333,7 +333,7 @@ __global__ void k_mat_add(int ncols, int P, double* __restrict__ acc, int lda, c
 // G comes either ready-made (G != nullptr) or as the chunk partials of k_panel_dot_p (partial[((c P + q) nchunks +
 // chunk)], summed here in the same fixed order as k_panel_dot_finish_p: one launch less per block step)
 template <int P>
-__global__ __launch_bounds__(64 * P * P) void k_chol_small(const double* __restrict__ G, int ldg, const double* __restrict__ partial,
+__global__ __launch_bounds__(64 * P * P > 1024 ? 1024 : 64 * P * P) void k_chol_small(const double* __restrict__ G, int ldg, const double* __restrict__ partial,
                                                            int nchunks, double* __restrict__ Tblk, int ldT,
                                                            double* __restrict__ Rinv, int32_t* __restrict__ counters) {
   __shared__ double sG[P * P];
@@ -788,11 +788,13 @@ void launch_panel_axpy_block(plfem_ctx* c, const double* Pm, int ncols, const do
 void launch_first_pass_block(plfem_ctx* c, const double* BVm, const double* Vm, int ncols, double* W, int64_t ldw, double* Hout,
                              int ldh) {
   constexpr int P = BLOCK_P;
-  const int nseg = (int)((c->n2 + FIRST_ROWS - 1) / FIRST_ROWS);      // (= npartial: PANEL_CHUNK rows per partial sum)
-  hipLaunchKernelGGL(k_permute_dot_first<P>, dim3(nseg), dim3(256), 0, c->stream, c->n2, c->N, nseg, ncols, c->d_npos, c->d_xl, W, ldw,
-                     BVm, c->d_partial);
-  hipLaunchKernelGGL(k_axpy_first<P>, dim3((unsigned)((c->n2 + 255) / 256)), dim3(256), 0, c->stream, c->n2, ncols, nseg, Vm,
-                     c->d_partial, Hout, ldh, W, ldw);
+  if constexpr (P == 4) {            // (8 columns x P sums per thread: the two kernels are written for P = 4; see lanczos_block)
+    const int nseg = (int)((c->n2 + FIRST_ROWS - 1) / FIRST_ROWS);      // (= npartial: PANEL_CHUNK rows per partial sum)
+    hipLaunchKernelGGL(k_permute_dot_first<P>, dim3(nseg), dim3(256), 0, c->stream, c->n2, c->N, nseg, ncols, c->d_npos, c->d_xl, W, ldw,
+                       BVm, c->d_partial);
+    hipLaunchKernelGGL(k_axpy_first<P>, dim3((unsigned)((c->n2 + 255) / 256)), dim3(256), 0, c->stream, c->n2, ncols, nseg, Vm,
+                       c->d_partial, Hout, ldh, W, ldw);
+  }
 }
 
 void launch_mat_add(plfem_ctx* c, int ncols, double* acc, int lda, const double* h, int ldh) {
@@ -810,13 +812,13 @@ void launch_gram_chol_block(plfem_ctx* c, const double* W, const double* BW, int
   constexpr int P = BLOCK_P;
   const int nchunks = c->npartial;
   hipLaunchKernelGGL(k_panel_dot_p<P>, dim3(nchunks, 1), dim3(256), 0, c->stream, c->n2, P, nchunks, W, BW, ldw, c->d_partial);
-  hipLaunchKernelGGL(k_chol_small<P>, dim3(1), dim3(64 * P * P), 0, c->stream, (const double*)nullptr, 0, c->d_partial, nchunks,
+  hipLaunchKernelGGL(k_chol_small<P>, dim3(1), dim3(std::min(1024, 64 * P * P)), 0, c->stream, (const double*)nullptr, 0, c->d_partial, nchunks,
                      Tblk, ldT, Rinv, c->d_counters);
 }
 
 void launch_chol_from_partials(plfem_ctx* c, int nchunks, double* Tblk, int ldT, double* Rinv) {
   constexpr int P = BLOCK_P;
-  hipLaunchKernelGGL(k_chol_small<P>, dim3(1), dim3(64 * P * P), 0, c->stream, (const double*)nullptr, 0, c->d_partial, nchunks,
+  hipLaunchKernelGGL(k_chol_small<P>, dim3(1), dim3(std::min(1024, 64 * P * P)), 0, c->stream, (const double*)nullptr, 0, c->d_partial, nchunks,
                      Tblk, ldT, Rinv, c->d_counters);
 }
 

@@ -36,7 +36,11 @@ static_assert(sizeof(FrontRec) == 32, "FrontRec layout");
 inline int fwd_block_rows(int count) { return count <= 8 ? 8 : count <= ROW_FORM_MAX_FRONTS ? 16 : 64; }
 // (round 3 re-measured the tile form at the two levels above the leaves: 28.1 / 25.5 us against 22.3 / 21.5 us in row form)
 inline int bwd_block_rows(int count, bool leaf) { return leaf ? 64 : count <= ROW_FORM_MAX_FRONTS ? 8 : 16; }
-constexpr int BLOCK_P = 4;      // right-hand sides per block solve / block Lanczos step
+#ifndef PLFEM_BLOCK_P
+#define PLFEM_BLOCK_P 4             // (-DPLFEM_BLOCK_P=8: the experiment of DESIGN section 11; the product is built and tested with 4)
+#endif
+constexpr int BLOCK_P = PLFEM_BLOCK_P;      // right-hand sides per block solve / block Lanczos step
+static_assert(BLOCK_P == 4 || BLOCK_P == 8, "a power of two: multi_reduce of the row-form sweeps");
 constexpr int ELEM_FORMS = 8;   // Axx Axy Ayx Ayy Minv Dxx Dxy Dyy
 constexpr int ELEM_STRIDE = ELEM_FORMS * 36;
 
