@@ -22,11 +22,16 @@ Deliberate deviations from the reference, both documented in DESIGN.md:
 from __future__ import annotations
 
 import hashlib
+import logging
+import pickle
 from collections import OrderedDict
 from dataclasses import dataclass
+from pathlib import Path
 from typing import Optional
 
 import numpy as np
+
+logger = logging.getLogger(__name__)
 
 _LOCAL_EDGES = ((0, 1), (1, 2), (0, 2))
 
@@ -216,6 +221,54 @@ class MeshGenerator:
                 "hit_rate": cls._cache_hits / total if total else 0.0, "memory_mb": cls._estimate_cache_memory_mb(),
                 "max_size": cls._cache_max_size, "max_memory_mb": cls._cache_max_memory_mb}
 
+    @classmethod
+    def print_cache_stats(cls):
+        """Cache statistics as a small table on stdout (``mesh.py:371-383``)."""
+        st = cls.get_cache_stats()
+        bar = "=" * 60
+        print(bar)
+        print("MESH CACHE")
+        print(bar)
+        print(f"entries  : {st['size']} / {st['max_size']}")
+        print(f"memory   : {st['memory_mb']:.1f} / {st['max_memory_mb']:.1f} MB")
+        print(f"hits     : {st['hits']:,}")
+        print(f"misses   : {st['misses']:,}")
+        print(f"hit rate : {st['hit_rate'] * 100:.1f}%")
+        print(bar)
+
+    @classmethod
+    def save_cache(cls, filepath):
+        """Writes the cached meshes and the hit / miss counters to ``filepath`` (``mesh.py:386-397``).  What goes to disk is
+        the mesh arrays ``(p, t)`` per key: the P2 basis view of an entry wraps a handle of the native library and is
+        rebuilt by ``load_cache``."""
+        filepath = Path(filepath)
+        with open(filepath, "wb") as f:
+            pickle.dump({"meshes": {k: (np.asarray(m.p), np.asarray(m.t)) for k, (m, _) in cls._cache.items()},
+                         "hits": cls._cache_hits, "misses": cls._cache_misses}, f, protocol=pickle.HIGHEST_PROTOCOL)
+        logger.info("mesh cache written: %s (%.1f MB)", filepath, cls._estimate_cache_memory_mb())
+
+    @classmethod
+    def load_cache(cls, filepath):
+        """Replaces the cache by the contents of a ``save_cache`` file; a missing file is a warning, not an error
+        (``mesh.py:400-416``)."""
+        from . import _native
+        from .solver_fem import P2BasisView
+
+        filepath = Path(filepath)
+        if not filepath.exists():
+            logger.warning("no mesh cache file at %s", filepath)
+            return
+        with open(filepath, "rb") as f:
+            data = pickle.load(f)
+        cache = OrderedDict()
+        for k, (p, t) in data["meshes"].items():
+            mesh = TriMesh(p, t)
+            cache[k] = (mesh, P2BasisView(_native.Symbolic(mesh.p, mesh.t)))
+        cls._cache = cache
+        cls._cache_hits = data["hits"]
+        cls._cache_misses = data["misses"]
+        logger.info("mesh cache read: %d entries, %.1f MB", len(cls._cache), cls._estimate_cache_memory_mb())
+
 
 class MeshQualityAnalyzer:
     """Triangle quality metrics (``mesh.py:419-496``)."""
@@ -245,6 +298,55 @@ class MeshQualityAnalyzer:
                 "poor_quality_frac": float(np.sum(quality < 0.35) / len(quality)),
                 "bad_aspect_frac": float(np.sum(aspect > 8.0) / len(aspect)),
                 "small_angle_frac": float(np.sum(min_angle < 20.0) / len(min_angle))}
+
+    @staticmethod
+    def print_analysis(mesh, logger_inst=None):
+        """The metrics of ``analyze`` as log lines (``mesh.py:499-524``)."""
+        log = logger_inst or logger
+        m = MeshQualityAnalyzer.analyze(mesh)
+        if not m:
+            log.warning("invalid mesh: nothing to analyse")
+            return
+        bar = "=" * 70
+        log.info(bar)
+        log.info("MESH QUALITY")
+        log.info(bar)
+        log.info(f"points       : {m['n_points']:,}")
+        log.info(f"triangles    : {m['n_elements']:,}")
+        log.info(f"area         : [{m['area_min']:.2e}, {m['area_max']:.2e}] (mean {m['area_mean']:.2e})")
+        log.info(f"aspect ratio : [{m['aspect_min']:.2f}, {m['aspect_max']:.2f}] (mean {m['aspect_mean']:.2f})")
+        log.info(f"quality      : [{m['quality_min']:.3f}, {m['quality_max']:.3f}] (mean {m['quality_mean']:.3f}; 1 = equilateral)")
+        log.info(f"smallest angle: {m['min_angle_min']:.1f} deg (mean {m['min_angle_mean']:.1f} deg)")
+        log.info(f"quality < 0.35 : {m['poor_quality_frac'] * 100:.1f}%")
+        log.info(f"aspect > 8     : {m['bad_aspect_frac'] * 100:.1f}%")
+        log.info(f"angle < 20 deg : {m['small_angle_frac'] * 100:.1f}%")
+        log.info(bar)
+
+    @staticmethod
+    def validate_mesh_quality(mesh, strict: bool = False):
+        """``(ok, message)``: the acceptance rule of ``mesh.py:527-568`` -- smallest angle >= 10 deg, aspect ratio <= 20, at
+        most 20 % of the elements below quality 0.35; with ``strict`` also smallest angle >= 20 deg, mean aspect ratio <= 3
+        and mean quality >= 0.7."""
+        m = MeshQualityAnalyzer.analyze(mesh)
+        if not m:
+            return False, "invalid mesh (analysis failed)"
+        issues = []
+        if m["min_angle_min"] < 10.0:
+            issues.append(f"critical smallest angle: {m['min_angle_min']:.1f} deg < 10 deg")
+        if m["aspect_max"] > 20.0:
+            issues.append(f"excessive aspect ratio: {m['aspect_max']:.1f} > 20")
+        if m["poor_quality_frac"] > 0.2:
+            issues.append(f"too many poor-quality elements: {m['poor_quality_frac'] * 100:.0f}%")
+        if strict:
+            if m["min_angle_min"] < 20.0:
+                issues.append(f"[strict] small smallest angle: {m['min_angle_min']:.1f} deg")
+            if m["aspect_mean"] > 3.0:
+                issues.append(f"[strict] high mean aspect ratio: {m['aspect_mean']:.1f}")
+            if m["quality_mean"] < 0.7:
+                issues.append(f"[strict] low mean quality: {m['quality_mean']:.2f}")
+        if issues:
+            return False, "; ".join(issues)
+        return True, "mesh quality acceptable"
 
 
 def unit_square_mesh(n: int = 4) -> TriMesh:

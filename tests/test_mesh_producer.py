@@ -64,3 +64,54 @@ def test_quality_metrics():
     assert abs(q["min_angle_mean"] - (60 + q["min_angle_min"]) / 2) < 1e-9
     assert q["area_min"] > 0 and 0 <= q["poor_quality_frac"] <= 1
     assert MeshQualityAnalyzer.analyze(None) == {}
+
+
+def test_cache_file_round_trip_and_stats_table(built_library, tmp_path, capsys, caplog):
+    """``save_cache`` / ``load_cache`` / ``print_cache_stats`` of reference ``mesh.py:371-416``: the meshes and counters
+    survive a round trip through a file (the P2 basis view is rebuilt), a missing file is a warning."""
+    MeshGenerator.clear_cache()
+    cfg = SimulationConfig(mesh_min_points=500, mesh_target_points=1500)
+    g = MCFGeometry(3, 8.0, 1.5, 1.535, 1.0)
+    m0, b0 = MeshGenerator.generate(g, 0.3, cfg)
+    MeshGenerator.generate(g, 0.3, cfg)
+    path = tmp_path / "meshes.pkl"
+    MeshGenerator.save_cache(path)
+    MeshGenerator.clear_cache()
+    with caplog.at_level("WARNING"):
+        MeshGenerator.load_cache(tmp_path / "absent.pkl")
+    assert MeshGenerator.get_cache_stats()["size"] == 0 and "no mesh cache file" in caplog.text
+    MeshGenerator.load_cache(path)
+    st = MeshGenerator.get_cache_stats()
+    assert (st["size"], st["hits"], st["misses"]) == (1, 1, 1)
+    m1, b1 = MeshGenerator.generate(g, 0.3, cfg)                       # a hit on the restored entry
+    np.testing.assert_array_equal(m1.p, m0.p)
+    np.testing.assert_array_equal(m1.t, m0.t)
+    assert b1.N == b0.N and MeshGenerator.get_cache_stats()["hits"] == 2
+    MeshGenerator.print_cache_stats()
+    out = capsys.readouterr().out
+    assert "MESH CACHE" in out and "hit rate" in out and "66.7%" in out
+    MeshGenerator.clear_cache()
+
+
+def test_quality_validation_and_report(caplog):
+    """``validate_mesh_quality`` / ``print_analysis`` of reference ``mesh.py:499-568``: thresholds 10 deg / 20 / 20 %, and
+    20 deg / 3 / 0.7 in strict mode."""
+    good = unit_square_mesh(4)                                         # right isosceles triangles: 45 deg, aspect 1.41
+    ok, msg = MeshQualityAnalyzer.validate_mesh_quality(good)
+    assert ok and "acceptable" in msg
+    ok, msg = MeshQualityAnalyzer.validate_mesh_quality(good, strict=True)
+    assert ok
+    sliver = TriMesh(np.array([[0.0, 1.0, 0.02], [0.0, 0.0, 0.01]]), np.array([[0], [1], [2]]))   # a needle: 0.6 deg, aspect 45
+    ok, msg = MeshQualityAnalyzer.validate_mesh_quality(sliver)
+    assert not ok and "smallest angle" in msg and "aspect ratio" in msg and "poor-quality" in msg
+    mid = TriMesh(np.array([[0.0, 1.0, 0.5], [0.0, 0.0, 0.17]]), np.array([[0], [1], [2]]))   # 18.8 deg, quality 0.38
+    assert MeshQualityAnalyzer.validate_mesh_quality(mid)[0]
+    ok_s, msg_s = MeshQualityAnalyzer.validate_mesh_quality(mid, strict=True)
+    assert not ok_s and "[strict]" in msg_s
+    assert MeshQualityAnalyzer.validate_mesh_quality(None) == (False, "invalid mesh (analysis failed)")
+    with caplog.at_level("INFO"):
+        MeshQualityAnalyzer.print_analysis(good)
+    assert "MESH QUALITY" in caplog.text and "triangles" in caplog.text
+    with caplog.at_level("WARNING"):
+        MeshQualityAnalyzer.print_analysis(None)
+    assert "nothing to analyse" in caplog.text
