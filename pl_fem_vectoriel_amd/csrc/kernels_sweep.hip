@@ -53,7 +53,6 @@ namespace plfem {
 namespace {
 
 struct SweepArgs {
-  const SweepJob* blk;
   int leaf_level;
   int dbg;                         // timing experiments only (plfem_debug_solve_block): 1 skip fronts with s2 > 128, 2 only those
   int ldv;                         // row forms: leading dimension of the staged vector in LDS (component-major [u][i])
@@ -573,46 +572,49 @@ __device__ __forceinline__ void bwd_rows_body(const SweepArgs& A, const SweepJob
 // them for 4 long fronts alone), every other front tile-form workgroups (64 rows, 4 waves splitting the columns).
 // Measured and dropped: 8-wave tiles in the mixed launch (the leaf level twice as slow), the tile form for the short
 // fronts of the backward mid levels (every level slower than the row form).
+// The launch list comes as a kernel argument OF ITS OWN in front of the argument block: with kernel-argument preloading (Makefile:
+// -amdgpu-kernarg-preload-count) it sits in scalar registers when a wave starts, and the load of the workgroup's job record --
+// the head of every workgroup's chain of dependent memory round trips -- no longer waits for a load of the argument block.
 // LD = 16-byte matrix loads in flight per lane and trip (8: twice the bytes of round 3's eight 8-byte loads, at the price of
 // 16-28 more registers; 4: the same bytes in half the instructions); chosen per kernel form in sweeps() below
 template <int P, int R, int LD>
-__global__ __launch_bounds__(512) void k_fwd_rows(SweepArgs A) {
+__global__ __launch_bounds__(512) void k_fwd_rows(const SweepJob* __restrict__ blk, SweepArgs A) {
   extern __shared__ __attribute__((aligned(16))) double sv[];
-  const SweepJob job = A.blk[blockIdx.x];
+  const SweepJob job = blk[blockIdx.x];
   fwd_rows_body<P, 8, R, (LD < R ? R : LD)>(A, job, sv);
 }
 
 template <int P, int R, int LD>
-__global__ __launch_bounds__(512) void k_bwd_rows(SweepArgs A) {
+__global__ __launch_bounds__(512) void k_bwd_rows(const SweepJob* __restrict__ blk, SweepArgs A) {
   extern __shared__ __attribute__((aligned(16))) double sv[];
-  const SweepJob job = A.blk[blockIdx.x];
+  const SweepJob job = blk[blockIdx.x];
   bwd_rows_body<P, 8, R, (LD < R ? R : LD)>(A, job, sv);
 }
 
 // forward, tile form only (levels without a long front: the mixed kernel's register budget costs occupancy there)
 template <int P, int LD>
-__global__ __launch_bounds__(256) void k_fwd(SweepArgs A) {
+__global__ __launch_bounds__(256) void k_fwd(const SweepJob* __restrict__ blk, SweepArgs A) {
   extern __shared__ __attribute__((aligned(16))) double sv[];
   __shared__ __attribute__((aligned(16))) double red[4 * P * 64];
-  const SweepJob job = A.blk[blockIdx.x];
+  const SweepJob job = blk[blockIdx.x];
   fwd_tile_body<P, 4, LD>(A, job, sv, red);
 }
 
 template <int P, int LD>
-__global__ __launch_bounds__(256) void k_fwd_mix(SweepArgs A) {
+__global__ __launch_bounds__(256) void k_fwd_mix(const SweepJob* __restrict__ blk, SweepArgs A) {
   extern __shared__ __attribute__((aligned(16))) double sv[];
   __shared__ __attribute__((aligned(16))) double red[4 * P * 64];
-  const SweepJob job = A.blk[blockIdx.x];
+  const SweepJob job = blk[blockIdx.x];
   if (job.rb & SWEEP_ROW_JOB_FLAG) fwd_rows_body<P, 4, 4, (LD < 4 ? 4 : LD)>(A, job, sv);
   else fwd_tile_body<P, 4, LD>(A, job, sv, red);
 }
 
 // backward, leaf level: tile form (leaf fronts have about as many owned rows as boundary columns)
 template <int P, int LD>
-__global__ __launch_bounds__(512) void k_bwd(SweepArgs A) {
+__global__ __launch_bounds__(512) void k_bwd(const SweepJob* __restrict__ blk, SweepArgs A) {
   extern __shared__ __attribute__((aligned(16))) double sv[];
   __shared__ __attribute__((aligned(16))) double red[8 * P * 64];
-  const SweepJob job = A.blk[blockIdx.x];
+  const SweepJob job = blk[blockIdx.x];
   bwd_tile_body<P, 8, LD>(A, job, sv, red);
 }
 
@@ -667,24 +669,24 @@ void sweeps(plfem_ctx* c) {
     const LevelInfo& li = c->levels[lev];
     if (li.fwd_n == 0) continue;
     A.leaf_level = lev == c->L ? 1 : 0;
-    A.blk = c->d_blk + li.fwd_off;
+    const SweepJob* blk = c->d_blk + li.fwd_off;
     A.ldv = (li.max_s2 + 2) & ~1;                   // even: the row forms read the staged planes as double2
     const size_t lds = sizeof(double) * P * A.ldv;
     if (li.fwd_rows == 8) {
-      if (ld_rows == 8) hipLaunchKernelGGL((k_fwd_rows<P, 1, 8>), dim3(li.fwd_n), dim3(512), lds, st, A);
-      else hipLaunchKernelGGL((k_fwd_rows<P, 1, 4>), dim3(li.fwd_n), dim3(512), lds, st, A);
+      if (ld_rows == 8) hipLaunchKernelGGL((k_fwd_rows<P, 1, 8>), dim3(li.fwd_n), dim3(512), lds, st, blk, A);
+      else hipLaunchKernelGGL((k_fwd_rows<P, 1, 4>), dim3(li.fwd_n), dim3(512), lds, st, blk, A);
     } else if (li.fwd_rows == 16) {
-      if (ld_rows == 8) hipLaunchKernelGGL((k_fwd_rows<P, 2, 8>), dim3(li.fwd_n), dim3(512), lds, st, A);
-      else hipLaunchKernelGGL((k_fwd_rows<P, 2, 4>), dim3(li.fwd_n), dim3(512), lds, st, A);
+      if (ld_rows == 8) hipLaunchKernelGGL((k_fwd_rows<P, 2, 8>), dim3(li.fwd_n), dim3(512), lds, st, blk, A);
+      else hipLaunchKernelGGL((k_fwd_rows<P, 2, 4>), dim3(li.fwd_n), dim3(512), lds, st, blk, A);
     } else {
       // optional live timing of this kernel (bench.py roofline): HIP events on the launch stream
       const int pid = time_launches ? prof_open(c, PLFEM_PROF_KFWD, li.sweep_bytes + 8.0 * (P - 1) * li.sweep_vec_doubles) : -1;
       if (li.fwd_mixed) {
-        if (ld_tile == 8) hipLaunchKernelGGL((k_fwd_mix<P, 8>), dim3(li.fwd_n), dim3(256), lds, st, A);
-        else hipLaunchKernelGGL((k_fwd_mix<P, 4>), dim3(li.fwd_n), dim3(256), lds, st, A);
+        if (ld_tile == 8) hipLaunchKernelGGL((k_fwd_mix<P, 8>), dim3(li.fwd_n), dim3(256), lds, st, blk, A);
+        else hipLaunchKernelGGL((k_fwd_mix<P, 4>), dim3(li.fwd_n), dim3(256), lds, st, blk, A);
       } else {
-        if (ld_tile == 8) hipLaunchKernelGGL((k_fwd<P, 8>), dim3(li.fwd_n), dim3(256), lds, st, A);
-        else hipLaunchKernelGGL((k_fwd<P, 4>), dim3(li.fwd_n), dim3(256), lds, st, A);
+        if (ld_tile == 8) hipLaunchKernelGGL((k_fwd<P, 8>), dim3(li.fwd_n), dim3(256), lds, st, blk, A);
+        else hipLaunchKernelGGL((k_fwd<P, 4>), dim3(li.fwd_n), dim3(256), lds, st, blk, A);
       }
       prof_close(c, pid);
     }
@@ -695,18 +697,18 @@ void sweeps(plfem_ctx* c) {
     const LevelInfo& li = c->levels[lev];
     if (li.bwd_n == 0) continue;
     A.leaf_level = lev == c->L ? 1 : 0;
-    A.blk = c->d_blk + li.bwd_off;
+    const SweepJob* blk = c->d_blk + li.bwd_off;
     A.ldv = (li.max_m + 2) & ~1;
     const size_t lds = sizeof(double) * P * A.ldv;
     if (li.bwd_rows == 8) {        // few large fronts: one row per wave, most blocks
-      if (ld_rows == 8) hipLaunchKernelGGL((k_bwd_rows<P, 1, 8>), dim3(li.bwd_n), dim3(512), lds, st, A);
-      else hipLaunchKernelGGL((k_bwd_rows<P, 1, 4>), dim3(li.bwd_n), dim3(512), lds, st, A);
+      if (ld_rows == 8) hipLaunchKernelGGL((k_bwd_rows<P, 1, 8>), dim3(li.bwd_n), dim3(512), lds, st, blk, A);
+      else hipLaunchKernelGGL((k_bwd_rows<P, 1, 4>), dim3(li.bwd_n), dim3(512), lds, st, blk, A);
     } else if (li.bwd_rows == 16) {
-      if (ld_rows == 8) hipLaunchKernelGGL((k_bwd_rows<P, 2, 8>), dim3(li.bwd_n), dim3(512), lds, st, A);
-      else hipLaunchKernelGGL((k_bwd_rows<P, 2, 4>), dim3(li.bwd_n), dim3(512), lds, st, A);
+      if (ld_rows == 8) hipLaunchKernelGGL((k_bwd_rows<P, 2, 8>), dim3(li.bwd_n), dim3(512), lds, st, blk, A);
+      else hipLaunchKernelGGL((k_bwd_rows<P, 2, 4>), dim3(li.bwd_n), dim3(512), lds, st, blk, A);
     } else {                       // leaf level: tile form
-      if (ld_tile == 8) hipLaunchKernelGGL((k_bwd<P, 8>), dim3(li.bwd_n), dim3(512), lds, st, A);
-      else hipLaunchKernelGGL((k_bwd<P, 4>), dim3(li.bwd_n), dim3(512), lds, st, A);
+      if (ld_tile == 8) hipLaunchKernelGGL((k_bwd<P, 8>), dim3(li.bwd_n), dim3(512), lds, st, blk, A);
+      else hipLaunchKernelGGL((k_bwd<P, 4>), dim3(li.bwd_n), dim3(512), lds, st, blk, A);
     }
   }
   prof_close(c, pid_bwd);
