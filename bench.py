@@ -51,6 +51,8 @@ def parse_args(argv=None):
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-all-cores", action="store_true", help="also time the CPU baseline with BLAS unrestricted")
+    ap.add_argument("--steady-seconds", type=float, default=6.0,
+                    help="extra info at N = 1: the same cold solves repeated for this long after the CPU leg (0 = skip)")
     ap.add_argument("--levels", type=int, default=1, help="uniform refinements of the synthetic mesh (1 = C1)")
     ap.add_argument("--ladder", action="store_true", help="BASELINE configs[2]: one line per rung L = 0, 1, 2")
     ap.add_argument("--sweep", action="store_true", help="BASELINE configs[3]: a step = the 64-solve multi-band sweep")
@@ -489,6 +491,21 @@ def run_solve_config(args, D: Dist, levels: int, with_cpu_baseline: bool):
     if world == 1 and with_cpu_baseline:
         base, ref_modes = cpu_baseline(geom, mesh, all_cores=args.cpu_all_cores)
 
+    # steady figure -- extra info, outside the timed region: the SAME cold step repeated for a few seconds (hundreds of
+    # steps instead of K): what the K timed steps are a sample of, with its spread (host jitter shows up in p95 / max)
+    steady = None
+    if world == 1 and levels == 1 and with_cpu_baseline and args.steady_seconds > 0:
+        ms = []
+        t_end = time.perf_counter() + args.steady_seconds
+        while time.perf_counter() < t_end:
+            ts = time.perf_counter()
+            step()
+            ms.append((time.perf_counter() - ts) * 1e3)
+        ms.sort()
+        steady = {"steps": len(ms), "seconds": args.steady_seconds, "ms_per_step_mean": sum(ms) / len(ms),
+                  "ms_per_step_median": ms[len(ms) // 2], "ms_per_step_p95": ms[min(len(ms) - 1, int(0.95 * len(ms)))],
+                  "ms_per_step_min": ms[0], "ms_per_step_max": ms[-1], "modes_per_s": N_MODES * len(ms) / (sum(ms) * 1e-3)}
+
     # warm figure (symbolic analysis + context kept, e.g. the other wavelengths of a sweep) — extra info
     ws = TrueVectorialMaxwellSolver(geom, device=D.local_rank, reuse_symbolic=True)
     ws.solve_vectorial_modes(mesh, N_MODES)
@@ -546,6 +563,8 @@ def run_solve_config(args, D: Dist, levels: int, with_cpu_baseline: bool):
                         "workspace_alloc": round(max(h[2] for h in host_ms), 2)},
         "roofline": roof,
     }
+    if steady is not None:
+        out["steady"] = steady
     if conc is not None:
         out["concurrent"] = {"in_flight": in_flight, "value": conc, "unit": "modes/s",
                              "note": "same cold solves, several in flight on the one GPU (host thread + stream each); "
