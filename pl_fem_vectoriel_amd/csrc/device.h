@@ -176,8 +176,6 @@ void launch_panel_axpy_block(plfem_ctx* c, const double* Pm, int ncols, const do
 // first Gram-Schmidt pass of a block step over ncols <= 8 columns in two launches: reads the sweeps' result d_xl (front
 // order), writes W in global order (what k_permute_out would have done), h = BVm^T W -> Hout, W -= Vm h
 void launch_first_pass_block(plfem_ctx* c, const double* BVm, const double* Vm, int ncols, double* W, int64_t ldw, double* Hout, int ldh);
-void launch_mat_add(plfem_ctx* c, int ncols, double* acc, int lda, const double* h, int ldh);
-void launch_gram_chol_block(plfem_ctx* c, const double* W, const double* BW, int64_t ldw, double* Tblk, int ldT, double* Rinv);
 // the Cholesky half alone, from nchunks Gram partials per entry already in d_partial (launch_spmv_b_block_il with gram)
 void launch_chol_from_partials(plfem_ctx* c, int nchunks, double* Tblk, int ldT, double* Rinv);
 void launch_chol_block(plfem_ctx* c, const double* G, int ldg, double* Tblk, int ldT, double* Rinv);

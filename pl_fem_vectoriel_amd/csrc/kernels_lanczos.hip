@@ -319,14 +319,6 @@ __global__ __launch_bounds__(256) void k_axpy_first(int64_t n, int ncols, int ns
   for (int q = 0; q < P; ++q) W[(int64_t)q * ldw + i] -= acc[q];
 }
 
-// acc[c + q*lda] += h[c + q*ldh]
-__global__ void k_mat_add(int ncols, int P, double* __restrict__ acc, int lda, const double* __restrict__ h, int ldh) {
-  int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= ncols * P) return;
-  int c = t % ncols, q = t / ncols;
-  acc[c + (int64_t)q * lda] += h[c + (int64_t)q * ldh];
-}
-
 // Cholesky G = R^T R of the P x P Gram matrix of the new block (one lane), R into the projected matrix
 // (rows nc.., columns c0..), R^-1 for the block scaling.  A non-positive pivot (rank-deficient block:
 // the Krylov space is exhausted) raises counters[2].
@@ -797,23 +789,9 @@ void launch_first_pass_block(plfem_ctx* c, const double* BVm, const double* Vm, 
   }
 }
 
-void launch_mat_add(plfem_ctx* c, int ncols, double* acc, int lda, const double* h, int ldh) {
-  const int n = ncols * BLOCK_P;
-  hipLaunchKernelGGL(k_mat_add, dim3((n + 255) / 256), dim3(256), 0, c->stream, ncols, BLOCK_P, acc, lda, h, ldh);
-}
-
 void launch_chol_block(plfem_ctx* c, const double* G, int ldg, double* Tblk, int ldT, double* Rinv) {
   hipLaunchKernelGGL(k_chol_small<BLOCK_P>, dim3(1), dim3(64), 0, c->stream, G, ldg, (const double*)nullptr, 0, Tblk, ldT,
                      Rinv, c->d_counters);
-}
-
-// Gram matrix W^T BW (chunk partials only) + its Cholesky factor in two launches
-void launch_gram_chol_block(plfem_ctx* c, const double* W, const double* BW, int64_t ldw, double* Tblk, int ldT, double* Rinv) {
-  constexpr int P = BLOCK_P;
-  const int nchunks = c->npartial;
-  hipLaunchKernelGGL(k_panel_dot_p<P>, dim3(nchunks, 1), dim3(256), 0, c->stream, c->n2, P, nchunks, W, BW, ldw, c->d_partial);
-  hipLaunchKernelGGL(k_chol_small<P>, dim3(1), dim3(std::min(1024, 64 * P * P)), 0, c->stream, (const double*)nullptr, 0, c->d_partial, nchunks,
-                     Tblk, ldT, Rinv, c->d_counters);
 }
 
 void launch_chol_from_partials(plfem_ctx* c, int nchunks, double* Tblk, int ldT, double* Rinv) {
