@@ -40,8 +40,13 @@ def random_cross_sections(n=N_ALL, seed=20261004):
 # Cases whose eigenvalues differ from eigsh run with the REFERENCE's own arguments (k = 18, tol 1e-7) and agree with a wider,
 # tighter eigsh instead -- i.e. where this path returns a different set than the reference's call would.  The list is
 # asserted, so that a new divergence from the reference-argument run shows up as a failure, not as a silent switch of
-# oracles.  Case 38: an exactly degenerate pair at the far edge of the wanted set (see below).
-KNOWN_WIDE_ORACLE_CASES = {38}
+# oracles.  All four hold an exactly degenerate pair at the far edge of the wanted set (see below): ARPACK's
+# single-vector recurrence finds the second copy of such a pair out of rounding noise only, so whether a run with the
+# reference's arguments returns it depends on the start vector and on the BLAS's rounding -- with the per-case start vector
+# below, 38 and 44 of the default 48 cases and 95, 96 of the full list of 104 take the fallback (round 4,
+# profiles/r04_pivoting_full.txt); with ARPACK's own start vector it was 38 alone.  The assertion is "no case outside this
+# list": a listed case that happens to agree with the reference-argument run is fine.
+KNOWN_WIDE_ORACLE_CASES = {38, 44, 95, 96}
 
 
 @pytest.mark.parametrize("chunk", range(4))          # (a quarter of the cases each -- 12 by default, 26 of the full list: a test that stays silent for minutes looks hung)
@@ -68,8 +73,12 @@ def test_random_coarse_cross_sections_factor_cleanly_and_match_the_oracle(chunk,
         A_int, B_int, _interior = hfield.restrict_interior(A, B, basis)
         sigma = hfield.shift_estimate(g)
         assert abs(sigma - st["sigma"]) <= 1e-12 * abs(sigma)
+        # (a start vector of the case's own: without one ARPACK draws from a generator whose state depends on every earlier
+        # eigsh call of the process, and which cases end up in KNOWN_WIDE_ORACLE_CASES would depend on the test selection)
+        v0 = np.random.default_rng(1000 + t).standard_normal(A_int.shape[0])
         raw = {"A_int": A_int, "B_int": B_int, "sigma": sigma,
-               "beta_sq": eigsh(A_int, k=18, M=B_int, sigma=sigma, which="LM", tol=1e-7, maxiter=12000, return_eigenvectors=False)}
+               "beta_sq": eigsh(A_int, k=18, M=B_int, sigma=sigma, which="LM", tol=1e-7, maxiter=12000, return_eigenvectors=False,
+                                v0=v0)}
         got = np.sort(np.sqrt(st["beta_sq"])) / g.k0
         want = np.sort(np.sqrt(raw["beta_sq"])) / g.k0
         if np.abs(got - want).max() >= 1e-9:
@@ -79,7 +88,7 @@ def test_random_coarse_cross_sections_factor_cleanly_and_match_the_oracle(chunk,
             # the wanted set and the next eigenvalue in its place (case 38 of this list: pair at sigma - 0.36247, eigsh
             # returns one copy and sigma - 0.36298); the block recurrence of the HIP path finds both copies.
             wide = eigsh(raw["A_int"], k=26, M=raw["B_int"], sigma=raw["sigma"], which="LM", tol=1e-10, maxiter=12000,
-                         return_eigenvectors=False)
+                         return_eigenvectors=False, v0=v0)
             wide = wide[np.argsort(np.abs(wide - raw["sigma"]))][:18]
             want = np.sort(np.sqrt(wide)) / g.k0
             took_wide_oracle.add(t)
