@@ -861,7 +861,8 @@ void post_enqueue(plfem_ctx* c, int k, double* evecs, int ncore, double* modes_i
   hipLaunchKernelGGL(k_core_mask, dim3((N + 255) / 256), dim3(256), 0, st, N, c->d_doflocs, c->d_cores, ncore,
                      c->d_bmask, c->d_coremask, c->d_counters);
   const int nblocks = (N + POST_ROWS - 1) / POST_ROWS;
-  const int group = group_done ? POST_GROUP : k;
+  static const int post_group = getenv("PLFEM_POST_GROUP") ? std::max(1, atoi(getenv("PLFEM_POST_GROUP"))) : POST_GROUP;   // (tuning aid)
+  const int group = group_done ? post_group : k;
   for (int g0 = 0; g0 < k; g0 += group) {
     const int kg = std::min(group, k - g0);
     double* ev = evecs + (int64_t)g0 * c->n2;
