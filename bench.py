@@ -495,16 +495,22 @@ def run_solve_config(args, D: Dist, levels: int, with_cpu_baseline: bool):
     # steps instead of K): what the K timed steps are a sample of, with its spread (host jitter shows up in p95 / max)
     steady = None
     if world == 1 and levels == 1 and with_cpu_baseline and args.steady_seconds > 0:
-        ms = []
+        ms, sym_ms = [], []
         t_end = time.perf_counter() + args.steady_seconds
         while time.perf_counter() < t_end:
             ts = time.perf_counter()
-            step()
+            sv, _ = step()
             ms.append((time.perf_counter() - ts) * 1e3)
+            sym_ms.append(sv.last_stats["t_symbolic"] * 1e3)
+        total = sum(ms)
         ms.sort()
-        steady = {"steps": len(ms), "seconds": args.steady_seconds, "ms_per_step_mean": sum(ms) / len(ms),
-                  "ms_per_step_median": ms[len(ms) // 2], "ms_per_step_p95": ms[min(len(ms) - 1, int(0.95 * len(ms)))],
-                  "ms_per_step_min": ms[0], "ms_per_step_max": ms[-1], "modes_per_s": N_MODES * len(ms) / (sum(ms) * 1e-3)}
+        sym_ms.sort()
+        pct = lambda v, q: v[min(len(v) - 1, int(q * len(v)))]
+        steady = {"steps": len(ms), "seconds": args.steady_seconds, "ms_per_step_mean": total / len(ms),
+                  "ms_per_step_median": pct(ms, 0.5), "ms_per_step_p95": pct(ms, 0.95),
+                  "ms_per_step_min": ms[0], "ms_per_step_max": ms[-1], "modes_per_s": N_MODES * len(ms) / (total * 1e-3),
+                  # the host analysis inside those steps: the part of a cold step that depends on the (shared) host
+                  "symbolic_host_ms": {"median": pct(sym_ms, 0.5), "p95": pct(sym_ms, 0.95), "max": sym_ms[-1]}}
 
     # warm figure (symbolic analysis + context kept, e.g. the other wavelengths of a sweep) — extra info
     ws = TrueVectorialMaxwellSolver(geom, device=D.local_rank, reuse_symbolic=True)
