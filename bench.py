@@ -372,7 +372,9 @@ class Dist:
                 self.local_rank = 0
             torch.cuda.set_device(self.local_rank)
         self.dist = None
-        if self.world > 1:
+        # PLFEM_BENCH_FORCE_DIST=1: a process group even for ONE rank (RANK / WORLD_SIZE / MASTER_* as torchrun sets them):
+        # barrier, max-reduction and the sweep's gather then run through RCCL on a one-GPU box (tests/test_gpu_rccl_one_rank.py)
+        if self.world > 1 or (os.environ.get("PLFEM_BENCH_FORCE_DIST") and "RANK" in os.environ):
             import torch.distributed as dist
             if self.backend == "nccl":
                 dist.init_process_group("nccl", device_id=torch.device("cuda", self.local_rank))

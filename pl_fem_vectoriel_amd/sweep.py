@@ -376,7 +376,9 @@ def run_sweep(items: Sequence[SweepItem], rank: int = 0, world_size: int = 1,
         for key in groups:
             solve.release(key)
     table: Dict[int, np.ndarray] = {}
-    if world_size > 1 and gather:
+    import torch.distributed as _dist
+    # (a process group of ONE rank still gathers through it: the collective path can then be exercised on a one-GPU box)
+    if gather and (world_size > 1 or (_dist.is_available() and _dist.is_initialized() and _dist.get_world_size() == 1)):
         import torch.distributed as dist
 
         dev = torch.device("cuda", device) if (device is not None and dist.get_backend() == "nccl") else torch.device("cpu")
