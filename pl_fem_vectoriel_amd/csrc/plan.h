@@ -5,9 +5,24 @@
 #pragma once
 #include <cstdint>
 #include <functional>
+#include <memory>
+#include <utility>
 #include <vector>
 
 namespace plfem {
+
+// std::vector whose resize() leaves the new elements uninitialised: the big index arrays of the front
+// tree are filled in parallel, and a value-initialising resize would first touch every page serially.
+template <class T>
+struct default_init_allocator : std::allocator<T> {
+  template <class U>
+  struct rebind { using other = default_init_allocator<U>; };
+  using std::allocator<T>::allocator;
+  template <class U>
+  void construct(U* ptr) noexcept { ::new (static_cast<void*>(ptr)) U; }
+  template <class U, class... Args>
+  void construct(U* ptr, Args&&... args) { ::new (static_cast<void*>(ptr)) U(std::forward<Args>(args)...); }
+};
 
 constexpr int NB = 32;          // pivot-block width of the block LDL^T
 constexpr int PANEL_CHUNK = 1024; // rows per partial sum of the tall-skinny panel products
@@ -73,10 +88,10 @@ struct LaunchPlan {
   std::vector<int32_t> fs2, fm;        // per front: owned DOFs, order of the front (DOFs)
   std::vector<int32_t> forder;         // per level: front ids in order of decreasing s2
   std::vector<int32_t> forder_s2, forder_maxm;   // s2 in that order, running maximum of m in that order
-  std::vector<FrontRec> frec;          // the fronts in launch order, with their parameters
+  std::vector<FrontRec, default_init_allocator<FrontRec>> frec;   // the fronts in launch order, with their parameters (this and the two lists below: filled in parallel into uninitialised storage)
   std::vector<LevelInfo> levels;
-  std::vector<SweepJob> jobs;          // one entry per sweep workgroup, level by level (forward then backward lists)
-  std::vector<Tile> tiles;             // 64 x 64 workgroup lists of the factorisation kernels
+  std::vector<SweepJob, default_init_allocator<SweepJob>> jobs;   // one entry per sweep workgroup, level by level (forward then backward lists)
+  std::vector<Tile, default_init_allocator<Tile>> tiles;   // 64 x 64 workgroup lists of the factorisation kernels
   std::vector<int64_t> upd_off;        // per (level, block step): first entry / entries of the trailing-update list
   std::vector<int32_t> upd_n;
   int64_t formz_all_off = 0, mirrorx_all_off = 0;
@@ -84,8 +99,9 @@ struct LaunchPlan {
   int64_t level_nodes_max = 0;         // sum of (padded) nodes over the fronts of one tree level, largest level
   int32_t worst_m = 0;                 // largest front order (LDS staging limit of the sweeps)
 };
-// run2 (may be empty): runs its two arguments side by side (the analysis lends a second thread)
-void build_launch_plan(const Symbolic& S, LaunchPlan& P,
-                       const std::function<void(const std::function<void()>&, const std::function<void()>&)>& run2 = {});
+// par (may be empty): runs f(0) .. f(ntasks - 1), side by side if it can (the analysis lends part of its team); the plan is
+// the same either way
+using PlanTasks = std::function<void(int ntasks, const std::function<void(int)>& f)>;
+void build_launch_plan(const Symbolic& S, LaunchPlan& P, const PlanTasks& par = {});
 
 }  // namespace plfem

@@ -1122,10 +1122,15 @@ std::string build_fronts(Symbolic& S, int nthreads) {
     }
   });
   };
-  const int n_plan = team_size() >= 4 ? 2 : 1;          // (two threads: the sweep lists and the tile lists side by side)
-  team_fork2(team_size() - n_plan, flatten, [&] {
-    build_launch_plan(S, S.plan, [](const std::function<void()>& a, const std::function<void()>& b) { team_fork2(1, a, b); });
+  // (the plan is ~200 list-filling tasks of up to 20 us, 0.25 ms on two threads: a quarter of the team)
+  const int n_plan = team_size() >= 4 ? std::max(2, team_size() / 4) : 1;
+  double t_flat = 0.0, t_plan = 0.0;                     // (trace only: which side of the fork the lap below is made of)
+  team_fork2(team_size() - n_plan, [&] { const auto t0 = clk::now(); flatten(); t_flat = secs(t0, clk::now()); }, [&] {
+    const auto t0 = clk::now();
+    build_launch_plan(S, S.plan, [&](int ntasks, const std::function<void(int)>& f) { parallel_tasks(ntasks, nthreads, f); });
+    t_plan = secs(t0, clk::now());
   });
+  if (tr.on) fprintf(stderr, "[sym]   (flatten %.3f ms | plan %.3f ms)\n", t_flat * 1e3, t_plan * 1e3);
   tr.lap("fronts: flatten + plan");
   return "";
 }

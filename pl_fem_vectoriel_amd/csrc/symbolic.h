@@ -19,18 +19,6 @@
 
 namespace plfem {
 
-// std::vector whose resize() leaves the new elements uninitialised: the big index arrays of the front
-// tree are filled in parallel, and a value-initialising resize would first touch every page serially.
-template <class T>
-struct default_init_allocator : std::allocator<T> {
-  template <class U>
-  struct rebind { using other = default_init_allocator<U>; };
-  using std::allocator<T>::allocator;
-  template <class U>
-  void construct(U* ptr) noexcept { ::new (static_cast<void*>(ptr)) U; }
-  template <class U, class... Args>
-  void construct(U* ptr, Args&&... args) { ::new (static_cast<void*>(ptr)) U(std::forward<Args>(args)...); }
-};
 using rawvec_i32 = std::vector<int32_t, default_init_allocator<int32_t>>;
 
 struct Symbolic {
