@@ -964,19 +964,28 @@ std::string build_fronts(Symbolic& S, int nthreads) {
       nodes.reserve(1024);
       // node -> position in this leaf's lists; only entries written for the current leaf are ever read (no clearing)
       static thread_local rawvec_i32 pos_of;
+      // node -> stamp of the leaf that listed it last (table and counter belong to the thread and outlive the analysis): a
+      // node goes into the list once, so the sort below runs over the ~70 distinct nodes of a leaf, not its ~130 references
+      static thread_local std::vector<uint32_t> seen;
+      static thread_local uint32_t last_stamp = 0;
       if ((int)pos_of.size() < N) pos_of.resize(N);
+      if ((int)seen.size() < N) { seen.assign(N, 0u); last_stamp = 0; }
       for (int lf = task * LB; lf < std::min(nleaf, (task + 1) * LB); ++lf) {
         const int e0 = S.leaf_elem_ptr[lf], e1 = S.leaf_elem_ptr[lf + 1];
+        if (++last_stamp == 0) {                   // (wrapped after 4e9 leaves on this thread: start over with a clean table)
+          std::fill(seen.begin(), seen.end(), 0u);
+          last_stamp = 1;
+        }
+        const uint32_t stamp = last_stamp;
         nodes.clear();
         for (int q = e0; q < e1; ++q) {
           const int32_t e = S.leaf_elems[q];
           for (int a = 0; a < 6; ++a) {
             const int32_t i = ed6[(size_t)e * 6 + a];
-            if (!S.bmask[i]) nodes.push_back(i);
+            if (!S.bmask[i] && seen[i] != stamp) { seen[i] = stamp; nodes.push_back(i); }
           }
         }
         std::sort(nodes.begin(), nodes.end());
-        nodes.erase(std::unique(nodes.begin(), nodes.end()), nodes.end());
         int32_t* own = lb.own.data() + lb.off[lf];
         int32_t* bnd = lb.bnd.data() + lb.off[lf];
         int no = 0, nb = 0;
