@@ -1150,9 +1150,20 @@ extern "C" int plfem_solve_modes(plfem_ctx* c, const double* cores_host, int32_t
     ~Defer() { c->defer_sync = false; c->refine_steps = saved_refine; }
   } defer{c, c->refine_steps};
   c->defer_sync = true;
+  // PLFEM_CALL_TRACE=1 (tuning aid): where the wall time of this call goes beyond its device phases -- host timestamps of the
+  // enqueue points, the stream's backlog at entry (work of plfem_create still queued) and the tail of the mode copy
+  static const bool call_trace = getenv("PLFEM_CALL_TRACE") != nullptr;
+  hipEvent_t tr_ev[3] = {nullptr, nullptr, nullptr};
+  double th_asm = 0, th_fac = 0, th_lan = 0, th_enq = 0, th_sync = 0;
+  if (call_trace) {
+    for (auto& e : tr_ev) (void)hipEventCreate(&e);
+    (void)hipEventRecord(tr_ev[0], c->stream);
+  }
   if (c->dpn == 2) TRY(plfem_assemble_hfield(c, cores_host, ncore, eps_core, eps_clad, k0, alpha_p));
   else TRY(plfem_assemble_scalar(c, cores_host, ncore, eps_core, eps_clad, k0));
+  th_asm = now_ms();
   TRY(plfem_factor(c, sigma));
+  th_fac = now_ms();
   double st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   double first_res = 0.0, res = 0.0;
   int perturbed = 0, refined = 0;
@@ -1170,6 +1181,7 @@ extern "C" int plfem_solve_modes(plfem_ctx* c, const double* cores_host, int32_t
       if (stats_host) { stats_host[0] = st[0]; stats_host[1] = n_opinv; stats_host[2] = restarts; stats_host[3] = st[3]; stats_host[4] = n_block; }
       return rc;
     }
+    th_lan = now_ms();
     double* modes = c->modes_dev;
     double* modes_int = c->d_BV2 != modes ? c->d_BV2 : c->d_BV;   // (a restart swaps the double buffers: take the idle one)
     HIP_TRY(c, hipEventRecord(c->ev[3][0], c->stream));
@@ -1196,7 +1208,13 @@ extern "C" int plfem_solve_modes(plfem_ctx* c, const double* cores_host, int32_t
     HIP_TRY(c, hipEventRecord(c->ev[5][1], c->stream));
     c->ev_used[5] = true;
     TRY(check_launch(c, "post-processing + residual check"));
+    if (call_trace) {
+      (void)hipEventRecord(tr_ev[1], c->stream);
+      (void)hipEventRecord(tr_ev[2], c->copy_stream);
+    }
+    th_enq = now_ms();
     HIP_TRY(c, hipStreamSynchronize(c->stream));   // THE synchronisation of the call
+    th_sync = now_ms();
     plfem::post_finish(c, k, post_host, frac_core_host);
     plfem::resid_finish(c, k, resid_host);
     perturbed = reinterpret_cast<const int32_t*>(c->h_pinned + 4096)[0];
@@ -1218,6 +1236,18 @@ extern "C" int plfem_solve_modes(plfem_ctx* c, const double* cores_host, int32_t
     refined = 1;
   }
   if (modes_int_host) HIP_TRY(c, hipStreamSynchronize(c->copy_stream));
+  if (call_trace) {
+    const double th_end = now_ms();
+    float backlog = 0, total = 0, copy_tail = 0;
+    (void)hipEventElapsedTime(&backlog, tr_ev[0], c->ev[0][0]);      // entry -> first assembly kernel may start
+    (void)hipEventElapsedTime(&total, tr_ev[0], tr_ev[1]);
+    (void)hipEventElapsedTime(&copy_tail, tr_ev[1], tr_ev[2]);        // end of the residual check -> end of the mode copy
+    fprintf(stderr, "[call] host: assemble enqueued +%.3f, factor +%.3f, lanczos returned +%.3f, post + check enqueued +%.3f, stream done +%.3f, "
+                    "copy done +%.3f ms | device: entry -> assembly %.3f (backlog of plfem_create + launch), entry -> end of check %.3f, "
+                    "check -> copy end %.3f ms\n",
+            th_asm - th0, th_fac - th0, th_lan - th0, th_enq - th0, th_sync - th0, th_end - th0, backlog, total, copy_tail);
+    for (auto& e : tr_ev) (void)hipEventDestroy(e);
+  }
   if (stats_host) {
     stats_host[0] = st[0]; stats_host[1] = n_opinv; stats_host[2] = restarts; stats_host[3] = st[3]; stats_host[4] = n_block;
     stats_host[5] = first_res; stats_host[6] = res; stats_host[7] = refined; stats_host[8] = perturbed;
